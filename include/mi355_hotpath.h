@@ -1,0 +1,232 @@
+/*
+ * libmi355_hotpath.so -- C ABI of the MI355X (gfx950 / CDNA4) SGLang hot path.
+ *
+ * Every entry point:
+ *   - takes plain device pointers, sizes and strides (in ELEMENTS unless a name says bytes)
+ *     and the hipStream_t to launch on (passed as void*; NULL = the null stream);
+ *   - returns 0 (MI355_OK) or a negative MI355_ERR_* code, never throws; the text of the
+ *     last error on the calling thread is available from mi355_last_error();
+ *   - validates shapes/dtypes/alignment on the host BEFORE launching anything;
+ *   - is asynchronous: no hipMalloc/hipFree, no host synchronisation, safe under HIP graph
+ *     capture; all scratch memory is passed in by the caller.
+ *
+ * "file:line" citations name the reference interface (under the reference checkout's root)
+ * that each entry point replaces.
+ */
+#ifndef MI355_HOTPATH_H_
+#define MI355_HOTPATH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_ERR_INVALID (-1)     /* bad argument: null pointer, negative size, misaligned */
+#define MI355_ERR_UNSUPPORTED (-2) /* dtype / head_dim / shape outside what the kernels cover */
+#define MI355_ERR_LAUNCH (-3)      /* hipGetLastError() after the launch was not hipSuccess */
+
+/* element type codes */
+#define MI355_F32 0
+#define MI355_BF16 1
+#define MI355_F16 2
+/* index type codes */
+#define MI355_I32 0
+#define MI355_I64 1
+
+#define MI355_ABI_VERSION 1
+int mi355_abi_version(void);
+const char* mi355_last_error(void);
+
+/* ---- K8  RMSNorm ------------------------------------------------------------------------
+ * out[r,:] = T( (x[r,:] * rsqrt(mean(x[r,:]^2) + eps)) * w ), fp32 math.
+ * replaces: RMSNorm.forward_native / forward_hip (python/sglang/srt/layers/layernorm.py:113-147),
+ *           sgl_kernel.rmsnorm (sgl-kernel/csrc/elementwise/ -> common_extension.cc:59),
+ *           rmsnorm_cpu (sgl-kernel/csrc/cpu/norm.cpp:68-134). */
+int mi355_rmsnorm(void* out, const void* x, const void* weight, int64_t rows, int64_t hidden,
+                  int64_t x_row_stride, int64_t out_row_stride, float eps, int dtype,
+                  void* stream);
+
+/* In place on BOTH tensors: s = f32(x)+f32(residual); residual = T(s);
+ * x = T( (s * rsqrt(mean(s^2)+eps)) * w ).
+ * replaces: layernorm.py:121-123,137-143; fused_add_rmsnorm
+ *           (sgl-kernel/csrc/elementwise/fused_add_rms_norm_kernel.cu:24-59). */
+int mi355_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t rows,
+                            int64_t hidden, float eps, int dtype, void* stream);
+
+/* ---- K10 SiLU-and-mul -------------------------------------------------------------------
+ * out[r, j] = T( f32(T(silu(x[r, j]))) * x[r, d + j] ), x is [rows, 2d] contiguous.
+ * replaces: SiluAndMul.forward_native/forward_cuda (python/sglang/srt/layers/activation.py:55-65),
+ *           silu_and_mul (sgl-kernel/csrc/elementwise/activation.cu:22-50). */
+int mi355_silu_and_mul(void* out, const void* x, int64_t rows, int64_t d, int dtype,
+                       void* stream);
+
+/* ---- K9 (+K7) RoPE from a cos|sin cache, in place, optional fused KV-cache write ----------
+ * q: [T, Hq, D] view with row stride q_stride; k: [T, Hkv, D] with k_stride; rotates the first
+ * rotary_dim of every head with cos_sin_cache[positions[t]] ([max_pos, rotary_dim], first half
+ * cos, second half sin; cache_dtype = MI355_F32 or the tensor dtype).  Rounding follows
+ * _apply_rotary_emb: cos/sin are cast to T, and every multiply/add rounds to T.
+ * If k_buffer != NULL also writes k (after rotation) and v rows to
+ * k_buffer[loc[t]] / v_buffer[loc[t]] ([slots, Hkv, D] contiguous) -- set_kv_buffer fused in.
+ * replaces: RotaryEmbedding.forward_native/forward_cuda (layers/rotary_embedding.py:138-166,
+ *           218-244), apply_rope_with_cos_sin_cache_inplace (sgl-kernel/csrc/elementwise/rope.cu:22-89),
+ *           MHATokenToKVPool.set_kv_buffer (mem_cache/memory_pool.py:420-458). */
+int mi355_rope_inplace(void* q, void* k, const void* v, const int64_t* positions,
+                       const void* cos_sin_cache, int cache_dtype, int64_t tokens, int hq,
+                       int hkv, int head_dim, int rotary_dim, int64_t q_stride, int64_t k_stride,
+                       int64_t v_stride, int is_neox, void* k_buffer, void* v_buffer,
+                       const void* loc, int loc_itype, int64_t num_slots, int dtype, void* stream);
+
+/* ---- K7 KV-cache write --------------------------------------------------------------------
+ * k_buffer[loc[t], :, :] = k[t], v_buffer[loc[t]] = v[t]; row = heads*dim elements.
+ * replaces: MHATokenToKVPool.set_kv_buffer (mem_cache/memory_pool.py:420-458),
+ *           decode_set_kv_buffer (sgl-kernel/csrc/cpu/decode.cpp:770-809). */
+int mi355_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const void* v,
+                        const void* loc, int loc_itype, int64_t tokens, int64_t k_row_elems,
+                        int64_t v_row_elems, int64_t k_stride, int64_t v_stride,
+                        int64_t num_slots, int dtype, void* stream);
+
+/* ---- K15 embedding gather -----------------------------------------------------------------
+ * out[t,:] = (vocab_start <= ids[t] < vocab_end) ? table[ids[t]-vocab_start,:] : 0
+ * replaces: VocabParallelEmbedding.forward (layers/vocab_parallel_embedding.py:453-475). */
+int mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens,
+                    int64_t hidden, int64_t vocab_start, int64_t vocab_end, int dtype,
+                    void* stream);
+
+/* ---- K6 paged-KV index gather -------------------------------------------------------------
+ * kv_indices[kv_indptr[b] + j] = req_to_token[req_pool_indices[b], kv_start[b] + j],
+ * j < page_kernel_lens[b]  (kv_start_idx may be NULL = 0).
+ * replaces: create_flashinfer_kv_indices_triton (layers/attention/utils.py:5-41). */
+int mi355_create_kv_indices(const int32_t* req_to_token, const void* req_pool_indices,
+                            int pool_itype, const void* page_kernel_lens, int lens_itype,
+                            const int32_t* kv_indptr, const int32_t* kv_start_idx,
+                            int32_t* kv_indices, int64_t req_to_token_stride, int64_t bs,
+                            void* stream);
+
+/* ---- K16 req->token table write (extend) ---------------------------------------------------
+ * req_to_token[req_pool_indices[b], pre_lens[b] + j] = out_cache_loc[cumsum(extend_lens)[b] + j]
+ * replaces: write_req_to_token_pool_triton (managers/schedule_batch.py:1900-1934). */
+int mi355_write_req_to_token(int32_t* req_to_token, const int64_t* req_pool_indices,
+                             const int64_t* pre_lens, const int64_t* seq_lens,
+                             const int64_t* extend_lens, const int64_t* out_cache_loc,
+                             int64_t req_to_token_stride, int64_t bs, void* stream);
+
+/* ---- K17 positions for an extend batch -----------------------------------------------------
+ * positions[start[b] + j] = prefix_lens[b] + j, extend_start_loc[b] = start[b] = excl. cumsum.
+ * replaces: compute_position_triton/_torch (model_executor/forward_batch_info.py:703-773). */
+int mi355_compute_position(const int32_t* extend_prefix_lens, const int32_t* extend_seq_lens,
+                           int64_t* positions, int32_t* extend_start_loc, int64_t bs,
+                           void* stream);
+
+/* ---- decode step bookkeeping (one launch) ---------------------------------------------------
+ * seq_lens[b] += 1; positions[b] = max(seq_lens[b]-1, 0);
+ * req_to_token[req_pool_indices[b], seq_lens[b]-1] = out_cache_loc[b]
+ * replaces: ScheduleBatch.prepare_for_decode's tensor updates (managers/schedule_batch.py:1543-1573)
+ *           + clamp_position (forward_batch_info.py:776-778). */
+int mi355_prepare_decode(int32_t* req_to_token, const int64_t* req_pool_indices,
+                         int64_t* seq_lens, const int64_t* out_cache_loc, int64_t* positions,
+                         int64_t req_to_token_stride, int64_t bs, void* stream);
+
+/* ---- K1+K2 decode attention (split-KV flash decoding) ---------------------------------------
+ * q [B, Hq, D] with row stride q_stride (elements), o [B, Hq, Dv] contiguous; k_buffer/v_buffer [slots, Hkv, D|Dv] contiguous.
+ * The KV slots of sequence b are page_table[page_off(b) + j], j < len(b), where
+ *   mode 0 (req_to_token, as decode_attention_cpu): page_off = req_pool_indices[b]*table_stride,
+ *          len = seq_lens[b]   (indptr unused)
+ *   mode 1 (kv_indices, as decode_attention_fwd):   page_off = kv_indptr[b],
+ *          len = kv_indptr[b+1]-kv_indptr[b]         (req_pool_indices/seq_lens unused)
+ * scratch: attn_logits fp32 [B, Hq, max_splits, Dv], attn_lse fp32 [B, Hq, max_splits]
+ * (unused when num_splits == 1).  logit_cap > 0 applies cap*tanh(s/cap).
+ * replaces: decode_attention_fwd (layers/attention/triton_ops/decode_attention.py:677-728),
+ *           decode_attention_cpu (sgl-kernel/csrc/cpu/decode.cpp:1375-1575),
+ *           TorchNativeAttnBackend._run_sdpa_forward_decode (torch_native_backend.py:112-180). */
+int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                           const int32_t* page_table, int mode, const int64_t* req_pool_indices,
+                           const int64_t* seq_lens, const int32_t* kv_indptr,
+                           int64_t table_stride, float* attn_logits, float* attn_lse,
+                           int num_splits, int64_t bs, int hq, int hkv, int head_dim,
+                           int v_head_dim, int64_t q_stride, int64_t num_slots, float sm_scale,
+                           float logit_cap, int dtype, void* stream);
+
+/* Number of KV splits mi355_decode_attention should be given for this batch (host-side
+ * planner; never exceeds max_splits).
+ * replaces: get_num_kv_splits_triton (layers/attention/triton_backend.py:875-924). */
+int mi355_decode_num_splits(int64_t bs, int hkv, int64_t max_seq_len, int max_splits);
+
+/* ---- K4 extend / prefill attention -----------------------------------------------------------
+ * q_extend [T, Hq, D], k_extend/v_extend [T, Hkv, D|Dv] (row strides given), o_extend [T,Hq,Dv]
+ * contiguous.  Sequence b owns rows qo_indptr[b]..qo_indptr[b+1]; its cached prefix is
+ * k_buffer[kv_indices[kv_indptr[b]..kv_indptr[b+1]]].  Phase 1 attends the prefix (no mask),
+ * phase 2 the new tokens (causal if is_causal).  custom_mask (uint8, may be NULL) follows the
+ * reference layout: mask_indptr[b] + row * (prefix+extend) + col, applied to phase 2 always
+ * and to phase 1 unless skip_prefix_custom_mask.  sliding_window_size < 0 = off.
+ * replaces: extend_attention_fwd (layers/attention/triton_ops/extend_attention.py:306-438),
+ *           extend_attention_cpu (sgl-kernel/csrc/cpu/extend.cpp:579-722),
+ *           TorchNativeAttnBackend._run_sdpa_forward_extend (torch_native_backend.py:27-110). */
+int mi355_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend,
+                           void* o_extend, const void* k_buffer, const void* v_buffer,
+                           const int32_t* qo_indptr, const int32_t* kv_indptr,
+                           const int32_t* kv_indices, const uint8_t* custom_mask,
+                           const int64_t* mask_indptr, int is_causal, int skip_prefix_custom_mask,
+                           int64_t bs, int64_t max_len_extend, int hq, int hkv, int head_dim,
+                           int v_head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                           int64_t num_slots, float sm_scale, float logit_cap,
+                           int sliding_window_size, int dtype, void* stream);
+
+/* ---- K12/K13 dense projection y = x @ W^T ------------------------------------------------------
+ * x [M, K] (row stride x_stride), W [N, K] contiguous (nn.Linear layout), y [M, N] contiguous.
+ * M <= 64 uses the weight-streaming MFMA kernel (bf16/f16) -- `workspace` must hold
+ * mi355_linear_workspace_bytes(M,N,K) bytes for its split-K slabs; fp32 uses an exact-fp32
+ * tiled kernel for any M.  out_dtype = dtype, or MI355_F32 to get T-rounded values widened to
+ * fp32 (the `.float()` of LogitsProcessor).  bias may be NULL.
+ * replaces: UnquantizedLinearMethod.apply / F.linear (layers/quantization/unquant.py:110-122),
+ *           LogitsProcessor._get_logits matmul (layers/logits_processor.py:453-455,490). */
+int64_t mi355_linear_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int mi355_linear(void* y, const void* x, const void* w, const void* bias, int64_t m, int64_t n,
+                 int64_t k, int64_t x_stride, void* workspace, int64_t workspace_bytes,
+                 int dtype, int out_dtype, void* stream);
+
+/* ---- K14 fp8 W8A8 ------------------------------------------------------------------------------
+ * Per-token dynamic quantisation to OCP e4m3fn (max 448): s[r] = max(absmax(x[r,:]), 1e-10)/448,
+ * q = clamp(x/s, +-448) -> fp8.
+ * replaces: per_token_group_quant_fp8 with group = K (layers/quantization/fp8_kernel.py:115-155,
+ *           fp8_utils.py:676-678), sgl_per_token_quant_fp8 (sgl-kernel/csrc/gemm/per_token_quant_fp8.cu). */
+int mi355_per_token_quant_fp8(uint8_t* xq, float* scales, const void* x, int64_t rows, int64_t k,
+                              int64_t x_stride, int dtype, void* stream);
+
+/* y[m,n] = T( (sum_k fp8(xq[m,k]) * fp8(wq[n,k])) * x_scale[m] * w_scale[n] (+ bias[n]) ),
+ * wq is [N, K] e4m3fn (row per output channel), fp32 accumulation on the fp8 MFMA; bias (may be
+ * NULL) has the output dtype; workspace must hold mi355_fp8_workspace_bytes(m,n,k) bytes.
+ * replaces: apply_fp8_linear (layers/quantization/fp8_utils.py:510-749), fp8_scaled_mm
+ *           (sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu). */
+int64_t mi355_fp8_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int mi355_fp8_scaled_mm(void* y, const uint8_t* xq, const uint8_t* wq, const float* x_scale,
+                        const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
+                        void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
+
+/* ---- K11 sampling --------------------------------------------------------------------------------
+ * ids[b] = first index of max(logits[b,:])   (torch.argmax tie rule)
+ * replaces: Sampler.forward greedy branch (layers/sampler.py:72-76). */
+int mi355_argmax(int64_t* ids, const float* logits, int64_t rows, int64_t vocab,
+                 int64_t row_stride, void* stream);
+
+/* In place: logits[b,:] = softmax(logits[b,:] / temperature[b])
+ * replaces: Sampler.forward lines 79-81 (layers/sampler.py). */
+int mi355_softmax_temperature(float* logits, const float* temperatures, int64_t rows,
+                              int64_t vocab, int64_t row_stride, void* stream);
+
+/* Joint top-k / top-p / min-p filter + one draw per row by inverse CDF over the kept set taken
+ * in index order, with the caller's uniform u[b] in [0,1).  A token is kept iff it is among the
+ * top_k largest probabilities AND the probability mass strictly above it is <= top_p AND
+ * (min_p == 0 or p >= min_p * pmax) -- the mask of top_k_top_p_min_p_sampling_from_probs_torch.
+ * replaces: top_k_top_p_min_p_sampling_from_probs_torch (layers/sampler.py:154-178),
+ *           top_k_top_p_sampling_from_probs / min_p_sampling_from_probs
+ *           (sgl-kernel/python/sgl_kernel/sampling.py, common_extension.cc:314-333). */
+int mi355_top_k_top_p_min_p_sample(int32_t* ids, const float* probs, const int32_t* top_ks,
+                                   const float* top_ps, const float* min_ps, const float* uniform,
+                                   int64_t rows, int64_t vocab, int64_t row_stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_HOTPATH_H_ */

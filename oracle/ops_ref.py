@@ -1,0 +1,220 @@
+"""Per-op CPU restatements (torch CPU tensors; any float dtype).  TEST INFRASTRUCTURE."""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# ---- layers/layernorm.py:128-147 RMSNorm.forward_native ------------------------------------
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float,
+            residual: Optional[torch.Tensor] = None):
+    orig = x.dtype
+    x = x.to(torch.float32)
+    if residual is not None:
+        x = x + residual.to(torch.float32)
+        residual = x.to(orig)
+    variance = x.pow(2).mean(dim=-1, keepdim=True)
+    x = x * torch.rsqrt(variance + eps)
+    x = (x * weight).to(orig)
+    return x if residual is None else (x, residual)
+
+
+# ---- layers/activation.py:55-58 SiluAndMul.forward_native -----------------------------------
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    d = x.shape[-1] // 2
+    return F.silu(x[..., :d]) * x[..., d:]
+
+
+# ---- layers/rotary_embedding.py:113-136 cache, :806-827 llama3 inverse frequencies -----------
+def rope_inv_freq(rotary_dim: int, base: float, llama3: Optional[dict] = None) -> torch.Tensor:
+    inv = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))
+    if llama3 is None:
+        return inv
+    orig = llama3["original_max_position_embeddings"]
+    lo_f, hi_f, factor = llama3["low_freq_factor"], llama3["high_freq_factor"], llama3["factor"]
+    low_wavelen, high_wavelen = orig / lo_f, orig / hi_f
+    wave_len = 2 * math.pi / inv
+    smooth = (orig / wave_len - lo_f) / (hi_f - lo_f) if lo_f != hi_f else 0
+    return torch.where(wave_len < high_wavelen, inv,
+                       torch.where(wave_len > low_wavelen, inv / factor,
+                                   (1 - smooth) * inv / factor + smooth * inv))
+
+
+def cos_sin_cache(rotary_dim: int, max_pos: int, base: float, llama3: Optional[dict] = None,
+                  dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    t = torch.arange(max_pos, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, rope_inv_freq(rotary_dim, base, llama3))
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+
+
+# ---- layers/rotary_embedding.py:49-75 _apply_rotary_emb, :138-166 forward_native ------------
+def _rotate(x, cos, sin, is_neox):
+    cos = cos.unsqueeze(-2).to(x.dtype)
+    sin = sin.unsqueeze(-2).to(x.dtype)
+    if is_neox:
+        x1, x2 = torch.chunk(x, 2, dim=-1)
+    else:
+        x1, x2 = x[..., ::2], x[..., 1::2]
+    o1 = x1 * cos - x2 * sin
+    o2 = x2 * cos + x1 * sin
+    if is_neox:
+        return torch.cat((o1, o2), dim=-1)
+    return torch.stack((o1, o2), dim=-1).flatten(-2)
+
+
+def apply_rope(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+               cache: torch.Tensor, is_neox: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    positions = positions.flatten()
+    n = positions.shape[0]
+    rotary_dim = cache.shape[1]
+    cos, sin = cache.index_select(0, positions).chunk(2, dim=-1)
+
+    def one(x):
+        shape = x.shape
+        x = x.reshape(n, -1, head_size)
+        rot = _rotate(x[..., :rotary_dim], cos, sin, is_neox)
+        return torch.cat((rot, x[..., rotary_dim:]), dim=-1).reshape(shape)
+
+    return one(query), one(key)
+
+
+# ---- layers/attention/torch_native_backend.py:112-180 decode, :27-110 extend ----------------
+def decode_attention(q, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens, scaling,
+                     enable_gqa: bool) -> torch.Tensor:
+    """q [B, Hq, D]; caches [slots, Hkv, D]; returns [B, Hq, Dv]."""
+    out = torch.empty((q.shape[0], q.shape[1], v_cache.shape[-1]), dtype=q.dtype)
+    qh = q.movedim(0, 1)  # [Hq, B, D]
+    for i in range(seq_lens.shape[0]):
+        toks = req_to_token[req_pool_indices[i], : seq_lens[i]].long()
+        k = k_cache[toks].movedim(0, 1)
+        v = v_cache[toks].movedim(0, 1)
+        o = F.scaled_dot_product_attention(qh[:, i:i + 1].unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0),
+                                           enable_gqa=enable_gqa, scale=scaling, is_causal=False)
+        out[i] = o.squeeze(0).movedim(1, 0)[0]
+    return out
+
+
+def extend_attention(q, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens,
+                     extend_prefix_lens, extend_seq_lens, scaling, enable_gqa: bool,
+                     causal: bool = True) -> torch.Tensor:
+    """q [T, Hq, D] (new tokens, all sequences concatenated); K/V of the new tokens must already
+    be in the caches.  The reference pads q with `prefix` junk rows so that is_causal lines up
+    (:81-87); only the real rows are kept."""
+    out = torch.empty((q.shape[0], q.shape[1], v_cache.shape[-1]), dtype=q.dtype)
+    qh = q.movedim(0, 1)
+    start = 0
+    for i in range(seq_lens.shape[0]):
+        ext, pre, total = int(extend_seq_lens[i]), int(extend_prefix_lens[i]), int(seq_lens[i])
+        qq = torch.zeros((qh.shape[0], total, qh.shape[2]), dtype=q.dtype)
+        qq[:, pre:, :] = qh[:, start:start + ext]
+        toks = req_to_token[req_pool_indices[i], :total].long()
+        k = k_cache[toks].movedim(0, 1)
+        v = v_cache[toks].movedim(0, 1)
+        o = F.scaled_dot_product_attention(qq.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0),
+                                           enable_gqa=enable_gqa, scale=scaling, is_causal=causal)
+        out[start:start + ext] = o.squeeze(0).movedim(1, 0)[pre:]
+        start += ext
+    return out
+
+
+def attention_fp64(q, k, v, scaling, causal_offset: Optional[int] = None, logit_cap: float = 0.0):
+    """Plain softmax(q k^T) v in float64 for shapes/features SDPA does not cover (logit cap,
+    custom masks): q [Hq, Lq, D], k/v [Hkv, S, D*]; row i sees keys <= i + causal_offset."""
+    g = q.shape[0] // k.shape[0]
+    k = k.repeat_interleave(g, 0).double()
+    v = v.repeat_interleave(g, 0).double()
+    s = torch.einsum("hqd,hkd->hqk", q.double(), k) * scaling
+    if logit_cap > 0:
+        s = logit_cap * torch.tanh(s / logit_cap)
+    if causal_offset is not None:
+        S, Lq = k.shape[1], q.shape[1]
+        keep = torch.arange(S)[None, :] <= torch.arange(Lq)[:, None] + causal_offset
+        s = s.masked_fill(~keep, float("-inf"))
+    return torch.einsum("hqk,hkd->hqd", torch.softmax(s, -1), v)
+
+
+# ---- layers/attention/utils.py:5-41, managers/schedule_batch.py:1287-1294,1571-1573 ----------
+def create_kv_indices(req_to_token, req_pool_indices, lens, kv_start=None) -> torch.Tensor:
+    parts = []
+    for i in range(len(req_pool_indices)):
+        s = 0 if kv_start is None else int(kv_start[i])
+        parts.append(req_to_token[req_pool_indices[i], s: s + int(lens[i])])
+    return torch.cat(parts) if parts else torch.empty(0, dtype=torch.int32)
+
+
+def write_req_to_token(req_to_token, req_pool_indices, prefix_lens, seq_lens, out_cache_loc):
+    pt = 0
+    for i in range(len(req_pool_indices)):
+        n = int(seq_lens[i]) - int(prefix_lens[i])
+        req_to_token[req_pool_indices[i], int(prefix_lens[i]): int(seq_lens[i])] = out_cache_loc[pt: pt + n].to(torch.int32)
+        pt += n
+
+
+# ---- model_executor/forward_batch_info.py:759-778 ---------------------------------------------
+def compute_position(extend_prefix_lens, extend_seq_lens):
+    positions = torch.cat([torch.arange(int(p), int(p) + int(e)) for p, e in zip(extend_prefix_lens, extend_seq_lens)])
+    start = torch.zeros_like(extend_seq_lens)
+    start[1:] = torch.cumsum(extend_seq_lens[:-1], dim=0)
+    return positions.to(torch.int64), start
+
+
+def clamp_position(seq_lens):
+    return torch.clamp(seq_lens - 1, min=0).to(torch.int64)
+
+
+# ---- layers/sampler.py:72-82, 154-178 ------------------------------------------------------------
+def greedy(logits: torch.Tensor) -> torch.Tensor:
+    return torch.argmax(logits, -1)
+
+
+def softmax_temperature(logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
+    return torch.softmax(logits / temperatures.view(-1, 1), dim=-1)
+
+
+def top_k_top_p_min_p_filter(probs, top_ks, top_ps, min_ps=None):
+    """The masked, SORTED probabilities and their vocabulary indices exactly as
+    top_k_top_p_min_p_sampling_from_probs_torch builds them before torch.multinomial."""
+    probs_sort, probs_idx = probs.sort(dim=-1, descending=True)
+    probs_sum = torch.cumsum(probs_sort, dim=-1)
+    probs_sort[torch.arange(0, probs.shape[-1]).view(1, -1) >= top_ks.view(-1, 1)] = 0.0
+    probs_sort[(probs_sum - probs_sort) > top_ps.view(-1, 1)] = 0.0
+    if min_ps is not None:
+        thr = probs_sort[:, 0] * min_ps
+        probs_sort[probs_sort < thr.view(-1, 1)] = 0.0
+    return probs_sort, probs_idx
+
+
+def top_k_top_p_min_p_sampling_from_probs(probs, top_ks, top_ps, min_ps=None):
+    probs_sort, probs_idx = top_k_top_p_min_p_filter(probs.clone(), top_ks, top_ps, min_ps)
+    sampled = torch.multinomial(probs_sort, num_samples=1)
+    return torch.gather(probs_idx.to(torch.int32), dim=1, index=sampled).view(-1)
+
+
+def kept_distribution(probs, top_ks, top_ps, min_ps=None):
+    """Renormalised distribution over the vocabulary that the reference sampler draws from."""
+    ps, pi = top_k_top_p_min_p_filter(probs.clone(), top_ks, top_ps, min_ps)
+    ps = ps / ps.sum(-1, keepdim=True)
+    return torch.zeros_like(ps).scatter_(-1, pi, ps)
+
+
+# ---- layers/quantization/fp8_kernel.py:144-155, fp8_utils.py:479-507 ---------------------------
+FP8_MAX = 448.0  # OCP e4m3fn (gfx950); fp8_kernel.py:71-85 picks fnuz only on gfx94x
+
+
+def per_token_quant_fp8(x: torch.Tensor):
+    y = x.to(torch.float32)
+    absmax = torch.clamp(y.abs().amax(dim=-1, keepdim=True), min=1e-10)
+    y_s = absmax / FP8_MAX
+    y_q = torch.clamp(y * (1.0 / y_s), -FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return y_q, y_s
+
+
+def fp8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias=None) -> torch.Tensor:
+    """wq [N, K] fp8, w_scale [N, 1] fp32: out = ((xq @ wq^T) * x_scale * w_scale^T (+bias)).to(x.dtype)."""
+    xq, xs = per_token_quant_fp8(x)
+    out = xq.to(torch.float32) @ wq.to(torch.float32).t()
+    out = out * xs * w_scale.t()
+    if bias is not None:
+        out = out + bias
+    return out.to(x.dtype)

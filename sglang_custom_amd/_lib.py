@@ -1,0 +1,84 @@
+"""ctypes binding of libmi355_hotpath.so (the C ABI declared in include/mi355_hotpath.h).
+
+The library is the product path: if it is missing or fails to load, importing the ops raises --
+there is no CPU or PyTorch fallback behind these functions.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_hotpath.so")
+
+MI355_OK = 0
+F32, BF16, F16 = 0, 1, 2
+I32, I64 = 0, 1
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); mirrors include/mi355_hotpath.h one to one
+_SIGNATURES = {
+    "mi355_abi_version": (I, []),
+    "mi355_last_error": (c_char_p, []),
+    "mi355_rmsnorm": (I, [P, P, P, L, L, L, L, F, I, P]),
+    "mi355_fused_add_rmsnorm": (I, [P, P, P, L, L, F, I, P]),
+    "mi355_silu_and_mul": (I, [P, P, L, L, I, P]),
+    "mi355_rope_inplace": (I, [P, P, P, P, P, I, L, I, I, I, I, L, L, L, I, P, P, P, I, L, I, P]),
+    "mi355_set_kv_buffer": (I, [P, P, P, P, P, I, L, L, L, L, L, L, I, P]),
+    "mi355_embedding": (I, [P, P, P, L, L, L, L, I, P]),
+    "mi355_create_kv_indices": (I, [P, P, I, P, I, P, P, P, L, L, P]),
+    "mi355_write_req_to_token": (I, [P, P, P, P, P, P, L, L, P]),
+    "mi355_compute_position": (I, [P, P, P, P, L, P]),
+    "mi355_prepare_decode": (I, [P, P, P, P, P, L, L, P]),
+    "mi355_decode_attention": (I, [P, P, P, P, P, I, P, P, P, L, P, P, I, L, I, I, I, I, L, L, F, F, I, P]),
+    "mi355_decode_num_splits": (I, [L, I, L, I]),
+    "mi355_extend_attention": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, I, L, L, L,
+                                   L, F, F, I, I, P]),
+    "mi355_linear_workspace_bytes": (L, [L, L, L]),
+    "mi355_linear": (I, [P, P, P, P, L, L, L, L, P, L, I, I, P]),
+    "mi355_per_token_quant_fp8": (I, [P, P, P, L, L, L, I, P]),
+    "mi355_fp8_workspace_bytes": (L, [L, L, L]),
+    "mi355_fp8_scaled_mm": (I, [P, P, P, P, P, P, L, L, L, P, L, I, P]),
+    "mi355_argmax": (I, [P, P, L, L, L, P]),
+    "mi355_softmax_temperature": (I, [P, P, L, L, L, P]),
+    "mi355_top_k_top_p_min_p_sample": (I, [P, P, P, P, P, P, L, L, L, P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once and type every entry point.  Raises if anything the
+    header declares is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Mi355Error(
+            f"{LIB_PATH} not found: build it with `python -m sglang_custom_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    # torch (if used by the caller) must be imported first so that its libamdhip64.so.7 is the
+    # one HIP runtime in the process; stream handles are only meaningful within one runtime.
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise Mi355Error(f"{LIB_PATH} does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mi355_abi_version() != 1:
+        raise Mi355Error("libmi355_hotpath.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != MI355_OK:
+        msg = load().mi355_last_error()
+        raise Mi355Error(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,406 @@
+// Extend / prefill attention: new tokens attend to (1) their sequence's cached prefix, gathered
+// through kv_indices from the paged KV cache, and (2) the new tokens themselves (causal
+// triangle), with one online softmax across both phases.
+//
+// Structure: a workgroup (4 waves) owns a tile of 64 "rows" = TM query tokens x Gc query heads
+// that share one kv head, so every K/V tile staged in LDS is reused by all heads of the group.
+// K/V tiles of BN keys are gathered with 16-byte loads into padded LDS rows (bank-conflict free
+// for the access patterns below).  Scores and P.V are register-blocked fp32 VALU FMAs (each lane
+// a 4 x KJ score block, then a 4 x DPL output block), which keeps exact-fp32 accumulation for
+// every dtype -- this is also the fp32 parity path.  Row max uses xor-shuffles across the 16
+// lanes that share a row; the row sum is reduced once at the end.
+#include "common.cuh"
+#include <math.h>
+
+namespace mi355 {
+
+static constexpr float kLog2eE = 1.4426950408889634f;
+
+struct ExtendParams {
+  const int32_t* qo_indptr;
+  const int32_t* kv_indptr;
+  const int32_t* kv_indices;
+  const uint8_t* custom_mask;
+  const int64_t* mask_indptr;
+  int64_t q_stride, k_stride, v_stride;
+  int is_causal, skip_prefix_custom_mask, hq, hkv, D, Dv, sliding_window;
+  float sm_scale, logit_cap;
+};
+
+// DP: padded head dim (>= D, Dv; multiple of 64). BN: keys per tile. VEC: 16-B global loads.
+template <typename T, int DP, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void extend_attn_kernel(const T* __restrict__ q_ext,
+                                                          const T* __restrict__ k_ext,
+                                                          const T* __restrict__ v_ext,
+                                                          T* __restrict__ o_ext,
+                                                          const T* __restrict__ kbuf,
+                                                          const T* __restrict__ vbuf,
+                                                          ExtendParams p) {
+  constexpr int VE = V16<T>::n;
+  constexpr int LROW = DP + VE;          // padded LDS row (elements): +16 B
+  constexpr int KJ = BN / 16;            // keys per lane in the score block
+  constexpr int DPL = DP / 16;           // output features per lane
+  constexpr int PROW = BN + 4;           // padded P row (floats)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* qs = reinterpret_cast<T*>(smem_raw);            // [64][LROW]
+  T* ks = qs + 64 * LROW;                            // [BN][LROW]
+  T* vs = ks + BN * LROW;                            // [BN][LROW]
+  float* ps = reinterpret_cast<float*>(vs + BN * LROW);  // [64][PROW]
+
+  const int gtotal = p.hq / p.hkv;
+  const int Gc = gtotal < 64 ? gtotal : 64;
+  const int chunks_per_kv = gtotal / Gc;
+  const int TM = 64 / Gc;
+  const int kvh = blockIdx.y / chunks_per_kv;
+  const int head0 = kvh * gtotal + (blockIdx.y % chunks_per_kv) * Gc;
+  const int b = blockIdx.z;
+  const int q_start = p.qo_indptr[b];
+  const int ext_len = p.qo_indptr[b + 1] - q_start;
+  const int t0 = blockIdx.x * TM;
+  if (t0 >= ext_len) return;
+  const int kv_start = p.kv_indptr[b];
+  const int prefix_len = p.kv_indptr[b + 1] - kv_start;
+  const int seq_len = prefix_len + ext_len;
+  const int D = p.D, Dv = p.Dv;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, rg = lane >> 4;  // c16: key / feature column group; rg: row group
+
+  // rows of this lane: r_i = 16*wave + rg + 4*i
+  int row_tok[4], row_head[4];
+  bool row_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 16 * wave + rg + 4 * i;
+    row_tok[i] = r / Gc;
+    row_head[i] = r - row_tok[i] * Gc;
+    row_ok[i] = row_tok[i] < TM && t0 + row_tok[i] < ext_len;
+  }
+
+  // ---- stage Q (zero padded to DP, rows beyond the tile zero) ----
+  for (int pidx = threadIdx.x; pidx < 64 * (DP / VE); pidx += 256) {
+    const int r = pidx / (DP / VE), c = (pidx % (DP / VE)) * VE;
+    const int tq = r / Gc, g = r - tq * Gc;
+    Vec<T, VE> val;
+#pragma unroll
+    for (int j = 0; j < VE; ++j) val.v[j] = (T)0.f;
+    if (tq < TM && t0 + tq < ext_len) {
+      const T* src = q_ext + (int64_t)(q_start + t0 + tq) * p.q_stride + (int64_t)(head0 + g) * D;
+      if (VEC && c + VE <= D) {
+        val = ldvec<T, VE>(src + c);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j)
+          if (c + j < D) val.v[j] = src[c + j];
+      }
+    }
+    stvec<T, VE>(qs + r * LROW + c, val);
+  }
+
+  float m[4], l[4], acc[4][DPL];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m[i] = -INFINITY;
+    l[i] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) acc[i][d] = 0.f;
+  }
+
+  const bool cap = p.logit_cap > 0.f;
+  // keys of phase 2 this tile needs: causal -> up to its last token
+  const int tile_last_tok = (t0 + TM < ext_len ? t0 + TM : ext_len) - 1;
+  const int ext_keys = p.is_causal ? tile_last_tok + 1 : ext_len;
+
+  for (int phase = 0; phase < 2; ++phase) {
+    const int nkeys = phase == 0 ? prefix_len : ext_keys;
+    for (int kb = 0; kb < nkeys; kb += BN) {
+      __syncthreads();  // previous tile fully consumed (also covers the Q staging)
+      // ---- stage K and V tiles ----
+      for (int pidx = threadIdx.x; pidx < BN * (DP / VE); pidx += 256) {
+        const int kr = pidx / (DP / VE), c = (pidx % (DP / VE)) * VE;
+        const int key = kb + kr;
+        Vec<T, VE> kval, vval;
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          kval.v[j] = (T)0.f;
+          vval.v[j] = (T)0.f;
+        }
+        if (key < nkeys) {
+          const T *ksrc, *vsrc;
+          if (phase == 0) {
+            const int64_t slot = p.kv_indices[kv_start + key];
+            ksrc = kbuf + (slot * p.hkv + kvh) * (int64_t)D;
+            vsrc = vbuf + (slot * p.hkv + kvh) * (int64_t)Dv;
+          } else {
+            ksrc = k_ext + (int64_t)(q_start + key) * p.k_stride + (int64_t)kvh * D;
+            vsrc = v_ext + (int64_t)(q_start + key) * p.v_stride + (int64_t)kvh * Dv;
+          }
+          if (VEC && c + VE <= D) {
+            kval = ldvec<T, VE>(ksrc + c);
+          } else {
+#pragma unroll
+            for (int j = 0; j < VE; ++j)
+              if (c + j < D) kval.v[j] = ksrc[c + j];
+          }
+          if (VEC && c + VE <= Dv) {
+            vval = ldvec<T, VE>(vsrc + c);
+          } else {
+#pragma unroll
+            for (int j = 0; j < VE; ++j)
+              if (c + j < Dv) vval.v[j] = vsrc[c + j];
+          }
+        }
+        stvec<T, VE>(ks + kr * LROW + c, kval);
+        stvec<T, VE>(vs + kr * LROW + c, vval);
+      }
+      __syncthreads();
+
+      // ---- scores: s[i][j] = q[row_i] . k[key c16 + 16 j] ----
+      float s[4][KJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) s[i][j] = 0.f;
+      const T* qrow = qs + (16 * wave + rg) * LROW;
+      const T* krow = ks + c16 * LROW;
+#pragma unroll 1
+      for (int c = 0; c < DP; c += VE) {
+        float qf[4][VE], kf[KJ][VE];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Vec<T, VE> t = ldvec<T, VE>(qrow + 4 * i * LROW + c);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) qf[i][e] = to_f32(t.v[e]);
+        }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+          Vec<T, VE> t = ldvec<T, VE>(krow + 16 * j * LROW + c);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) kf[j][e] = to_f32(t.v[e]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < KJ; ++j)
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s[i][j] = fmaf(qf[i][e], kf[j][e], s[i][j]);
+      }
+
+      // ---- scale, cap, mask; online softmax ----
+      float alpha[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tq = t0 + row_tok[i];  // extend-local query index
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+          const int key = kb + c16 + 16 * j;
+          float x = s[i][j] * p.sm_scale;
+          if (cap) x = p.logit_cap * tanhf(x / p.logit_cap);
+          x *= kLog2eE;
+          bool keep = row_ok[i] && key < nkeys;
+          if (phase == 0) {
+            if (p.custom_mask && !p.skip_prefix_custom_mask && keep)
+              keep = p.custom_mask[p.mask_indptr[b] + (int64_t)tq * seq_len + key] != 0;
+            if (p.sliding_window > 0) keep = keep && tq <= key + p.sliding_window;
+          } else {
+            if (p.custom_mask) {
+              if (keep)
+                keep = p.custom_mask[p.mask_indptr[b] + (int64_t)tq * seq_len + prefix_len + key] != 0;
+            } else if (p.is_causal) {
+              keep = keep && key <= tq;
+            }
+          }
+          x = keep ? x : -INFINITY;
+          s[i][j] = x;
+          mx = fmaxf(mx, x);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float mnew = fmaxf(m[i], mx);
+        const float ms = mnew == -INFINITY ? 0.f : mnew;
+        alpha[i] = exp2f(m[i] - ms);
+        m[i] = mnew;
+        float psum = 0.f;
+        float* prow = ps + (16 * wave + rg + 4 * i) * PROW;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+          const float pe = exp2f(s[i][j] - ms);
+          psum += pe;
+          prow[c16 + 16 * j] = pe;
+        }
+        l[i] = l[i] * alpha[i] + psum;
+      }
+      __syncthreads();  // P visible (only same-wave rows are read, barrier keeps it simple)
+
+      // ---- acc[i][d] = acc*alpha + sum_key P[row_i][key] * V[key][c16*DPL + d] ----
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) acc[i][d] *= alpha[i];
+      const float* pbase = ps + (16 * wave + rg) * PROW;
+      const T* vcol = vs + c16 * DPL;
+#pragma unroll 1
+      for (int k4 = 0; k4 < BN; k4 += 4) {
+        float pf[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 t = *reinterpret_cast<const float4*>(pbase + 4 * i * PROW + k4);
+          pf[i][0] = t.x; pf[i][1] = t.y; pf[i][2] = t.z; pf[i][3] = t.w;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          float vf[DPL];
+          if constexpr (DPL >= VE) {
+#pragma unroll
+            for (int d0 = 0; d0 < DPL; d0 += VE) {
+              Vec<T, VE> t = ldvec<T, VE>(vcol + (k4 + kk) * LROW + d0);
+#pragma unroll
+              for (int e = 0; e < VE; ++e) vf[d0 + e] = to_f32(t.v[e]);
+            }
+          } else {
+            Vec<T, DPL> t = ldvec<T, DPL>(vcol + (k4 + kk) * LROW);
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) vf[e] = to_f32(t.v[e]);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) acc[i][d] = fmaf(pf[i][kk], vf[d], acc[i][d]);
+        }
+      }
+    }
+  }
+
+  // ---- finish: reduce row sums over the 16 lanes of a row, normalise, store ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lt = l[i];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) lt += __shfl_xor(lt, off, 64);
+    if (!row_ok[i]) continue;
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    T* dst = o_ext + ((int64_t)(q_start + t0 + row_tok[i]) * p.hq + head0 + row_head[i]) * Dv +
+             c16 * DPL;
+    if (VEC && c16 * DPL + DPL <= Dv) {
+      Vec<T, DPL> out;
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) out.v[d] = from_f32<T>(acc[i][d] * inv);
+      stvec<T, DPL>(dst, out);
+    } else {
+#pragma unroll
+      for (int d = 0; d < DPL; ++d)
+        if (c16 * DPL + d < Dv) dst[d] = from_f32<T>(acc[i][d] * inv);
+    }
+  }
+}
+
+template <typename T, int DP, int BN>
+static int launch_extend_cfg(const void* q, const void* k, const void* v, void* o, const void* kb,
+                             const void* vb, const ExtendParams& p, int64_t bs,
+                             int64_t max_len_extend, bool vec, hipStream_t st) {
+  constexpr int VE = V16<T>::n;
+  const int gtotal = p.hq / p.hkv;
+  const int Gc = gtotal < 64 ? gtotal : 64;
+  const int TM = 64 / Gc;
+  const dim3 grid((unsigned)((max_len_extend + TM - 1) / TM), (unsigned)(p.hkv * (gtotal / Gc)),
+                  (unsigned)bs);
+  const size_t lds = (size_t)(64 + 2 * BN) * (DP + VE) * sizeof(T) + (size_t)64 * (BN + 4) * 4;
+  if (vec) {
+    auto kern = extend_attn_kernel<T, DP, BN, true>;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, (T*)o,
+                       (const T*)kb, (const T*)vb, p);
+  } else {
+    auto kern = extend_attn_kernel<T, DP, BN, false>;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, (T*)o,
+                       (const T*)kb, (const T*)vb, p);
+  }
+  return MI355_OK;
+}
+
+template <typename T>
+static int launch_extend(const void* q, const void* k, const void* v, void* o, const void* kb,
+                         const void* vb, const ExtendParams& p, int64_t bs, int64_t max_len_extend,
+                         hipStream_t st) {
+  constexpr int VE = V16<T>::n;
+  const int dmax = p.D > p.Dv ? p.D : p.Dv;
+  const bool vec = p.D % VE == 0 && p.Dv % VE == 0 && p.q_stride % VE == 0 &&
+                   p.k_stride % VE == 0 && p.v_stride % VE == 0 && aligned16(q) && aligned16(k) &&
+                   aligned16(v) && aligned16(o) && aligned16(kb) && aligned16(vb);
+  if (dmax <= 64) return launch_extend_cfg<T, 64, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
+  if (dmax <= 128) return launch_extend_cfg<T, 128, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
+  if (dmax <= 256) {
+    if (sizeof(T) == 4)
+      return launch_extend_cfg<T, 256, 32>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
+    return launch_extend_cfg<T, 256, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
+  }
+  set_error("extend_attention: head_dim %d / v_head_dim %d > 256 not supported", p.D, p.Dv);
+  return MI355_ERR_UNSUPPORTED;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+int mi355_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend,
+                           void* o_extend, const void* k_buffer, const void* v_buffer,
+                           const int32_t* qo_indptr, const int32_t* kv_indptr,
+                           const int32_t* kv_indices, const uint8_t* custom_mask,
+                           const int64_t* mask_indptr, int is_causal, int skip_prefix_custom_mask,
+                           int64_t bs, int64_t max_len_extend, int hq, int hkv, int head_dim,
+                           int v_head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                           int64_t num_slots, float sm_scale, float logit_cap,
+                           int sliding_window_size, int dtype, void* stream) {
+  MI355_REQUIRE(q_extend && k_extend && v_extend && o_extend && qo_indptr && kv_indptr,
+                MI355_ERR_INVALID, "extend_attention: null pointer");
+  MI355_REQUIRE(k_buffer && v_buffer && kv_indices, MI355_ERR_INVALID,
+                "extend_attention: k_buffer/v_buffer/kv_indices must be valid pointers (may be "
+                "unused when every prefix is empty, but must not be null)");
+  MI355_REQUIRE(!custom_mask || mask_indptr, MI355_ERR_INVALID,
+                "extend_attention: custom_mask needs mask_indptr");
+  MI355_REQUIRE(bs >= 0 && max_len_extend >= 0 && hq > 0 && hkv > 0 && hq % hkv == 0 &&
+                    head_dim > 0 && v_head_dim > 0,
+                MI355_ERR_INVALID, "extend_attention: bad shape");
+  const int gtotal = hq / hkv;
+  MI355_REQUIRE(gtotal <= 64 ? true : gtotal % 64 == 0, MI355_ERR_UNSUPPORTED,
+                "extend_attention: q heads per kv head (%d) must be <= 64 or a multiple of 64",
+                gtotal);
+  MI355_REQUIRE(q_stride >= (int64_t)hq * head_dim && k_stride >= (int64_t)hkv * head_dim &&
+                    v_stride >= (int64_t)hkv * v_head_dim,
+                MI355_ERR_INVALID, "extend_attention: row strides smaller than rows");
+  MI355_REQUIRE(bs <= 65535, MI355_ERR_UNSUPPORTED, "extend_attention: batch > 65535");
+  if (bs == 0 || max_len_extend == 0) return MI355_OK;
+  ExtendParams p;
+  p.qo_indptr = qo_indptr;
+  p.kv_indptr = kv_indptr;
+  p.kv_indices = kv_indices;
+  p.custom_mask = custom_mask;
+  p.mask_indptr = mask_indptr;
+  p.q_stride = q_stride;
+  p.k_stride = k_stride;
+  p.v_stride = v_stride;
+  p.is_causal = is_causal;
+  p.skip_prefix_custom_mask = skip_prefix_custom_mask;
+  p.hq = hq;
+  p.hkv = hkv;
+  p.D = head_dim;
+  p.Dv = v_head_dim;
+  p.sliding_window = sliding_window_size;
+  p.sm_scale = sm_scale;
+  p.logit_cap = logit_cap;
+  int rc = MI355_OK;
+  MI355_DISPATCH_DTYPE(dtype, "extend_attention",
+                       rc = launch_extend<T>(q_extend, k_extend, v_extend, o_extend, k_buffer,
+                                             v_buffer, p, bs, max_len_extend, (hipStream_t)stream));
+  if (rc != MI355_OK) return rc;
+  MI355_CHECK_LAUNCH("extend_attention");
+  return MI355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Shared device/host helpers for the MI355X (gfx950, CDNA4) hot-path kernels.
+// wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mi355_hotpath.h"
+
+namespace mi355 {
+
+using bf16_t = __bf16;      // native bf16: cast to/from float rounds to nearest even, keeps NaN
+using f16_t = _Float16;
+
+template <typename T> struct DType;
+template <> struct DType<float> { static constexpr int code = MI355_F32; };
+template <> struct DType<bf16_t> { static constexpr int code = MI355_BF16; };
+template <> struct DType<f16_t> { static constexpr int code = MI355_F16; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+// "Round through T": what a torch elementwise op on dtype T does to an fp32 intermediate.
+template <typename T> __device__ __forceinline__ float round_to(float x) { return (float)(T)x; }
+template <> __device__ __forceinline__ float round_to<float>(float x) { return x; }
+// bf16: done on the bits (round to nearest even, NaN kept).  A (float)(__bf16)x round trip in
+// registers is NOT safe: clang's default bf16 "excess precision" mode may drop the rounding.
+template <> __device__ __forceinline__ float round_to<bf16_t>(float x) {
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+
+// N contiguous elements moved with one memory instruction (N * sizeof(T) in {4,8,16}).
+template <typename T, int N> struct alignas(sizeof(T) * N) Vec {
+  T v[N];
+};
+template <typename T, int N> __device__ __forceinline__ Vec<T, N> ldvec(const T* p) {
+  return *reinterpret_cast<const Vec<T, N>*>(p);
+}
+template <typename T, int N> __device__ __forceinline__ void stvec(T* p, const Vec<T, N>& x) {
+  *reinterpret_cast<Vec<T, N>*>(p) = x;
+}
+// Elements per 16-byte access.
+template <typename T> struct V16 { static constexpr int n = 16 / sizeof(T); };
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+  return x;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float x, float* red) {
+  x = wave_sum(x);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();  // protect `red` against a previous use
+  if (lane == 0) red[w] = x;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];  // same order in every thread: identical result
+  return t;
+}
+
+// ---- host side -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define MI355_REQUIRE(cond, code, ...)      \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::mi355::set_error(__VA_ARGS__);      \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+// After a launch: report (never sync).
+#define MI355_CHECK_LAUNCH(name)                                                   \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      ::mi355::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+      return MI355_ERR_LAUNCH;                                                     \
+    }                                                                              \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+__host__ __device__ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Dispatch a lambda templated on the element type.
+#define MI355_DISPATCH_DTYPE(dtype, NAME, ...)                               \
+  switch (dtype) {                                                           \
+    case MI355_F32: { using T = float; __VA_ARGS__; break; }                 \
+    case MI355_BF16: { using T = ::mi355::bf16_t; __VA_ARGS__; break; }      \
+    case MI355_F16: { using T = ::mi355::f16_t; __VA_ARGS__; break; }        \
+    default:                                                                 \
+      ::mi355::set_error("%s: unsupported dtype code %d", NAME, (int)dtype); \
+      return MI355_ERR_UNSUPPORTED;                                          \
+  }
+
+}  // namespace mi355

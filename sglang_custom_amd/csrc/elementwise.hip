@@ -1,0 +1,451 @@
+// Bandwidth-bound row kernels: RMSNorm, fused add+RMSNorm, SiLU-and-mul, RoPE (+KV write),
+// KV-cache scatter, embedding gather.  All use 16-byte vector accesses when the row length
+// and pointers allow it and fall back to scalar accesses otherwise.
+#include "common.cuh"
+#include <algorithm>
+
+namespace mi355 {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm.  One workgroup per row.  The row is held in registers between the sum-of-squares
+// pass and the scale pass when it fits (CHUNKS vectors per thread), so HBM sees each element
+// once; longer rows are re-read (from L2).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool ADD, int CHUNKS>
+__global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ x,
+                                                          T* __restrict__ residual,
+                                                          const T* __restrict__ w, int64_t hidden,
+                                                          int64_t x_stride, int64_t out_stride,
+                                                          float eps) {
+  constexpr int VE = V16<T>::n;
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  T* xr = x + row * x_stride;
+  T* rr = ADD ? residual + row * hidden : nullptr;
+  T* orow = out + row * out_stride;
+  const int nvec = (int)(hidden / VE);
+  float vals[CHUNKS][VE];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int vi = threadIdx.x + c * 256;
+    if (vi < nvec) {
+      Vec<T, VE> a = ldvec<T, VE>(xr + (int64_t)vi * VE);
+      if (ADD) {
+        Vec<T, VE> b = ldvec<T, VE>(rr + (int64_t)vi * VE);
+        Vec<T, VE> s;
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          float f = to_f32(a.v[j]) + to_f32(b.v[j]);
+          vals[c][j] = f;
+          s.v[j] = from_f32<T>(f);
+        }
+        stvec<T, VE>(rr + (int64_t)vi * VE, s);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) vals[c][j] = to_f32(a.v[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < VE; ++j) ss += vals[c][j] * vals[c][j];
+    }
+  }
+  ss = block_sum(ss, red);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int vi = threadIdx.x + c * 256;
+    if (vi < nvec) {
+      Vec<T, VE> wv = ldvec<T, VE>(w + (int64_t)vi * VE);
+      Vec<T, VE> o;
+#pragma unroll
+      for (int j = 0; j < VE; ++j) o.v[j] = from_f32<T>((vals[c][j] * inv) * to_f32(wv.v[j]));
+      stvec<T, VE>(orow + (int64_t)vi * VE, o);
+    }
+  }
+}
+
+// Any hidden size / alignment; two passes over the row (second pass re-reads from L2).
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_generic_kernel(T* __restrict__ out,
+                                                              const T* __restrict__ x,
+                                                              const T* __restrict__ w,
+                                                              int64_t hidden, int64_t x_stride,
+                                                              int64_t out_stride, float eps) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const T* xr = x + row * x_stride;
+  T* orow = out + row * out_stride;
+  float ss = 0.f;
+  for (int64_t i = threadIdx.x; i < hidden; i += 256) {
+    const float f = to_f32(xr[i]);
+    ss += f * f;
+  }
+  ss = block_sum(ss, red);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  for (int64_t i = threadIdx.x; i < hidden; i += 256)
+    orow[i] = from_f32<T>((to_f32(xr[i]) * inv) * to_f32(w[i]));
+}
+
+// Generic ADD variant that keeps the unrounded fp32 sum: pass 1 computes the sum of squares
+// from the inputs WITHOUT storing; pass 2 re-reads both inputs, stores residual and output.
+template <typename T>
+__global__ __launch_bounds__(256) void fused_add_rmsnorm_generic_kernel(T* __restrict__ x,
+                                                                        T* __restrict__ residual,
+                                                                        const T* __restrict__ w,
+                                                                        int64_t hidden, float eps) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  T* xr = x + row * hidden;
+  T* rr = residual + row * hidden;
+  float ss = 0.f;
+  for (int64_t i = threadIdx.x; i < hidden; i += 256) {
+    float f = to_f32(xr[i]) + to_f32(rr[i]);
+    ss += f * f;
+  }
+  ss = block_sum(ss, red);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  for (int64_t i = threadIdx.x; i < hidden; i += 256) {
+    float f = to_f32(xr[i]) + to_f32(rr[i]);
+    rr[i] = from_f32<T>(f);
+    xr[i] = from_f32<T>((f * inv) * to_f32(w[i]));
+  }
+}
+
+template <typename T, bool ADD>
+static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, int64_t hidden,
+                          int64_t x_stride, int64_t out_stride, float eps, hipStream_t st) {
+  constexpr int VE = V16<T>::n;
+  const bool vec_ok = hidden % VE == 0 && x_stride % VE == 0 && out_stride % VE == 0 &&
+                      aligned16(out) && aligned16(x) && aligned16(w) &&
+                      (!ADD || aligned16(residual));
+  const int64_t nvec = hidden / VE;
+  dim3 grid((unsigned)rows), block(256);
+  if (vec_ok && nvec <= 256 * 8) {
+    const int chunks = (int)((nvec + 255) / 256);
+#define LAUNCH(C)                                                                              \
+  hipLaunchKernelGGL((rmsnorm_vec_kernel<T, ADD, C>), grid, block, 0, st, out, x, residual, w, \
+                     hidden, x_stride, out_stride, eps)
+    if (chunks <= 1) LAUNCH(1);
+    else if (chunks <= 2) LAUNCH(2);
+    else if (chunks <= 4) LAUNCH(4);
+    else LAUNCH(8);
+#undef LAUNCH
+  } else if (ADD) {
+    hipLaunchKernelGGL((fused_add_rmsnorm_generic_kernel<T>), grid, block, 0, st, x, residual, w,
+                       hidden, eps);
+  } else {
+    hipLaunchKernelGGL((rmsnorm_generic_kernel<T>), grid, block, 0, st, out, (const T*)x, w,
+                       hidden, x_stride, out_stride, eps);
+  }
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// SiLU-and-mul
+// ------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T silu_mul_one(T a, T b) {
+  const float x = to_f32(a);
+  const float s = round_to<T>(x / (1.0f + expf(-x)));  // F.silu on dtype T rounds here
+  return from_f32<T>(s * to_f32(b));
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void silu_and_mul_kernel(T* __restrict__ out,
+                                                           const T* __restrict__ x, int64_t rows,
+                                                           int64_t d) {
+  constexpr int VE = VEC ? V16<T>::n : 1;
+  const int64_t per_row = d / VE;
+  const int64_t total = rows * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per_row, c = (i - r * per_row) * VE;
+    const T* g = x + r * 2 * d + c;
+    Vec<T, VE> a = ldvec<T, VE>(g), b = ldvec<T, VE>(g + d), o;
+#pragma unroll
+    for (int j = 0; j < VE; ++j) o.v[j] = silu_mul_one<T>(a.v[j], b.v[j]);
+    stvec<T, VE>(out + r * d + c, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE (+ fused KV-cache write).  One workgroup per token.  Work items: for every q and k head,
+// rotary_dim/2 rotation pairs handled VE pairs at a time; then pass-through/k/v copies to the
+// cache.  Rounding mirrors torch elementwise ops on dtype T: cos,sin -> T; each product and
+// each sum rounds to T.
+// ------------------------------------------------------------------------------------------
+template <typename T, typename CT, typename LT>
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restrict__ k,
+                                                   const T* __restrict__ v,
+                                                   const int64_t* __restrict__ positions,
+                                                   const CT* __restrict__ cache, int hq, int hkv,
+                                                   int head_dim, int rotary_dim, int64_t q_stride,
+                                                   int64_t k_stride, int64_t v_stride, int is_neox,
+                                                   T* __restrict__ k_buffer,
+                                                   T* __restrict__ v_buffer,
+                                                   const LT* __restrict__ loc) {
+  const int64_t t = blockIdx.x;
+  const int64_t pos = positions[t];
+  const CT* cs = cache + pos * rotary_dim;
+  const int half = rotary_dim / 2;
+  T* qt = q + t * q_stride;
+  T* kt = k + t * k_stride;
+  const int nheads = hq + hkv;
+  const int64_t slot = k_buffer ? (int64_t)loc[t] : 0;
+  T* kdst = k_buffer ? k_buffer + slot * (int64_t)hkv * head_dim : nullptr;
+
+  for (int w = threadIdx.x; w < nheads * half; w += 256) {
+    const int h = w / half, i = w - h * half;
+    T* base = (h < hq) ? qt + (int64_t)h * head_dim : kt + (int64_t)(h - hq) * head_dim;
+    const int i1 = is_neox ? i : 2 * i, i2 = is_neox ? i + half : 2 * i + 1;
+    const float c = round_to<T>((float)cs[i]), s = round_to<T>((float)cs[half + i]);
+    const float x1 = to_f32(base[i1]), x2 = to_f32(base[i2]);
+    const float o1 = round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * s));
+    const float o2 = round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * s));
+    base[i1] = from_f32<T>(o1);
+    base[i2] = from_f32<T>(o2);
+    if (kdst && h >= hq) {
+      T* d = kdst + (int64_t)(h - hq) * head_dim;
+      d[i1] = from_f32<T>(o1);
+      d[i2] = from_f32<T>(o2);
+    }
+  }
+  if (k_buffer) {
+    // pass-through part of k (rotary_dim < head_dim) and all of v
+    const int pass = head_dim - rotary_dim;
+    for (int w = threadIdx.x; w < hkv * pass; w += 256) {
+      const int h = w / pass, i = rotary_dim + (w - h * pass);
+      kdst[(int64_t)h * head_dim + i] = kt[(int64_t)h * head_dim + i];
+    }
+    T* vdst = v_buffer + slot * (int64_t)hkv * head_dim;
+    const T* vt = v + t * v_stride;
+    for (int w = threadIdx.x; w < hkv * head_dim; w += 256) vdst[w] = vt[w];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// KV-cache scatter: one workgroup per token copies K row and V row to slot loc[t].
+// ------------------------------------------------------------------------------------------
+template <typename T, typename LT, bool VEC>
+__global__ __launch_bounds__(256) void set_kv_kernel(T* __restrict__ kb, T* __restrict__ vb,
+                                                     const T* __restrict__ k,
+                                                     const T* __restrict__ v,
+                                                     const LT* __restrict__ loc, int64_t k_row,
+                                                     int64_t v_row, int64_t k_stride,
+                                                     int64_t v_stride) {
+  constexpr int VE = VEC ? V16<T>::n : 1;
+  const int64_t t = blockIdx.x;
+  const int64_t slot = (int64_t)loc[t];
+  const T* ks = k + t * k_stride;
+  const T* vs = v + t * v_stride;
+  T* kd = kb + slot * k_row;
+  T* vd = vb + slot * v_row;
+  for (int64_t i = threadIdx.x * VE; i < k_row; i += 256 * VE)
+    stvec<T, VE>(kd + i, ldvec<T, VE>(ks + i));
+  for (int64_t i = threadIdx.x * VE; i < v_row; i += 256 * VE)
+    stvec<T, VE>(vd + i, ldvec<T, VE>(vs + i));
+}
+
+// ------------------------------------------------------------------------------------------
+// Embedding gather
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void embedding_kernel(T* __restrict__ out,
+                                                        const int64_t* __restrict__ ids,
+                                                        const T* __restrict__ table,
+                                                        int64_t hidden, int64_t v0, int64_t v1) {
+  constexpr int VE = VEC ? V16<T>::n : 1;
+  const int64_t t = blockIdx.x;
+  const int64_t id = ids[t];
+  const bool ok = id >= v0 && id < v1;
+  const T* src = table + (ok ? (id - v0) : 0) * hidden;
+  T* dst = out + t * hidden;
+  for (int64_t i = threadIdx.x * VE; i < hidden; i += 256 * VE) {
+    Vec<T, VE> x = ldvec<T, VE>(src + i);
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) x.v[j] = from_f32<T>(0.f);
+    }
+    stvec<T, VE>(dst + i, x);
+  }
+}
+
+template <typename T>
+static void rope_launch(void* q, void* k, const void* v, const int64_t* positions,
+                        const void* cache, int cache_dtype, int64_t tokens, int hq, int hkv,
+                        int head_dim, int rotary_dim, int64_t q_stride, int64_t k_stride,
+                        int64_t v_stride, int is_neox, void* k_buffer, void* v_buffer,
+                        const void* loc, int loc_itype, hipStream_t st) {
+  const dim3 grid((unsigned)tokens), block(256);
+  const bool f32cache = cache_dtype == MI355_F32 && DType<T>::code != MI355_F32;
+  const bool i32 = loc_itype == MI355_I32;
+#define ROPE_ARGS(CT, LT)                                                                    \
+  (T*)q, (T*)k, (const T*)v, positions, (const CT*)cache, hq, hkv, head_dim, rotary_dim,      \
+      q_stride, k_stride, v_stride, is_neox, (T*)k_buffer, (T*)v_buffer, (const LT*)loc
+  if (f32cache && i32)
+    hipLaunchKernelGGL((rope_kernel<T, float, int32_t>), grid, block, 0, st, ROPE_ARGS(float, int32_t));
+  else if (f32cache)
+    hipLaunchKernelGGL((rope_kernel<T, float, int64_t>), grid, block, 0, st, ROPE_ARGS(float, int64_t));
+  else if (i32)
+    hipLaunchKernelGGL((rope_kernel<T, T, int32_t>), grid, block, 0, st, ROPE_ARGS(T, int32_t));
+  else
+    hipLaunchKernelGGL((rope_kernel<T, T, int64_t>), grid, block, 0, st, ROPE_ARGS(T, int64_t));
+#undef ROPE_ARGS
+}
+
+template <typename T>
+static void set_kv_launch(void* kb, void* vb, const void* k, const void* v, const void* loc,
+                          int loc_itype, int64_t tokens, int64_t k_row, int64_t v_row,
+                          int64_t k_stride, int64_t v_stride, hipStream_t st) {
+  constexpr int VE = V16<T>::n;
+  const bool vec = k_row % VE == 0 && v_row % VE == 0 && k_stride % VE == 0 && v_stride % VE == 0 &&
+                   aligned16(kb) && aligned16(vb) && aligned16(k) && aligned16(v);
+  const dim3 grid((unsigned)tokens), block(256);
+#define KV_ARGS(LT) (T*)kb, (T*)vb, (const T*)k, (const T*)v, (const LT*)loc, k_row, v_row, k_stride, v_stride
+  if (loc_itype == MI355_I32) {
+    if (vec) hipLaunchKernelGGL((set_kv_kernel<T, int32_t, true>), grid, block, 0, st, KV_ARGS(int32_t));
+    else hipLaunchKernelGGL((set_kv_kernel<T, int32_t, false>), grid, block, 0, st, KV_ARGS(int32_t));
+  } else {
+    if (vec) hipLaunchKernelGGL((set_kv_kernel<T, int64_t, true>), grid, block, 0, st, KV_ARGS(int64_t));
+    else hipLaunchKernelGGL((set_kv_kernel<T, int64_t, false>), grid, block, 0, st, KV_ARGS(int64_t));
+  }
+#undef KV_ARGS
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+int mi355_abi_version(void) { return MI355_ABI_VERSION; }
+const char* mi355_last_error(void) { return mi355::get_error(); }
+
+int mi355_rmsnorm(void* out, const void* x, const void* weight, int64_t rows, int64_t hidden,
+                  int64_t x_row_stride, int64_t out_row_stride, float eps, int dtype,
+                  void* stream) {
+  MI355_REQUIRE(out && x && weight, MI355_ERR_INVALID, "rmsnorm: null pointer");
+  MI355_REQUIRE(rows >= 0 && hidden > 0 && x_row_stride >= hidden && out_row_stride >= hidden,
+                MI355_ERR_INVALID, "rmsnorm: bad shape rows=%lld hidden=%lld", (long long)rows,
+                (long long)hidden);
+  if (rows == 0) return MI355_OK;
+  MI355_DISPATCH_DTYPE(dtype, "rmsnorm",
+                       launch_rmsnorm<T, false>((T*)out, (T*)x, nullptr, (const T*)weight, rows,
+                                                hidden, x_row_stride, out_row_stride, eps,
+                                                (hipStream_t)stream));
+  MI355_CHECK_LAUNCH("rmsnorm");
+  return MI355_OK;
+}
+
+int mi355_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t rows,
+                            int64_t hidden, float eps, int dtype, void* stream) {
+  MI355_REQUIRE(x && residual && weight, MI355_ERR_INVALID, "fused_add_rmsnorm: null pointer");
+  MI355_REQUIRE(rows >= 0 && hidden > 0, MI355_ERR_INVALID, "fused_add_rmsnorm: bad shape");
+  if (rows == 0) return MI355_OK;
+  MI355_DISPATCH_DTYPE(dtype, "fused_add_rmsnorm",
+                       launch_rmsnorm<T, true>((T*)x, (T*)x, (T*)residual, (const T*)weight, rows,
+                                               hidden, hidden, hidden, eps, (hipStream_t)stream));
+  MI355_CHECK_LAUNCH("fused_add_rmsnorm");
+  return MI355_OK;
+}
+
+int mi355_silu_and_mul(void* out, const void* x, int64_t rows, int64_t d, int dtype,
+                       void* stream) {
+  MI355_REQUIRE(out && x, MI355_ERR_INVALID, "silu_and_mul: null pointer");
+  MI355_REQUIRE(rows >= 0 && d > 0, MI355_ERR_INVALID, "silu_and_mul: bad shape");
+  if (rows == 0) return MI355_OK;
+  MI355_DISPATCH_DTYPE(dtype, "silu_and_mul", {
+    constexpr int VE = V16<T>::n;
+    const bool vec = d % VE == 0 && aligned16(out) && aligned16(x);
+    const int64_t items = rows * (vec ? d / VE : d);
+    const int grid = (int)std::min<int64_t>((items + 255) / 256, 256 * 16);
+    if (vec)
+      hipLaunchKernelGGL((silu_and_mul_kernel<T, true>), dim3(grid), dim3(256), 0,
+                         (hipStream_t)stream, (T*)out, (const T*)x, rows, d);
+    else
+      hipLaunchKernelGGL((silu_and_mul_kernel<T, false>), dim3(grid), dim3(256), 0,
+                         (hipStream_t)stream, (T*)out, (const T*)x, rows, d);
+  });
+  MI355_CHECK_LAUNCH("silu_and_mul");
+  return MI355_OK;
+}
+
+int mi355_rope_inplace(void* q, void* k, const void* v, const int64_t* positions,
+                       const void* cos_sin_cache, int cache_dtype, int64_t tokens, int hq,
+                       int hkv, int head_dim, int rotary_dim, int64_t q_stride, int64_t k_stride,
+                       int64_t v_stride, int is_neox, void* k_buffer, void* v_buffer,
+                       const void* loc, int loc_itype, int64_t num_slots, int dtype,
+                       void* stream) {
+  MI355_REQUIRE(q && k && positions && cos_sin_cache, MI355_ERR_INVALID, "rope: null pointer");
+  MI355_REQUIRE(tokens >= 0 && hq > 0 && hkv >= 0 && head_dim > 0 && rotary_dim > 0 &&
+                    rotary_dim <= head_dim && rotary_dim % 2 == 0,
+                MI355_ERR_INVALID, "rope: bad shape hq=%d hkv=%d head_dim=%d rotary_dim=%d", hq,
+                hkv, head_dim, rotary_dim);
+  MI355_REQUIRE(q_stride >= (int64_t)hq * head_dim && k_stride >= (int64_t)hkv * head_dim,
+                MI355_ERR_INVALID, "rope: row strides smaller than rows");
+  MI355_REQUIRE(cache_dtype == MI355_F32 || cache_dtype == dtype, MI355_ERR_UNSUPPORTED,
+                "rope: cos_sin_cache must be fp32 or the tensor dtype");
+  if (k_buffer) {
+    MI355_REQUIRE(v && v_buffer && loc && num_slots > 0, MI355_ERR_INVALID,
+                  "rope: fused KV write needs v, v_buffer, loc, num_slots");
+    MI355_REQUIRE(v_stride >= (int64_t)hkv * head_dim, MI355_ERR_INVALID, "rope: bad v_stride");
+  }
+  if (tokens == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  MI355_DISPATCH_DTYPE(dtype, "rope",
+                       rope_launch<T>(q, k, v, positions, cos_sin_cache, cache_dtype, tokens, hq,
+                                      hkv, head_dim, rotary_dim, q_stride, k_stride, v_stride,
+                                      is_neox, k_buffer, v_buffer, loc, loc_itype, st));
+  MI355_CHECK_LAUNCH("rope");
+  return MI355_OK;
+}
+
+int mi355_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const void* v,
+                        const void* loc, int loc_itype, int64_t tokens, int64_t k_row_elems,
+                        int64_t v_row_elems, int64_t k_stride, int64_t v_stride,
+                        int64_t num_slots, int dtype, void* stream) {
+  MI355_REQUIRE(k_buffer && v_buffer && k && v && loc, MI355_ERR_INVALID,
+                "set_kv_buffer: null pointer");
+  MI355_REQUIRE(tokens >= 0 && k_row_elems > 0 && v_row_elems > 0 && k_stride >= k_row_elems &&
+                    v_stride >= v_row_elems && num_slots > 0,
+                MI355_ERR_INVALID, "set_kv_buffer: bad shape");
+  if (tokens == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  MI355_DISPATCH_DTYPE(dtype, "set_kv_buffer",
+                       set_kv_launch<T>(k_buffer, v_buffer, k, v, loc, loc_itype, tokens,
+                                        k_row_elems, v_row_elems, k_stride, v_stride, st));
+  MI355_CHECK_LAUNCH("set_kv_buffer");
+  return MI355_OK;
+}
+
+int mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens,
+                    int64_t hidden, int64_t vocab_start, int64_t vocab_end, int dtype,
+                    void* stream) {
+  MI355_REQUIRE(out && ids && table, MI355_ERR_INVALID, "embedding: null pointer");
+  MI355_REQUIRE(tokens >= 0 && hidden > 0 && vocab_end > vocab_start, MI355_ERR_INVALID,
+                "embedding: bad shape");
+  if (tokens == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  MI355_DISPATCH_DTYPE(dtype, "embedding", {
+    constexpr int VE = V16<T>::n;
+    const bool vec = hidden % VE == 0 && aligned16(out) && aligned16(table);
+    if (vec)
+      hipLaunchKernelGGL((embedding_kernel<T, true>), dim3((unsigned)tokens), dim3(256), 0, st,
+                         (T*)out, ids, (const T*)table, hidden, vocab_start, vocab_end);
+    else
+      hipLaunchKernelGGL((embedding_kernel<T, false>), dim3((unsigned)tokens), dim3(256), 0, st,
+                         (T*)out, ids, (const T*)table, hidden, vocab_start, vocab_end);
+  });
+  MI355_CHECK_LAUNCH("embedding");
+  return MI355_OK;
+}
+
+}  // extern "C"

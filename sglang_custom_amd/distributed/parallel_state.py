@@ -1,0 +1,70 @@
+"""Tensor-parallel process group: one process per GPU, torch.distributed with the "nccl"
+backend (= RCCL over xGMI on ROCm) for device tensors, "gloo" for CPU tests.
+
+Covers what the hot path uses of the reference's GroupCoordinator
+(python/sglang/srt/distributed/parallel_state.py:426-597) and communication_op.py:11-20:
+sum all-reduce after row-parallel projections / the vocab-parallel embedding, and the
+concatenating all-gather of vocab-sharded logits.  With world_size 1 every call is the identity.
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+_TP_GROUP: Optional[dist.ProcessGroup] = None
+_TP_RANK = 0
+_TP_SIZE = 1
+
+
+def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: str = "nccl",
+                                 init_method: Optional[str] = None) -> None:
+    """Create the default process group (if world_size > 1) and use it as the TP group."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    _TP_RANK, _TP_SIZE = rank, world_size
+    if world_size == 1:
+        _TP_GROUP = None
+        return
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, init_method=init_method or "env://",
+                                world_size=world_size, rank=rank)
+    _TP_GROUP = dist.group.WORLD
+
+
+def destroy_model_parallel() -> None:
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return _TP_SIZE
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return _TP_RANK
+
+
+def get_tp_group() -> Optional[dist.ProcessGroup]:
+    return _TP_GROUP
+
+
+def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
+    """In-place sum over the TP group (communication_op.py:11-13)."""
+    if _TP_SIZE == 1:
+        return x
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=_TP_GROUP)
+    return x
+
+
+def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """Concatenate the shards of every rank along `dim` (parallel_state.py:528-597)."""
+    if _TP_SIZE == 1:
+        return x
+    if dim < 0:
+        dim += x.dim()
+    x = x.contiguous()
+    out = torch.empty((_TP_SIZE,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=_TP_GROUP)
+    out = out.movedim(0, dim)
+    shape = list(x.shape)
+    shape[dim] *= _TP_SIZE
+    return out.reshape(shape)

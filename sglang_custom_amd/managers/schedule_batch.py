@@ -1,0 +1,193 @@
+"""Req / ScheduleBatch / ModelWorkerBatch: CPU -> device batch materialisation and KV-slot
+bookkeeping for one static batch, with the semantics of the reference's
+python/sglang/srt/managers/schedule_batch.py (prepare_for_extend :1106-1303,
+prepare_for_decode :1503-1573, get_model_worker_batch :1671-1756, ModelWorkerBatch :1829-1897).
+
+What differs on purpose: the req->token table writes go through the HIP kernels
+(mi355_write_req_to_token / mi355_prepare_decode) instead of Triton / index_put, the decode
+update is ONE launch that also produces `positions`, and the sequence lengths are mirrored on
+the host so that the attention planner never has to read a device tensor back.
+"""
+import dataclasses
+from typing import List, Optional
+
+import torch
+
+from ..model_executor.forward_batch_info import ForwardMode
+from ..ops_backend import get_ops
+from ..sampling.sampling_batch_info import SamplingBatchInfo
+from ..sampling.sampling_params import SamplingParams
+
+
+class Req:
+    """The request fields the hot path reads (schedule_batch.py Req)."""
+
+    def __init__(self, rid, origin_input_ids: List[int], sampling_params: Optional[SamplingParams] = None,
+                 origin_input_text: str = ""):
+        self.rid = rid
+        self.origin_input_text = origin_input_text
+        self.origin_input_ids = list(origin_input_ids)
+        self.output_ids: List[int] = []
+        self.sampling_params = sampling_params or SamplingParams(temperature=0)
+        self.req_pool_idx: Optional[int] = None
+        # prefix reuse: slots of an already-cached prefix (empty without a prefix cache)
+        self.prefix_indices = []
+        self.fill_ids = self.origin_input_ids
+        self.extend_input_len = len(self.fill_ids)
+        self.cached_tokens = 0
+        self.already_computed = 0
+
+    @property
+    def seqlen(self) -> int:
+        return len(self.origin_input_ids) + len(self.output_ids)
+
+
+@dataclasses.dataclass
+class ModelWorkerBatch:
+    forward_mode: ForwardMode
+    input_ids: torch.Tensor
+    req_pool_indices: torch.Tensor
+    seq_lens: torch.Tensor
+    out_cache_loc: torch.Tensor
+    seq_lens_sum: int
+    seq_lens_cpu: Optional[torch.Tensor]
+    return_logprob: bool
+    extend_num_tokens: Optional[int]
+    extend_seq_lens: Optional[List[int]]
+    extend_prefix_lens: Optional[List[int]]
+    sampling_info: SamplingBatchInfo
+    positions: Optional[torch.Tensor] = None  # decode: produced by the prepare kernel
+
+
+class ScheduleBatch:
+    def __init__(self, reqs, req_to_token_pool, token_to_kv_pool_allocator, model_config, device):
+        self.reqs: List[Req] = reqs
+        self.req_to_token_pool = req_to_token_pool
+        self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
+        self.model_config = model_config
+        self.device = device
+        self.forward_mode: Optional[ForwardMode] = None
+        self.return_logprob = False
+        self.input_ids = None
+        self.req_pool_indices = None
+        self.seq_lens = None
+        self.seq_lens_cpu_list: List[int] = []
+        self.out_cache_loc = None
+        self.output_ids = None
+        self.positions = None
+        self.seq_lens_sum = 0
+        self.sampling_info = None
+        self.prefix_lens = None
+        self.extend_lens = None
+        self.extend_num_tokens = None
+
+    @classmethod
+    def init_new(cls, reqs, req_to_token_pool, token_to_kv_pool_allocator, tree_cache=None,
+                 model_config=None, enable_overlap: bool = False, spec_algorithm=None,
+                 enable_custom_logit_processor: bool = False):
+        """Same keyword list as the reference's ScheduleBatch.init_new (schedule_batch.py:891)."""
+        return cls(reqs, req_to_token_pool, token_to_kv_pool_allocator, model_config,
+                   req_to_token_pool.device)
+
+    def batch_size(self) -> int:
+        return len(self.reqs)
+
+    # -- allocation helpers (schedule_batch.py alloc_req_slots / alloc_token_slots) --
+    def alloc_req_slots(self, num_reqs: int) -> List[int]:
+        idx = self.req_to_token_pool.alloc(num_reqs)
+        if idx is None:
+            raise RuntimeError("alloc_req_slots runs out of memory: raise max_running_requests")
+        return idx
+
+    def alloc_token_slots(self, num_tokens: int) -> torch.Tensor:
+        loc = self.token_to_kv_pool_allocator.alloc(num_tokens)
+        if loc is None:
+            raise RuntimeError(
+                f"Out of KV slots: need {num_tokens}, "
+                f"available {self.token_to_kv_pool_allocator.available_size()}")
+        return loc
+
+    def prepare_for_extend(self):
+        self.forward_mode = ForwardMode.EXTEND
+        bs = len(self.reqs)
+        req_pool_indices = self.alloc_req_slots(bs)
+        reqs = self.reqs
+        input_ids = [r.fill_ids[len(r.prefix_indices):] for r in reqs]
+        extend_num_tokens = sum(len(ids) for ids in input_ids)
+        seq_lens = [len(r.fill_ids) for r in reqs]
+        prefix_lens = [len(r.prefix_indices) for r in reqs]
+        extend_lens = [r.extend_input_len for r in reqs]
+        dev = self.device
+
+        flat = [t for ids in input_ids for t in ids]
+        self.req_pool_indices = torch.tensor(req_pool_indices, dtype=torch.int64).to(dev, non_blocking=True)
+        self.input_ids = torch.tensor(flat, dtype=torch.int64).to(dev, non_blocking=True)
+        self.seq_lens = torch.tensor(seq_lens, dtype=torch.int64).to(dev, non_blocking=True)
+        prefix_lens_tensor = torch.tensor(prefix_lens, dtype=torch.int64).to(dev, non_blocking=True)
+        extend_lens_tensor = torch.tensor(extend_lens, dtype=torch.int64).to(dev, non_blocking=True)
+
+        for i, (req, seq_len, pre_len) in enumerate(zip(reqs, seq_lens, prefix_lens)):
+            req.req_pool_idx = req_pool_indices[i]
+            assert seq_len - pre_len == req.extend_input_len
+            if pre_len > 0:
+                self.req_to_token_pool.write((req.req_pool_idx, slice(0, pre_len)), req.prefix_indices)
+            req.cached_tokens += pre_len - req.already_computed
+            req.already_computed = seq_len
+
+        self.out_cache_loc = self.alloc_token_slots(extend_num_tokens)
+        self.seq_lens_cpu_list = list(seq_lens)
+        self.seq_lens_sum = sum(seq_lens)
+        self.extend_num_tokens = extend_num_tokens
+        self.prefix_lens = prefix_lens
+        self.extend_lens = extend_lens
+        self.positions = None
+
+        get_ops().write_req_to_token(self.req_to_token_pool.req_to_token, self.req_pool_indices,
+                                     prefix_lens_tensor, self.seq_lens, extend_lens_tensor,
+                                     self.out_cache_loc)
+        self.sampling_info = SamplingBatchInfo.from_schedule_batch(self, self.model_config.vocab_size)
+
+    def prepare_for_decode(self):
+        self.forward_mode = ForwardMode.DECODE
+        bs = len(self.reqs)
+        self.input_ids = self.output_ids.to(torch.int64) if self.output_ids.dtype != torch.int64 else self.output_ids
+        self.output_ids = None
+        self.out_cache_loc = self.alloc_token_slots(bs)
+        if self.positions is None or self.positions.numel() != bs:
+            self.positions = torch.empty(bs, dtype=torch.int64, device=self.device)
+        # seq_lens += 1; positions = seq_lens - 1; req_to_token[req, seq_lens - 1] = out_cache_loc
+        get_ops().prepare_decode(self.req_to_token_pool.req_to_token, self.req_pool_indices,
+                                 self.seq_lens, self.out_cache_loc, self.positions)
+        self.seq_lens_cpu_list = [x + 1 for x in self.seq_lens_cpu_list]
+        self.seq_lens_sum += bs
+
+    def get_model_worker_batch(self) -> ModelWorkerBatch:
+        if self.forward_mode.is_decode_or_idle():
+            extend_seq_lens = extend_prefix_lens = None
+        else:
+            extend_seq_lens, extend_prefix_lens = self.extend_lens, self.prefix_lens
+        return ModelWorkerBatch(
+            forward_mode=self.forward_mode,
+            input_ids=self.input_ids,
+            req_pool_indices=self.req_pool_indices,
+            seq_lens=self.seq_lens,
+            out_cache_loc=self.out_cache_loc,
+            seq_lens_sum=self.seq_lens_sum,
+            seq_lens_cpu=torch.tensor(self.seq_lens_cpu_list, dtype=torch.int64),
+            return_logprob=self.return_logprob,
+            extend_num_tokens=self.extend_num_tokens,
+            extend_seq_lens=extend_seq_lens,
+            extend_prefix_lens=extend_prefix_lens,
+            sampling_info=self.sampling_info,
+            positions=self.positions if self.forward_mode.is_decode() else None,
+        )
+
+    def release(self):
+        """Return every slot of the batch (what the scheduler's cache_finished_req does)."""
+        for r, n in zip(self.reqs, self.seq_lens_cpu_list):
+            if r.req_pool_idx is None:
+                continue
+            slots = self.req_to_token_pool.req_to_token[r.req_pool_idx, :n].to(torch.int64)
+            self.token_to_kv_pool_allocator.free(slots)
+            self.req_to_token_pool.free(r.req_pool_idx)
+            r.req_pool_idx = None

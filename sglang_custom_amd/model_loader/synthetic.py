@@ -1,0 +1,109 @@
+"""Synthetic Llama checkpoints (no network, no real weights in this environment).
+
+The reference's ``--load-format dummy`` initialiser draws uniform(-1e-3, 1e-3)
+(python/sglang/srt/model_loader/weight_utils.py:750-779), which gives logits of ~1e-6 and
+is useless for arg-max parity.  This module instead draws seeded N(0, std) projection
+weights and (1 + 0.1 N(0,1)) norm weights, named exactly like a HuggingFace Llama
+checkpoint (q_proj/k_proj/v_proj/o_proj/gate_proj/up_proj/down_proj), so the same tensors
+can be written to safetensors for the reference's loader and fed to this package's loader.
+
+Generation is on the CPU with a private torch.Generator, so the same seed gives the same
+bits wherever this image runs.
+"""
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+# Named shape presets (public model cards).  "tiny*" presets are for parity tests.
+LLAMA_PRESETS = {
+    "tiny-llama-d64": dict(
+        hidden_size=512, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
+        head_dim=64, intermediate_size=1024, vocab_size=2048, rms_norm_eps=1e-5,
+        rope_theta=500000.0, max_position_embeddings=2048, tie_word_embeddings=False,
+        rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0,
+                          high_freq_factor=4.0, original_max_position_embeddings=256),
+    ),
+    "tiny-llama-d128": dict(
+        hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=1,
+        head_dim=128, intermediate_size=1536, vocab_size=4096, rms_norm_eps=1e-5,
+        rope_theta=500000.0, max_position_embeddings=2048, tie_word_embeddings=True,
+        rope_scaling=None,
+    ),
+    "llama-3.2-1b": dict(
+        hidden_size=2048, num_hidden_layers=16, num_attention_heads=32, num_key_value_heads=8,
+        head_dim=64, intermediate_size=8192, vocab_size=128256, rms_norm_eps=1e-5,
+        rope_theta=500000.0, max_position_embeddings=131072, tie_word_embeddings=True,
+        rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0,
+                          high_freq_factor=4.0, original_max_position_embeddings=8192),
+    ),
+    "llama-3-8b": dict(
+        hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+        head_dim=128, intermediate_size=14336, vocab_size=128256, rms_norm_eps=1e-5,
+        rope_theta=500000.0, max_position_embeddings=8192, tie_word_embeddings=False,
+        rope_scaling=None,
+    ),
+    "llama-3-70b": dict(
+        hidden_size=8192, num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8,
+        head_dim=128, intermediate_size=28672, vocab_size=128256, rms_norm_eps=1e-5,
+        rope_theta=500000.0, max_position_embeddings=8192, tie_word_embeddings=False,
+        rope_scaling=None,
+    ),
+}
+
+
+def hf_config_dict(preset: str, torch_dtype: str = "bfloat16") -> dict:
+    """A HuggingFace-style config.json body for the preset (what the reference's
+    ModelConfig.from_server_args reads, python/sglang/srt/configs/model_config.py)."""
+    c = dict(LLAMA_PRESETS[preset])
+    c.update(
+        architectures=["LlamaForCausalLM"], model_type="llama", hidden_act="silu",
+        attention_bias=False, mlp_bias=False, bos_token_id=1, eos_token_id=2,
+        torch_dtype=torch_dtype, initializer_range=0.02, use_cache=True,
+    )
+    return c
+
+
+def llama_param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
+    h = cfg["hidden_size"]
+    d = cfg.get("head_dim") or h // cfg["num_attention_heads"]
+    hq, hkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    inter, vocab = cfg["intermediate_size"], cfg["vocab_size"]
+    shapes = OrderedDict()
+    shapes["model.embed_tokens.weight"] = (vocab, h)
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        shapes[p + "input_layernorm.weight"] = (h,)
+        shapes[p + "self_attn.q_proj.weight"] = (hq * d, h)
+        shapes[p + "self_attn.k_proj.weight"] = (hkv * d, h)
+        shapes[p + "self_attn.v_proj.weight"] = (hkv * d, h)
+        shapes[p + "self_attn.o_proj.weight"] = (h, hq * d)
+        shapes[p + "post_attention_layernorm.weight"] = (h,)
+        shapes[p + "mlp.gate_proj.weight"] = (inter, h)
+        shapes[p + "mlp.up_proj.weight"] = (inter, h)
+        shapes[p + "mlp.down_proj.weight"] = (h, inter)
+    shapes["model.norm.weight"] = (h,)
+    if not cfg.get("tie_word_embeddings", False):
+        shapes["lm_head.weight"] = (vocab, h)
+    return shapes
+
+
+def make_synthetic_llama_weights(
+    cfg: dict, seed: int = 1234, std: float = 0.02, dtype: torch.dtype = torch.bfloat16,
+    device: str = "cpu",
+) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic checkpoint.  device='cpu' is bit-reproducible (used by parity
+    tests and the golden generator); any other device draws with that device's generator
+    (used by the benchmark, where only shapes matter)."""
+    out = OrderedDict()
+    if device == "cpu":
+        g = torch.Generator(device="cpu").manual_seed(seed)
+    else:
+        g = torch.Generator(device=device).manual_seed(seed)
+    for name, shape in llama_param_shapes(cfg).items():
+        if name.endswith("layernorm.weight") or name == "model.norm.weight":
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float32, device=device)
+        else:
+            w = std * torch.randn(shape, generator=g, dtype=torch.float32, device=device)
+        out[name] = w.to(dtype)
+    return out

@@ -1,0 +1,397 @@
+"""torch.Tensor front-end of the C ABI (include/mi355_hotpath.h).
+
+Each function checks device / dtype / contiguity (raising like the reference's
+CHECK_INPUT / TORCH_CHECK do, sgl-kernel/csrc/torch_extension_rocm.cc), then passes raw
+pointers and the current torch stream to libmi355_hotpath.so.  Nothing here computes: PyTorch
+is used for memory and streams only.  Outputs are allocated by the caller or returned fresh,
+mirroring sgl-kernel/python/sgl_kernel/{elementwise,sampling}.py.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, I32, I64, check
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_IT = {torch.int32: I32, torch.int64: I64}
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}; expected float32/bfloat16/float16")
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mi355 hot-path ops need tensors on the GPU (no CPU fallback)")
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------- norms
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sgl_kernel.rmsnorm(input, weight, eps, out) (sgl-kernel/python/sgl_kernel/elementwise.py)."""
+    _gpu(x, weight)
+    assert x.dim() == 2 and x.stride(1) == 1 and weight.is_contiguous()
+    assert weight.dtype == x.dtype and weight.numel() == x.shape[1]
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    assert out.stride(1) == 1 and out.shape == x.shape and out.dtype == x.dtype
+    check(_lib_().mi355_rmsnorm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), x.shape[0],
+                                x.shape[1], x.stride(0), out.stride(0), float(eps), _dt(x),
+                                _stream(x)), "rmsnorm")
+    return out
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                      eps: float) -> None:
+    """In place on x and residual (sgl_kernel.fused_add_rmsnorm)."""
+    _gpu(x, residual, weight)
+    assert x.dim() == 2 and x.is_contiguous() and residual.is_contiguous()
+    assert residual.shape == x.shape and residual.dtype == x.dtype == weight.dtype
+    check(_lib_().mi355_fused_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                          x.shape[0], x.shape[1], float(eps), _dt(x), _stream(x)),
+          "fused_add_rmsnorm")
+
+
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sgl_kernel.silu_and_mul(input, out): out = silu(x[..., :d]) * x[..., d:]."""
+    _gpu(x)
+    assert x.is_contiguous() and x.shape[-1] % 2 == 0
+    d = x.shape[-1] // 2
+    rows = x.numel() // (2 * d)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
+    assert out.is_contiguous() and out.dtype == x.dtype
+    check(_lib_().mi355_silu_and_mul(out.data_ptr(), x.data_ptr(), rows, d, _dt(x), _stream(x)),
+          "silu_and_mul")
+    return out
+
+
+# ---------------------------------------------------------------------------------- rope / kv
+def rope_inplace(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, head_size: int,
+                 cos_sin_cache: torch.Tensor, is_neox: bool, v: Optional[torch.Tensor] = None,
+                 k_buffer: Optional[torch.Tensor] = None, v_buffer: Optional[torch.Tensor] = None,
+                 loc: Optional[torch.Tensor] = None) -> None:
+    """apply_rope_with_cos_sin_cache_inplace(positions, query, key, head_size, cos_sin_cache,
+    is_neox) (sgl-kernel/python/sgl_kernel/elementwise.py), optionally fused with the KV-cache
+    write of MHATokenToKVPool.set_kv_buffer when k_buffer/v_buffer/loc/v are given.
+    q: [T, Hq*D], k: [T, Hkv*D] (row-strided views allowed, last dim contiguous)."""
+    _gpu(positions, q, k, cos_sin_cache)
+    assert positions.dtype == torch.int64 and positions.is_contiguous()
+    T = positions.numel()
+    q2, k2 = q.view(T, -1), k.view(T, -1)
+    assert q2.stride(1) == 1 and k2.stride(1) == 1
+    hq, hkv = q2.shape[1] // head_size, k2.shape[1] // head_size
+    rotary_dim = cos_sin_cache.shape[1]
+    assert cos_sin_cache.is_contiguous()
+    cache_dt = _dt(cos_sin_cache)
+    fused = k_buffer is not None
+    if fused:
+        assert v is not None and v_buffer is not None and loc is not None
+        v2 = v.view(T, -1)
+        assert v2.stride(1) == 1 and k_buffer.is_contiguous() and v_buffer.is_contiguous()
+        assert k_buffer.dtype == q.dtype and v_buffer.dtype == q.dtype and v.dtype == q.dtype
+        assert loc.is_contiguous() and loc.numel() == T
+    check(_lib_().mi355_rope_inplace(
+        q2.data_ptr(), k2.data_ptr(), _p(v) if fused else None, positions.data_ptr(),
+        cos_sin_cache.data_ptr(), cache_dt, T, hq, hkv, head_size, rotary_dim, q2.stride(0),
+        k2.stride(0), v.view(T, -1).stride(0) if fused else 0, 1 if is_neox else 0,
+        _p(k_buffer) if fused else None, _p(v_buffer) if fused else None,
+        _p(loc) if fused else None, _IT[loc.dtype] if fused else I64,
+        k_buffer.shape[0] if fused else 0, _dt(q), _stream(q)), "rope_inplace")
+
+
+def set_kv_buffer(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor,
+                  cache_k: torch.Tensor, cache_v: torch.Tensor) -> None:
+    """k_buffer[loc] = cache_k; v_buffer[loc] = cache_v (memory_pool.py:457-458)."""
+    _gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
+    T = loc.numel()
+    k2, v2 = cache_k.view(T, -1), cache_v.view(T, -1)
+    assert k2.stride(1) == 1 and v2.stride(1) == 1 and loc.is_contiguous()
+    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
+    assert k_buffer.dtype == cache_k.dtype == cache_v.dtype == v_buffer.dtype
+    k_row = k_buffer.numel() // k_buffer.shape[0]
+    v_row = v_buffer.numel() // v_buffer.shape[0]
+    assert k2.shape[1] == k_row and v2.shape[1] == v_row
+    check(_lib_().mi355_set_kv_buffer(k_buffer.data_ptr(), v_buffer.data_ptr(), k2.data_ptr(),
+                                      v2.data_ptr(), loc.data_ptr(), _IT[loc.dtype], T, k_row,
+                                      v_row, k2.stride(0), v2.stride(0), k_buffer.shape[0],
+                                      _dt(cache_k), _stream(cache_k)), "set_kv_buffer")
+
+
+def embedding(ids: torch.Tensor, table: torch.Tensor, vocab_start: int = 0,
+              vocab_end: Optional[int] = None) -> torch.Tensor:
+    _gpu(ids, table)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and table.is_contiguous()
+    if vocab_end is None:
+        vocab_end = vocab_start + table.shape[0]
+    out = torch.empty((ids.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
+    check(_lib_().mi355_embedding(out.data_ptr(), ids.data_ptr(), table.data_ptr(), ids.numel(),
+                                  table.shape[1], vocab_start, vocab_end, _dt(table),
+                                  _stream(table)), "embedding")
+    return out
+
+
+# ---------------------------------------------------------------------------------- index ops
+def create_kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
+                      page_kernel_lens: torch.Tensor, kv_indptr: torch.Tensor,
+                      kv_start_idx: Optional[torch.Tensor], kv_indices: torch.Tensor) -> None:
+    """create_flashinfer_kv_indices_triton[(bs,)](...) (layers/attention/utils.py:5-41)."""
+    _gpu(req_to_token, req_pool_indices, page_kernel_lens, kv_indptr, kv_indices)
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
+    assert kv_start_idx is None or kv_start_idx.dtype == torch.int32
+    bs = req_pool_indices.numel()
+    check(_lib_().mi355_create_kv_indices(
+        req_to_token.data_ptr(), req_pool_indices.data_ptr(), _IT[req_pool_indices.dtype],
+        page_kernel_lens.data_ptr(), _IT[page_kernel_lens.dtype], kv_indptr.data_ptr(),
+        _p(kv_start_idx), kv_indices.data_ptr(), req_to_token.stride(0), bs,
+        _stream(req_to_token)), "create_kv_indices")
+
+
+def write_req_to_token(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
+                       pre_lens: torch.Tensor, seq_lens: torch.Tensor, extend_lens: torch.Tensor,
+                       out_cache_loc: torch.Tensor) -> None:
+    """write_req_to_token_pool_triton[(bs,)](...) (managers/schedule_batch.py:1900-1934)."""
+    _gpu(req_to_token, req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc)
+    for t in (req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    check(_lib_().mi355_write_req_to_token(
+        req_to_token.data_ptr(), req_pool_indices.data_ptr(), pre_lens.data_ptr(),
+        seq_lens.data_ptr(), extend_lens.data_ptr(), out_cache_loc.data_ptr(),
+        req_to_token.stride(0), req_pool_indices.numel(), _stream(req_to_token)),
+        "write_req_to_token")
+
+
+def compute_position(extend_prefix_lens: torch.Tensor, extend_seq_lens: torch.Tensor,
+                     extend_seq_lens_sum: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """compute_position_triton (model_executor/forward_batch_info.py:703-726)."""
+    _gpu(extend_prefix_lens, extend_seq_lens)
+    assert extend_prefix_lens.dtype == torch.int32 and extend_seq_lens.dtype == torch.int32
+    bs = extend_seq_lens.numel()
+    dev = extend_seq_lens.device
+    positions = torch.empty(extend_seq_lens_sum, dtype=torch.int64, device=dev)
+    extend_start_loc = torch.empty(bs, dtype=torch.int32, device=dev)
+    check(_lib_().mi355_compute_position(extend_prefix_lens.data_ptr(), extend_seq_lens.data_ptr(),
+                                         positions.data_ptr(), extend_start_loc.data_ptr(), bs,
+                                         _stream(extend_seq_lens)), "compute_position")
+    return positions, extend_start_loc
+
+
+def prepare_decode(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
+                   seq_lens: torch.Tensor, out_cache_loc: torch.Tensor,
+                   positions: torch.Tensor) -> None:
+    """In place: seq_lens += 1; positions = clamp(seq_lens-1, 0);
+    req_to_token[req_pool_indices, seq_lens-1] = out_cache_loc
+    (managers/schedule_batch.py:1543-1573, forward_batch_info.py:776-778)."""
+    _gpu(req_to_token, req_pool_indices, seq_lens, out_cache_loc, positions)
+    for t in (req_pool_indices, seq_lens, out_cache_loc, positions):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    check(_lib_().mi355_prepare_decode(req_to_token.data_ptr(), req_pool_indices.data_ptr(),
+                                       seq_lens.data_ptr(), out_cache_loc.data_ptr(),
+                                       positions.data_ptr(), req_to_token.stride(0),
+                                       seq_lens.numel(), _stream(seq_lens)), "prepare_decode")
+
+
+# ---------------------------------------------------------------------------------- attention
+def decode_num_splits(bs: int, hkv: int, max_seq_len: int, max_splits: int) -> int:
+    return _lib_().mi355_decode_num_splits(bs, hkv, max_seq_len, max_splits)
+
+
+def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
+                         num_kv_splits: int, max_kv_splits: int, sm_scale: float,
+                         logit_cap: float = 0.0) -> None:
+    """decode_attention_fwd(...) of the Triton backend (triton_ops/decode_attention.py:677-728),
+    kv_indptr/kv_indices addressing.  num_kv_splits is one int for the whole batch."""
+    _gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices)
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous()
+    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
+    assert kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
+    assert num_kv_splits <= max_kv_splits
+    if num_kv_splits > 1:
+        assert attn_logits.dtype == torch.float32 and attn_lse.dtype == torch.float32
+        assert attn_logits.numel() >= B * Hq * num_kv_splits * Dv and attn_lse.numel() >= B * Hq * num_kv_splits
+    check(_lib_().mi355_decode_attention(
+        q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
+        kv_indices.data_ptr(), 1, None, None, kv_indptr.data_ptr(), 0, _p(attn_logits),
+        _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), k_buffer.shape[0], float(sm_scale),
+        float(logit_cap), _dt(q), _stream(q)), "decode_attention")
+
+
+def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
+                           attn_logits, attn_lse, num_kv_splits: int, sm_scale: float,
+                           logit_cap: float = 0.0) -> None:
+    """decode_attention_cpu-style addressing (sgl-kernel/csrc/cpu/decode.cpp:1375): the kernel
+    reads req_to_token[req_pool_indices[b], :seq_lens[b]] directly, no kv_indices gather."""
+    _gpu(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous()
+    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    check(_lib_().mi355_decode_attention(
+        q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
+        req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
+        req_to_token.stride(0), _p(attn_logits), _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, Dv,
+        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _dt(q), _stream(q)),
+        "decode_attention")
+
+
+def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+                         kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr,
+                         max_len_extend, sm_scale=None, logit_cap=0.0,
+                         skip_prefix_custom_mask=True, sliding_window_size=-1) -> None:
+    """extend_attention_fwd(...) (triton_ops/extend_attention.py:306-438), same argument order."""
+    _gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
+    T, Hq, D = q_extend.shape
+    Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
+    assert q_extend.stride(2) == 1 and q_extend.stride(1) == D
+    assert k_extend.stride(2) == 1 and k_extend.stride(1) == D
+    assert v_extend.stride(2) == 1 and v_extend.stride(1) == Dv
+    assert o_extend.is_contiguous() and k_buffer.is_contiguous() and v_buffer.is_contiguous()
+    assert qo_indptr.dtype == torch.int32 and kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
+    if sm_scale is None:
+        sm_scale = 1.0 / (D ** 0.5)
+    if custom_mask is not None:
+        assert mask_indptr is not None and mask_indptr.dtype == torch.int64
+        if custom_mask.dtype == torch.bool:
+            custom_mask = custom_mask.view(torch.uint8)
+        assert custom_mask.dtype == torch.uint8
+    bs = qo_indptr.numel() - 1
+    check(_lib_().mi355_extend_attention(
+        q_extend.data_ptr(), k_extend.data_ptr(), v_extend.data_ptr(), o_extend.data_ptr(),
+        k_buffer.data_ptr(), v_buffer.data_ptr(), qo_indptr.data_ptr(), kv_indptr.data_ptr(),
+        kv_indices.data_ptr(), _p(custom_mask), _p(mask_indptr) if custom_mask is not None else None,
+        1 if is_causal else 0, 1 if skip_prefix_custom_mask else 0, bs, int(max_len_extend), Hq,
+        Hkv, D, Dv, q_extend.stride(0), k_extend.stride(0), v_extend.stride(0),
+        k_buffer.shape[0], float(sm_scale), float(logit_cap), int(sliding_window_size),
+        _dt(q_extend), _stream(q_extend)), "extend_attention")
+
+
+# ---------------------------------------------------------------------------------- linear
+_WS = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Per-device grow-only scratch for split-K slabs (allocated outside graph capture by the
+    first eager call of each shape; ModelRunner warms every shape up before capturing)."""
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = ws
+    return ws
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """F.linear(x, weight, bias) (layers/quantization/unquant.py:110-122) through the C ABI:
+    weight-streaming MFMA kernel for M <= 64 (bf16/f16), exact tiled kernel otherwise."""
+    _gpu(x, weight, bias)
+    assert x.dim() == 2 and x.stride(1) == 1 and weight.is_contiguous() and weight.dtype == x.dtype
+    M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    lib = _lib_()
+    need = lib.mi355_linear_workspace_bytes(M, N, K)
+    ws = _workspace(x.device, need) if need > 0 else None
+    check(lib.mi355_linear(y.data_ptr(), x.data_ptr(), weight.data_ptr(), _p(bias), M, N, K,
+                           x.stride(0), _p(ws), ws.numel() if ws is not None else 0, _dt(x),
+                           _DT[out_dtype], _stream(x)), "linear")
+    return y
+
+
+def per_token_quant_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """per_token_group_quant_fp8(x, group_size=K) (fp8_kernel.py:115-155) -> (xq e4m3fn, scale [M,1])."""
+    _gpu(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    xq = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    check(_lib_().mi355_per_token_quant_fp8(xq.data_ptr(), s.data_ptr(), x.data_ptr(), M, K,
+                                            x.stride(0), _dt(x), _stream(x)), "per_token_quant_fp8")
+    return xq, s
+
+
+def fp8_scaled_mm(xq: torch.Tensor, wq: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor,
+                  out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias) (sgl-kernel gemm.py) with
+    wq given as [N, K] (one row per output channel)."""
+    _gpu(xq, wq, x_scale, w_scale, bias)
+    assert xq.is_contiguous() and wq.is_contiguous()
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and x_scale.numel() == M and w_scale.numel() == N
+    assert x_scale.dtype == torch.float32 and w_scale.dtype == torch.float32
+    assert bias is None or bias.dtype == out_dtype
+    y = torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    lib = _lib_()
+    need = lib.mi355_fp8_workspace_bytes(M, N, K)
+    ws = _workspace(xq.device, need) if need > 0 else None
+    check(lib.mi355_fp8_scaled_mm(y.data_ptr(), xq.data_ptr(), wq.data_ptr(), x_scale.data_ptr(),
+                                  w_scale.data_ptr(), _p(bias), M, N, K, _p(ws),
+                                  ws.numel() if ws is not None else 0, _DT[out_dtype],
+                                  _stream(xq)), "fp8_scaled_mm")
+    return y
+
+
+# ---------------------------------------------------------------------------------- sampling
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    """torch.argmax(logits, -1) on fp32 [B, V] (layers/sampler.py:74)."""
+    _gpu(logits)
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    ids = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    check(_lib_().mi355_argmax(ids.data_ptr(), logits.data_ptr(), logits.shape[0], logits.shape[1],
+                               logits.stride(0), _stream(logits)), "argmax")
+    return ids
+
+
+def softmax_temperature_(logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
+    """In place logits.div_(temperatures); logits[:] = softmax(logits) (layers/sampler.py:79-81)."""
+    _gpu(logits, temperatures)
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    assert temperatures.dtype == torch.float32 and temperatures.numel() == logits.shape[0]
+    check(_lib_().mi355_softmax_temperature(logits.data_ptr(), temperatures.data_ptr(),
+                                            logits.shape[0], logits.shape[1], logits.stride(0),
+                                            _stream(logits)), "softmax_temperature")
+    return logits
+
+
+def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor],
+                             top_ps: Optional[torch.Tensor], min_ps: Optional[torch.Tensor],
+                             uniform: torch.Tensor) -> torch.Tensor:
+    """Joint top-k/top-p/min-p sampling from probabilities with caller-supplied uniforms."""
+    _gpu(probs, top_ks, top_ps, min_ps, uniform)
+    assert probs.dim() == 2 and probs.dtype == torch.float32 and probs.stride(1) == 1
+    B = probs.shape[0]
+    assert uniform.dtype == torch.float32 and uniform.numel() == B
+    assert top_ks is None or (top_ks.dtype == torch.int32 and top_ks.numel() == B)
+    assert top_ps is None or (top_ps.dtype == torch.float32 and top_ps.numel() == B)
+    assert min_ps is None or (min_ps.dtype == torch.float32 and min_ps.numel() == B)
+    ids = torch.empty(B, dtype=torch.int32, device=probs.device)
+    check(_lib_().mi355_top_k_top_p_min_p_sample(ids.data_ptr(), probs.data_ptr(), _p(top_ks),
+                                                 _p(top_ps), _p(min_ps), uniform.data_ptr(), B,
+                                                 probs.shape[1], probs.stride(0), _stream(probs)),
+          "top_k_top_p_min_p_sample")
+    return ids

@@ -1,0 +1,25 @@
+"""The subset of the reference's ServerArgs (python/sglang/srt/server_args.py:46-265) that the
+hot path reads, same field names."""
+import dataclasses
+from typing import Optional
+
+
+@dataclasses.dataclass
+class ServerArgs:
+    model_path: str = ""
+    dtype: str = "auto"
+    device: str = "cuda"
+    tp_size: int = 1
+    quantization: Optional[str] = None          # None | "w8a8_fp8"
+    attention_backend: str = "mi355"
+    sampling_backend: str = "mi355"
+    max_total_tokens: Optional[int] = None
+    max_running_requests: Optional[int] = None
+    context_length: Optional[int] = None
+    mem_fraction_static: float = 0.85
+    disable_cuda_graph: bool = False
+    cuda_graph_max_bs: int = 64
+    cuda_graph_bs: Optional[list] = None
+    random_seed: int = 0
+    dist_backend: Optional[str] = None          # default: nccl (RCCL) on GPU, gloo on CPU
+    dist_init_method: Optional[str] = None

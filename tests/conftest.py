@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_ops():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "ops.npz"))
+
+
+def load_e2e(preset, dtn):
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", f"e2e_{preset}_{dtn}.npz"))
