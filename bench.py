@@ -1,0 +1,292 @@
+"""Headline benchmark: decode output tokens/s (+ TTFT) of Llama-3-8B bf16 TP=1, static batch of 64
+requests, 1024-token prompts, on MI355X -- BASELINE.json configs[1] -- measured with the
+semantics of the reference's bench_one_batch.py (synthetic fixed-length prompts, greedy).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one decode forward of the whole batch (bs new tokens).  W untimed warm-up steps,
+then exactly K timed steps between barrier + synchronize; rank 0 prints ONE JSON line.
+N > 1 (default): N independent TP=1 replicas, one per GPU, no data-path collective ("weak"
+scaling: per-GPU work fixed); `--parallelism tp` shards one model over the N GPUs with RCCL
+all-reduce instead (strong scaling).
+
+The same line carries
+  roofline      -- the dominant kernel (weight-streaming skinny GEMM): algorithmic bytes per launch
+                   / its average duration measured here with HIP events on the launch stream,
+                   against the 8 TB/s HBM3E peak;
+  cpu_baseline  -- the CPU restatement (oracle/) of the same decode step timed on this host's cores
+                   on a bounded sample (a few of the 32 layers + the LM head, scaled).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--input-len", type=int, default=1024)
+    ap.add_argument("--quantization", default=None, choices=[None, "w8a8_fp8"])
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--ttft-repeats", type=int, default=3)
+    return ap.parse_args()
+
+
+def weight_bytes_per_step(cfg, tp, dtype_bytes, quant):
+    """Bytes of every matmul weight touched once per decode step on one GPU (layers + LM head)."""
+    h, d = cfg["hidden_size"], cfg["head_dim"]
+    hq, hkv = cfg["num_attention_heads"] // tp, max(1, cfg["num_key_value_heads"] // tp)
+    inter, vocab, L = cfg["intermediate_size"] // tp, cfg["vocab_size"] // tp, cfg["num_hidden_layers"]
+    per_layer = (hq + 2 * hkv) * d * h + hq * d * h + 2 * inter * h + inter * h
+    wb = 1 if quant == "w8a8_fp8" else dtype_bytes
+    return L * per_layer * wb + vocab * h * dtype_bytes, L * per_layer + vocab * h
+
+
+def gemm_shapes(cfg, tp):
+    h, d = cfg["hidden_size"], cfg["head_dim"]
+    hq, hkv = cfg["num_attention_heads"] // tp, max(1, cfg["num_key_value_heads"] // tp)
+    inter = cfg["intermediate_size"] // tp
+    return [((hq + 2 * hkv) * d, h), (h, hq * d), (2 * inter, h), (h, inter)]
+
+
+def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
+    """Average duration of the decode projection kernel (gemm_skinny_kernel) over one step's worth
+    of launches -- every layer's real weights in order, M = bs -- bracketed by HIP events on the
+    stream the kernels are launched on."""
+    from sglang_custom_amd import ops
+
+    dev = mr.device
+    layers = mr.model.model.layers
+    x_h = torch.randn(bs, cfg["hidden_size"], device=dev).to(mr.dtype)
+    x_attn = torch.randn(bs, layers[0].self_attn.o_proj.weight.shape[1], device=dev).to(mr.dtype)
+    x_mlp = torch.randn(bs, layers[0].mlp.down_proj.weight.shape[1], device=dev).to(mr.dtype)
+    head = mr.model.lm_head.weight
+
+    def one_pass():
+        for layer in layers:
+            ops.linear(x_h, layer.self_attn.qkv_proj.weight)
+            ops.linear(x_attn, layer.self_attn.o_proj.weight)
+            ops.linear(x_h, layer.mlp.gate_up_proj.weight)
+            ops.linear(x_mlp, layer.mlp.down_proj.weight)
+        ops.linear(x_h, head, None, out_dtype=torch.float32)
+
+    stream = torch.cuda.current_stream()
+    one_pass()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()   # replay from a graph: no host launch gaps inside the bracket
+    with torch.cuda.graph(g):
+        one_pass()
+    reps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g.replay()
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        g.replay()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches = 4 * len(layers) + 1
+    total_ms = e0.elapsed_time(e1) / reps
+    wbytes, _ = weight_bytes_per_step(cfg, tp, dtype_bytes, None)
+    # algorithmic bytes: weights once + activations in/out (small)
+    act = sum(bs * (n + k) * dtype_bytes for (n, k) in gemm_shapes(cfg, tp)) * len(layers) \
+        + bs * (cfg["hidden_size"] * dtype_bytes + cfg["vocab_size"] // tp * 4)
+    bytes_per_launch = (wbytes + act) / launches
+    dur_s = total_ms * 1e-3 / launches
+    return dict(kernel="gemm_skinny_kernel", launches_per_step=launches,
+                avg_duration_us=dur_s * 1e6, bytes_per_launch=bytes_per_launch,
+                achieved_gbs=bytes_per_launch / dur_s / 1e9)
+
+
+def cpu_baseline(cfg, bs, ctx, dtype):
+    """Oracle decode step on the host cores: time `nl` layers + the LM head and scale to the full
+    depth (every layer does identical work)."""
+    from oracle.llama_ref import OracleLlama
+    from oracle import ops_ref
+
+    nl = 1
+    torch.manual_seed(0)
+    small = dict(cfg)
+    small["num_hidden_layers"] = nl
+    from sglang_custom_amd.model_loader.synthetic import llama_param_shapes
+
+    w = {}
+    for name, shape in llama_param_shapes(small).items():
+        w[name] = (torch.randn(shape, dtype=torch.bfloat16) * 0.02).to(dtype) if len(shape) > 1 \
+            else torch.ones(shape, dtype=dtype)
+    m = OracleLlama(small, w, dtype, max_total_tokens=bs * (ctx + 4), max_reqs=bs, context_len=ctx + 8)
+    # fill the cache as if `ctx` tokens per request were already there (contents are irrelevant
+    # to the timing): allocate slots and table entries without running a prefill
+    m.req_pool_indices = torch.arange(bs, dtype=torch.int64)
+    m.seq_lens = torch.full((bs,), ctx, dtype=torch.int64)
+    slots = m._alloc(bs * ctx).view(bs, ctx)
+    m.req_to_token[:bs, :ctx] = slots.to(torch.int32)
+    for c in m.k_cache + m.v_cache:
+        c.normal_(0, 1)
+    ids = torch.randint(0, 10000, (bs,))
+    threads = torch.get_num_threads()
+    # layers: time the whole step, then the head alone, subtract
+    m.decode(ids)  # warm-up
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        m.decode(ids)
+    t_step = (time.perf_counter() - t0) / reps
+    h = torch.randn(bs, cfg["hidden_size"]).to(dtype)
+    m._logits(h)
+    t0 = time.perf_counter()
+    m._logits(h)
+    t_head = time.perf_counter() - t0
+    t_layer = max(t_step - t_head, 1e-9) / nl
+    full = t_layer * cfg["num_hidden_layers"] + t_head
+    return dict(value=bs / full, unit="tok/s", cores=threads, kind="port",
+                sample=f"oracle decode step bs={bs} ctx={ctx}: {nl} of {cfg['num_hidden_layers']} layers "
+                       f"({t_layer * 1e3:.0f} ms/layer) + LM head ({t_head * 1e3:.0f} ms) timed on "
+                       f"{threads} threads, scaled to {cfg['num_hidden_layers']} layers")
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    assert world in (1, n_gpus), f"WORLD_SIZE={world} but --gpus {n_gpus}"
+    import torch.distributed as dist
+
+    from sglang_custom_amd import bench_one_batch as bob
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict
+    from sglang_custom_amd.server_args import ServerArgs
+
+    torch.cuda.set_device(local_rank)
+    tp = world if (args.parallelism == "tp" and world > 1) else 1
+    if world > 1 and tp == 1:
+        dist.init_process_group("nccl", world_size=world, rank=rank,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+    cfg = hf_config_dict(args.model, args.dtype)
+    bs, in_len = args.batch_size, args.input_len
+    out_len = args.warmup + args.steps + 1
+    sa = ServerArgs(dtype=args.dtype, max_total_tokens=bs * (in_len + out_len + 8) + 64,
+                    max_running_requests=max(bs, 8) + 8, context_length=in_len + out_len + 16,
+                    disable_cuda_graph=args.no_graph, cuda_graph_bs=[bs], tp_size=tp,
+                    quantization=args.quantization, random_seed=rank if tp == 1 else 0)
+    mc = ModelConfig(cfg, dtype=args.dtype, context_length=in_len + out_len + 16)
+    graph_ok = True
+    try:
+        mr = ModelRunner(mc, sa, gpu_id=local_rank, tp_rank=rank if tp > 1 else 0, tp_size=tp)
+    except Exception as e:  # graph capture of collectives can fail: fall back to eager launches
+        if args.no_graph:
+            raise
+        print(f"[bench] HIP-graph capture failed ({e!r}); running eager", file=sys.stderr)
+        sa.disable_cuda_graph = True
+        graph_ok = False
+        mr = ModelRunner(mc, sa, gpu_id=local_rank, tp_rank=rank if tp > 1 else 0, tp_size=tp)
+    graph_ok = graph_ok and mr.graph_runner is not None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- TTFT: prefill latency of the whole batch, p50 over a few repeats ----
+    reqs = bob.prepare_synthetic_inputs_for_latency_test(bs, in_len, seed=0)
+    ttfts = []
+    for r in range(args.ttft_repeats + 1):
+        bob.clear_pools(mr)
+        for q in reqs:
+            q.req_pool_idx = None
+            q.already_computed = 0
+            q.cached_tokens = 0
+        barrier()
+        t0 = time.perf_counter()
+        next_ids, _, batch = bob.extend(reqs, mr)
+        torch.cuda.synchronize()
+        if r > 0:  # first run is the warm-up
+            ttfts.append(time.perf_counter() - t0)
+    ttft = sorted(ttfts)[len(ttfts) // 2]
+
+    # ---- decode: W warm-up + K timed steps ----
+    for _ in range(args.warmup):
+        next_ids, _ = bob.decode(next_ids, batch, mr)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        next_ids, _ = bob.decode(next_ids, batch, mr)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    replicas = world if tp == 1 else 1
+    value = bs * replicas * args.steps / elapsed
+
+    dtype_bytes = 2 if args.dtype != "float32" else 4
+    wbytes, _ = weight_bytes_per_step(cfg, tp, dtype_bytes, args.quantization)
+    mean_ctx = in_len + args.warmup + (args.steps + 1) / 2.0
+    kv_tok = 2 * max(1, cfg["num_key_value_heads"] // tp) * cfg["head_dim"] * cfg["num_hidden_layers"] * dtype_bytes
+    bytes_step = wbytes + bs * mean_ctx * kv_tok + bs * kv_tok
+    step_gbs = bytes_step / (ms_per_step * 1e-3) / 1e9
+
+    out = {
+        "metric": "decode output tok/s (Llama-3-8B bf16 TP=1, bs=64, 1024-in) + p50 TTFT",
+        "value": round(value, 1), "unit": "tok/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None,
+        "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype]
+                 + ("+fp8-w8a8" if args.quantization else ""),
+        "data": "synthetic (random-init weights of the named shape, np.random prompts seed 0)",
+        "config": {"workload": f"{args.model} {args.dtype} decode, static batch {bs}, {in_len}-token prompts, "
+                               f"greedy, context {in_len + args.warmup}..{in_len + args.warmup + args.steps}",
+                   "global_batch": bs * replicas, "seq_len": in_len,
+                   "parallelism": f"tp{tp}" if tp > 1 else (f"dp{world}" if world > 1 else "tp1"),
+                   "hip_graph": bool(graph_ok)},
+        "ttft_p50_ms": round(ttft * 1e3, 2),
+        "prefill_tok_s": round(bs * in_len / ttft, 1),
+        "step_bytes_algorithmic": int(bytes_step),
+        "step_hbm_gbs": round(step_gbs, 1),
+        "step_hbm_frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
+    }
+    if rank == 0 and not args.no_roofline and args.quantization is None and tp == 1:
+        k = measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes)
+        out["roofline"] = {"bound": "hbm", "achieved": round(k["achieved_gbs"], 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(k["achieved_gbs"] / HBM_PEAK_GBS, 4),
+                           "traffic": None, "kernel": k["kernel"],
+                           "avg_duration_us": round(k["avg_duration_us"], 2),
+                           "bytes_per_launch": int(k["bytes_per_launch"]),
+                           "launches_per_step": k["launches_per_step"]}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        del mr
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(cfg, bs, in_len + args.warmup + args.steps // 2,
+                                           torch.bfloat16 if args.dtype == "bfloat16" else torch.float32)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1 and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
                                                    T* __restrict__ k_buffer,
                                                    T* __restrict__ v_buffer,
                                                    const LT* __restrict__ loc) {
+  // Every product and sum below must round on its own (torch evaluates x1*cos, x2*sin and their
+  // difference as separate elementwise ops): no fused multiply-add contraction in this kernel.
+#pragma clang fp contract(off)
   const int64_t t = blockIdx.x;
   const int64_t pos = positions[t];
   const CT* cs = cache + pos * rotary_dim;

@@ -52,6 +52,8 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float,
     if out is None:
         out = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
     assert out.stride(1) == 1 and out.shape == x.shape and out.dtype == x.dtype
+    if x.numel() == 0:
+        return out
     check(_lib_().mi355_rmsnorm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), x.shape[0],
                                 x.shape[1], x.stride(0), out.stride(0), float(eps), _dt(x),
                                 _stream(x)), "rmsnorm")
@@ -64,6 +66,8 @@ def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Ten
     _gpu(x, residual, weight)
     assert x.dim() == 2 and x.is_contiguous() and residual.is_contiguous()
     assert residual.shape == x.shape and residual.dtype == x.dtype == weight.dtype
+    if x.numel() == 0:
+        return
     check(_lib_().mi355_fused_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
                                           x.shape[0], x.shape[1], float(eps), _dt(x), _stream(x)),
           "fused_add_rmsnorm")
@@ -78,6 +82,8 @@ def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     if out is None:
         out = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
     assert out.is_contiguous() and out.dtype == x.dtype
+    if x.numel() == 0:
+        return out
     check(_lib_().mi355_silu_and_mul(out.data_ptr(), x.data_ptr(), rows, d, _dt(x), _stream(x)),
           "silu_and_mul")
     return out
@@ -142,6 +148,8 @@ def embedding(ids: torch.Tensor, table: torch.Tensor, vocab_start: int = 0,
     if vocab_end is None:
         vocab_end = vocab_start + table.shape[0]
     out = torch.empty((ids.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
+    if ids.numel() == 0:
+        return out
     check(_lib_().mi355_embedding(out.data_ptr(), ids.data_ptr(), table.data_ptr(), ids.numel(),
                                   table.shape[1], vocab_start, vocab_end, _dt(table),
                                   _stream(table)), "embedding")
@@ -313,6 +321,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     assert weight.shape[1] == K
     out_dtype = out_dtype or x.dtype
     y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    if M == 0:
+        return y
     lib = _lib_()
     need = lib.mi355_linear_workspace_bytes(M, N, K)
     ws = _workspace(x.device, need) if need > 0 else None

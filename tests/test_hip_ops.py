@@ -1,0 +1,404 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle on the seeded
+inputs of tests/golden/cases.py, and against the reference-generated golden vectors.
+Integer / index work must be bit-exact; floating point within the tolerance written at each
+test (fp32 paths 1e-5-level; bf16/f16 one-rounding-level, as the reference's own kernel tests:
+sgl-kernel/tests/test_norm.py 1e-3 fp16, test_rotary_embedding.py 1e-2 bf16,
+test/srt/cpu/test_decode.py 3e-2)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import ops_ref
+
+pytestmark = pytest.mark.gpu
+DT = cases.DTYPES
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_custom_amd import ops as _ops
+    from sglang_custom_amd import _lib
+
+    _lib.load()
+    return _ops
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+# one rounding step of the dtype at |x| ~ 4 (bf16 ulp 2^-5 at [4,8)), 0 for fp32 compare-in-fp32
+ROUND_TOL = {"f32": 2e-6, "bf16": 3.2e-2, "f16": 4e-3}
+
+
+@pytest.mark.parametrize("dtn", list(DT))
+def test_rmsnorm(ops, golden_ops, dtn):
+    dt = DT[dtn]
+    for i in range(len(cases.NORM_CASES)):
+        x, r, w = cases.norm_inputs(i, dt)
+        ref = ops_ref.rmsnorm(x, w, 1e-5)
+        got = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5)
+        assert maxdiff(got, ref) <= ROUND_TOL[dtn]
+        assert maxdiff(got, t(golden_ops[f"rmsnorm/{dtn}/{i}"])) <= ROUND_TOL[dtn]
+        # at most a handful of elements may differ by one rounding (different summation order)
+        if dtn != "f32":
+            assert (got.cpu() != ref).float().mean() < 0.02
+        yref, rref = ops_ref.rmsnorm(x, w, 1e-5, r)
+        xg, rg = x.to(DEV), r.to(DEV)
+        ops.fused_add_rmsnorm(xg, rg, w.to(DEV), 1e-5)
+        assert torch.equal(rg.cpu(), rref), "residual = T(x + residual) must be bit-exact"
+        assert maxdiff(xg, yref) <= ROUND_TOL[dtn]
+        if dtn != "f32":
+            assert (xg.cpu() != yref).float().mean() < 0.02
+
+
+def test_rmsnorm_strided_and_shapes(ops):
+    for rows, h in ((1, 8), (19, 3072), (3, 16384), (2, 20000)):
+        x = cases.randn((rows, 2 * h), 1, torch.bfloat16)[:, :h]   # row stride 2h
+        w = cases.randn((h,), 2, torch.bfloat16)
+        got = ops.rmsnorm(cases.randn((rows, 2 * h), 1, torch.bfloat16).to(DEV)[:, :h], w.to(DEV), 1e-6)
+        assert maxdiff(got, ops_ref.rmsnorm(x, w, 1e-6)) <= 6.3e-2
+    assert ops.rmsnorm(torch.empty(0, 64, device=DEV), torch.ones(64, device=DEV), 1e-6).shape == (0, 64)
+
+
+@pytest.mark.parametrize("dtn", list(DT))
+def test_silu_and_mul(ops, golden_ops, dtn):
+    for i in range(len(cases.ACT_CASES)):
+        x = cases.act_inputs(i, DT[dtn])
+        got = ops.silu_and_mul(x.to(DEV))
+        ref = ops_ref.silu_and_mul(x)
+        assert maxdiff(got, ref) <= ROUND_TOL[dtn]
+        assert maxdiff(got, t(golden_ops[f"silu_and_mul/{dtn}/{i}"])) <= ROUND_TOL[dtn]
+        if dtn != "f32":
+            assert (got.cpu() != ref).float().mean() < 0.02   # expf vs the CPU's vectorised exp
+
+
+@pytest.mark.parametrize("dtn", list(DT))
+def test_rope_and_kv_write(ops, golden_ops, dtn):
+    dt = DT[dtn]
+    for i, (T, hq, hkv, hd, rd, neox, l3) in enumerate(cases.ROPE_CASES):
+        pos, q, k = cases.rope_inputs(i, dt)
+        cache = ops_ref.cos_sin_cache(rd, 2048, 500000.0 if l3 else 10000.0, cases.LLAMA3 if l3 else None, dt)
+        qref, kref = ops_ref.apply_rope(pos, q, k, hd, cache, neox)
+        qg, kg = q.to(DEV), k.to(DEV)
+        ops.rope_inplace(pos.to(DEV), qg, kg, hd, cache.to(DEV), neox)
+        # same products, same roundings as the reference's native formula: bit-exact
+        assert torch.equal(qg.cpu(), qref) and torch.equal(kg.cpu(), kref)
+        assert torch.equal(qg.cpu().float(), t(golden_ops[f"rope/{dtn}/{i}/q"]))
+        # fused KV write, on a strided qkv like the model produces
+        qkv = torch.cat([q, k, cases.randn((T, hkv * hd), 530 + i, dt)], dim=1).to(DEV)
+        q2, k2, v2 = qkv.split([hq * hd, hkv * hd, hkv * hd], dim=-1)
+        kb = torch.zeros((40, hkv, hd), dtype=dt, device=DEV)
+        vb = torch.zeros_like(kb)
+        loc = (torch.randperm(39)[:T] + 1).to(DEV)
+        ops.rope_inplace(pos.to(DEV), q2, k2, hd, cache.to(DEV), neox, v=v2, k_buffer=kb, v_buffer=vb, loc=loc)
+        assert torch.equal(q2.cpu(), qref) and torch.equal(k2.cpu(), kref)
+        assert torch.equal(kb[loc].view(T, -1).cpu(), kref) and torch.equal(vb[loc].view(T, -1), v2)
+        assert kb[0].abs().sum() == 0  # sink row untouched
+
+
+def test_set_kv_buffer_and_embedding(ops):
+    for dt in DT.values():
+        k = cases.randn((11, 2, 64), 1, dt).to(DEV)
+        v = cases.randn((11, 2, 64), 2, dt).to(DEV)
+        kb = torch.zeros((30, 2, 64), dtype=dt, device=DEV)
+        vb = torch.zeros_like(kb)
+        for loc in ((torch.randperm(29)[:11] + 1).to(DEV), (torch.randperm(29)[:11] + 1).to(DEV).int()):
+            ops.set_kv_buffer(kb, vb, loc, k, v)
+            assert torch.equal(kb[loc.long()], k) and torch.equal(vb[loc.long()], v)
+        tab = cases.randn((100, 48), 3, dt).to(DEV)
+        ids = torch.randint(0, 100, (17,)).to(DEV)
+        assert torch.equal(ops.embedding(ids, tab), tab[ids])
+        part = ops.embedding(ids, tab[25:50].contiguous(), 25, 50)
+        ref = torch.where(((ids >= 25) & (ids < 50))[:, None], tab[ids], torch.zeros_like(tab[ids]))
+        assert torch.equal(part, ref)
+
+
+def test_index_ops_exact(ops):
+    g = torch.Generator().manual_seed(5)
+    for bs in (1, 37, 300):
+        r2t = torch.randint(1, 10 ** 6, (bs + 5, 600), generator=g, dtype=torch.int32)
+        pool = torch.randperm(bs + 5, generator=g)[:bs]
+        lens = torch.randint(1, 600, (bs,), generator=g)
+        indptr = torch.zeros(bs + 1, dtype=torch.int32)
+        indptr[1:] = torch.cumsum(lens, 0)
+        start = torch.randint(0, 3, (bs,), generator=g, dtype=torch.int32)
+        lens2 = torch.clamp(lens - 3, min=0)
+        for ptype in (torch.int64, torch.int32):
+            out = torch.empty(int(lens.sum()), dtype=torch.int32, device=DEV)
+            ops.create_kv_indices(r2t.to(DEV), pool.to(ptype).to(DEV), lens.to(DEV), indptr.to(DEV), None, out)
+            assert torch.equal(out.cpu(), ops_ref.create_kv_indices(r2t, pool, lens))
+        indptr2 = torch.zeros(bs + 1, dtype=torch.int32)
+        indptr2[1:] = torch.cumsum(lens2, 0)
+        out = torch.empty(max(int(lens2.sum()), 1), dtype=torch.int32, device=DEV)
+        ops.create_kv_indices(r2t.to(DEV), pool.to(DEV), lens2.int().to(DEV), indptr2.to(DEV), start.to(DEV), out)
+        assert torch.equal(out.cpu()[: int(lens2.sum())], ops_ref.create_kv_indices(r2t, pool, lens2, start))
+        pre = torch.randint(0, 100, (bs,), generator=g)
+        ext = torch.randint(1, 400, (bs,), generator=g)
+        seq = pre + ext
+        ocl = torch.randint(1, 10 ** 6, (int(ext.sum()),), generator=g)
+        a = r2t.clone().to(DEV)
+        ops.write_req_to_token(a, pool.to(DEV), pre.to(DEV), seq.to(DEV), ext.to(DEV), ocl.to(DEV))
+        b = r2t.clone()
+        ops_ref.write_req_to_token(b, pool, pre, seq, ocl)
+        assert torch.equal(a.cpu(), b)
+        p, s = ops.compute_position(pre.int().to(DEV), ext.int().to(DEV), int(ext.sum()))
+        pr, sr = ops_ref.compute_position(pre.int(), ext.int())
+        assert torch.equal(p.cpu(), pr) and torch.equal(s.cpu(), sr)
+        sl = seq.clone().to(DEV)
+        pos = torch.empty(bs, dtype=torch.int64, device=DEV)
+        oc = torch.randint(1, 10 ** 6, (bs,), generator=g)
+        ops.prepare_decode(a, pool.to(DEV), sl, oc.to(DEV), pos)
+        b[pool, seq] = oc.int()
+        assert torch.equal(a.cpu(), b) and torch.equal(sl.cpu(), seq + 1) and torch.equal(pos.cpu(), ops_ref.clamp_position(seq + 1))
+
+
+def _decode_run(ops, q, kc, vc, r2t, pool, lens, splits, cap=0.0, mode="paged"):
+    B, Hq, D = q.shape
+    o = torch.empty((B, Hq, vc.shape[-1]), dtype=q.dtype, device=DEV)
+    al = torch.empty((B, Hq, splits, vc.shape[-1]), dtype=torch.float32, device=DEV)
+    ll = torch.empty((B, Hq, splits), dtype=torch.float32, device=DEV)
+    scale = D ** -0.5
+    if mode == "paged":
+        ops.decode_attention_paged(q.to(DEV), kc.to(DEV), vc.to(DEV), o, r2t.to(DEV), pool.to(DEV), lens.to(DEV), al, ll, splits, scale, cap)
+    else:
+        indptr = torch.zeros(B + 1, dtype=torch.int32)
+        indptr[1:] = torch.cumsum(lens, 0)
+        kvi = ops_ref.create_kv_indices(r2t, pool, lens).to(DEV)
+        ops.decode_attention_fwd(q.to(DEV), kc.to(DEV), vc.to(DEV), o, indptr.to(DEV), kvi, al, ll, splits, splits, scale, cap)
+    return o
+
+
+# bf16: one rounding step of an output in [2, 4) is 2^-6
+ATTN_TOL = {"f32": 2e-5, "bf16": 1.6e-2, "f16": 2e-3}
+
+
+@pytest.mark.parametrize("dtn", list(DT))
+def test_decode_attention(ops, golden_ops, dtn):
+    for i, (B, Hq, Hkv, D, _) in enumerate(cases.DECODE_CASES):
+        q, kc, vc, r2t, pool, lens = cases.decode_inputs(i, DT[dtn])
+        ref = ops_ref.decode_attention(q, kc, vc, r2t, pool, lens, D ** -0.5, Hq != Hkv)
+        for splits in (1, 3, 8):
+            for mode in ("paged", "indices"):
+                o = _decode_run(ops, q, kc, vc, r2t, pool, lens, splits, mode=mode)
+                assert maxdiff(o, ref) <= ATTN_TOL[dtn], (i, splits, mode)
+                assert maxdiff(o, t(golden_ops[f"decode/{dtn}/{i}"])) <= ATTN_TOL[dtn]
+
+
+def test_decode_attention_shapes_and_logit_cap(ops):
+    # reference test shapes (test/srt/test_triton_attention_kernels.py:293-388, cpu/test_decode.py:62-163)
+    for (B, Hq, Hkv, D, S, cap) in ((2, 12, 4, 80, 100, 0.0), (3, 40, 8, 128, 500, 0.0), (2, 16, 16, 96, 128, 0.0),
+                                    (2, 8, 2, 64, 77, 30.0), (1, 64, 8, 128, 1024, 0.0), (2, 6, 2, 256, 65, 0.0),
+                                    (2, 4, 1, 13, 9, 0.0)):
+        for dtn in ("f32", "bf16"):
+            dt = DT[dtn]
+            lens = [S, max(1, S // 3)][:B] + [5] * (B - 2)
+            kc, vc, r2t, pool = cases.paged_inputs(42, dt, B, Hkv, D, lens)
+            q = cases.randn((B, Hq, D), 43, dt)
+            lt = torch.tensor(lens, dtype=torch.int64)
+            for splits in (1, 4):
+                o = _decode_run(ops, q, kc, vc, r2t, pool, lt, splits, cap)
+                for b in range(B):
+                    toks = r2t[pool[b], : lens[b]].long()
+                    ref = ops_ref.attention_fp64(q[b][:, None], kc[toks].transpose(0, 1), vc[toks].transpose(0, 1), D ** -0.5, None, cap)[:, 0]
+                    assert maxdiff(o[b], ref) <= ATTN_TOL[dtn], (B, Hq, Hkv, D, S, cap, splits)
+
+
+def _extend_run(ops, q, kc, vc, r2t, pool, seq, pre, ext, Hkv, D):
+    """New-token K/V are read from the cache rows (they are already there) as k_extend/v_extend."""
+    T = q.shape[0]
+    kext = torch.empty((T, Hkv, D), dtype=q.dtype)
+    vext = torch.empty((T, Hkv, D), dtype=q.dtype)
+    p = 0
+    for b in range(len(seq)):
+        toks = r2t[pool[b], int(pre[b]): int(seq[b])].long()
+        kext[p: p + len(toks)] = kc[toks]
+        vext[p: p + len(toks)] = vc[toks]
+        p += len(toks)
+    qo = torch.zeros(len(seq) + 1, dtype=torch.int32)
+    qo[1:] = torch.cumsum(ext, 0)
+    kvp = torch.zeros(len(seq) + 1, dtype=torch.int32)
+    kvp[1:] = torch.cumsum(pre, 0)
+    kvi = ops_ref.create_kv_indices(r2t, pool, pre) if int(pre.sum()) else torch.zeros(1, dtype=torch.int32)
+    o = torch.empty((T, q.shape[1], D), dtype=q.dtype, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), kext.to(DEV), vext.to(DEV), o, kc.to(DEV), vc.to(DEV), qo.to(DEV),
+                             kvp.to(DEV), kvi.to(DEV), None, True, None, int(ext.max()), D ** -0.5)
+    return o
+
+
+@pytest.mark.parametrize("dtn", list(DT))
+def test_extend_attention(ops, golden_ops, dtn):
+    for i, (Hq, Hkv, D, pre, ext) in enumerate(cases.EXTEND_CASES):
+        q, kc, vc, r2t, pool, seq, pre_t, ext_t = cases.extend_inputs(i, DT[dtn])
+        ref = ops_ref.extend_attention(q, kc, vc, r2t, pool, seq, pre_t, ext_t, D ** -0.5, Hq != Hkv, True)
+        o = _extend_run(ops, q, kc, vc, r2t, pool, seq, pre_t, ext_t, Hkv, D)
+        assert maxdiff(o, ref) <= ATTN_TOL[dtn], i
+        assert maxdiff(o, t(golden_ops[f"extend/{dtn}/{i}"])) <= ATTN_TOL[dtn]
+
+
+def test_extend_attention_reference_test_shapes(ops):
+    # test/srt/test_triton_attention_kernels.py:36-181: Hq=12, Hkv=4, D in {128, 96, 80, 13}
+    for D in (128, 96, 80, 13):
+        pre, ext = [31, 0, 200], [65, 130, 7]
+        seq = [a + b for a, b in zip(pre, ext)]
+        for dtn in ("f32", "bf16"):
+            dt = DT[dtn]
+            kc, vc, r2t, pool = cases.paged_inputs(77, dt, 3, 4, D, seq)
+            q = cases.randn((sum(ext), 12, D), 78, dt)
+            o = _extend_run(ops, q, kc, vc, r2t, pool, torch.tensor(seq), torch.tensor(pre), torch.tensor(ext), 4, D)
+            p = 0
+            for b in range(3):
+                toks = r2t[pool[b], : seq[b]].long()
+                ref = ops_ref.attention_fp64(q[p: p + ext[b]].transpose(0, 1), kc[toks].transpose(0, 1),
+                                             vc[toks].transpose(0, 1), D ** -0.5, pre[b]).transpose(0, 1)
+                assert maxdiff(o[p: p + ext[b]], ref) <= ATTN_TOL[dtn], (D, b)
+                p += ext[b]
+
+
+def test_extend_attention_custom_mask_equals_causal(ops):
+    # the reference checks causal flag == explicit lower-triangular custom mask (same file :120-181)
+    Hq, Hkv, D = 8, 2, 64
+    pre, ext = [5, 0], [9, 33]
+    seq = [a + b for a, b in zip(pre, ext)]
+    dt = torch.bfloat16
+    kc, vc, r2t, pool = cases.paged_inputs(91, dt, 2, Hkv, D, seq)
+    q = cases.randn((sum(ext), Hq, D), 92, dt)
+    base = _extend_run(ops, q, kc, vc, r2t, pool, torch.tensor(seq), torch.tensor(pre), torch.tensor(ext), Hkv, D)
+    masks, indptr = [], [0]
+    for p_, e_ in zip(pre, ext):
+        m = torch.zeros((e_, p_ + e_), dtype=torch.bool)
+        m[:, :p_] = True
+        m[:, p_:] = torch.tril(torch.ones(e_, e_, dtype=torch.bool))
+        masks.append(m.flatten())
+        indptr.append(indptr[-1] + m.numel())
+    T = sum(ext)
+    kext = torch.cat([kc[r2t[pool[b], pre[b]: seq[b]].long()] for b in range(2)])
+    vext = torch.cat([vc[r2t[pool[b], pre[b]: seq[b]].long()] for b in range(2)])
+    qo = torch.tensor([0, ext[0], T], dtype=torch.int32)
+    kvp = torch.tensor([0, pre[0], pre[0] + pre[1]], dtype=torch.int32)
+    kvi = ops_ref.create_kv_indices(r2t, pool, torch.tensor(pre))
+    o = torch.empty((T, Hq, D), dtype=dt, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), kext.to(DEV), vext.to(DEV), o, kc.to(DEV), vc.to(DEV), qo.to(DEV), kvp.to(DEV),
+                             kvi.to(DEV), torch.cat(masks).to(DEV), False, torch.tensor(indptr, dtype=torch.int64).to(DEV),
+                             max(ext), D ** -0.5, skip_prefix_custom_mask=False)
+    assert torch.equal(o, base)
+
+
+@pytest.mark.parametrize("dtn", list(DT))
+def test_linear(ops, dtn):
+    dt = DT[dtn]
+    shapes = [(1, 512, 512), (7, 1000, 256), (64, 768, 512), (33, 2048, 1536), (64, 1024, 4096), (100, 512, 300),
+              (5, 64, 8), (16, 4100, 1024)]
+    for (M, N, K) in shapes:
+        x = cases.randn((M, K), 7, dt)
+        w = cases.randn((N, K), 8, dt, 1.0 / math.sqrt(K))
+        ref = torch.nn.functional.linear(x, w)
+        exact = x.double() @ w.double().t()
+        got = ops.linear(x.to(DEV), w.to(DEV))
+        if dtn == "f32":
+            assert maxdiff(got, exact) <= 2e-5
+        else:
+            # fp32-accumulated, rounded once: within one rounding of the exact product, and as close
+            # to it as the CPU's own F.linear is
+            assert maxdiff(got, exact) <= max(1.5 * maxdiff(ref, exact), ROUND_TOL[dtn] / 2)
+    # strided input (a column slice) and fp32-widened output
+    x = cases.randn((9, 1024), 9, torch.bfloat16)
+    w = cases.randn((300, 512), 10, torch.bfloat16, 0.05)
+    got = ops.linear(x.to(DEV)[:, :512], w.to(DEV), out_dtype=torch.float32)
+    ref = (x[:, :512].double() @ w.double().t())
+    assert got.dtype == torch.float32 and maxdiff(got, ref) <= 1.6e-2
+    assert torch.equal(got, got.bfloat16().float()), "fp32 output must hold bf16-rounded values"
+
+
+def test_fp8_quant_and_gemm(ops, golden_ops):
+    for dtn in ("bf16", "f16", "f32"):
+        for (M, K) in ((5, 256), (64, 4096), (3, 1000)):
+            x = cases.randn((M, K), 900, DT[dtn])
+            qref, sref = ops_ref.per_token_quant_fp8(x)
+            q, s = ops.per_token_quant_fp8(x.to(DEV))
+            assert torch.equal(s.cpu(), sref), "scale = absmax/448 must be bit-exact"
+            assert torch.equal(q.cpu().float(), qref.float()), "fp8 codes must be bit-exact"
+    x = cases.randn((5, 256), 900, torch.bfloat16)
+    w = cases.randn((48, 256), 901, torch.float32, 0.05)
+    ws = w.abs().amax(1, keepdim=True) / 448.0
+    wq = (w / ws).clamp(-448, 448).to(torch.float8_e4m3fn)
+    xq, xs = ops.per_token_quant_fp8(x.to(DEV))
+    y = ops.fp8_scaled_mm(xq, wq.to(DEV), xs, ws.to(DEV), torch.bfloat16)
+    assert maxdiff(y, ops_ref.fp8_linear(x, wq, ws)) <= 8e-3
+    if "fp8/fallback_scaled_mm" in golden_ops:
+        assert maxdiff(y, t(golden_ops["fp8/fallback_scaled_mm"])) <= 1e-2
+    for (M, N, K) in ((64, 1024, 4096), (3, 1000, 1024), (16, 512, 14336), (100, 256, 512), (1, 4096, 4096)):
+        x = cases.randn((M, K), 11, torch.bfloat16)
+        w = cases.randn((N, K), 12, torch.float32, 1 / math.sqrt(K))
+        ws = w.abs().amax(1, keepdim=True) / 448.0
+        wq = (w / ws).clamp(-448, 448).to(torch.float8_e4m3fn)
+        xq, xs = ops.per_token_quant_fp8(x.to(DEV))
+        y = ops.fp8_scaled_mm(xq, wq.to(DEV), xs, ws.to(DEV), torch.bfloat16)
+        exact = (xq.cpu().double() @ wq.double().t()) * xs.cpu().double() * ws.double().t()
+        assert maxdiff(y, exact) <= 1.6e-2, (M, N, K)
+
+
+def test_sampling(ops, golden_ops):
+    for i in range(len(cases.SAMPLING_CASES)):
+        logits, temps, ks, ps, mps = cases.sampling_inputs(i)
+        assert torch.equal(ops.argmax(logits.to(DEV)).cpu(), t(golden_ops[f"sampling/{i}/argmax"]))
+        probs = ops.softmax_temperature_(logits.clone().to(DEV), temps.view(-1).to(DEV))
+        pref = ops_ref.softmax_temperature(logits, temps)
+        assert maxdiff(probs, pref) <= 1e-6
+        # draws land in the reference's kept set, for both filter variants
+        for use_minp in (False, True):
+            dist = ops_ref.kept_distribution(pref, ks, ps, mps if use_minp else None)
+            for trial in range(8):
+                u = torch.rand(logits.shape[0], generator=torch.Generator().manual_seed(trial))
+                ids = ops.top_k_top_p_min_p_sample(pref.to(DEV), ks.to(DEV), ps.to(DEV),
+                                                   mps.to(DEV) if use_minp else None, u.to(DEV)).cpu()
+                assert (dist.gather(1, ids.long()[:, None]) > 0).all()
+    # ties: first maximal index wins (torch.argmax rule)
+    lg = torch.zeros(3, 1000)
+    lg[0, 7] = lg[0, 500] = 5.0
+    lg[1, 999] = 1.0
+    assert ops.argmax(lg.to(DEV)).tolist() == [7, 999, 0]
+
+
+def test_sampling_distribution_matches_reference_sampler(ops):
+    """Statistical check in the style of sgl-kernel/tests/test_sampling.py: empirical frequencies
+    of the HIP sampler follow the reference sampler's renormalised distribution."""
+    V, n = 500, 20000
+    g = torch.Generator().manual_seed(3)
+    probs = torch.softmax(2 * torch.randn((1, V), generator=g), -1)
+    ks, ps = torch.tensor([25], dtype=torch.int32), torch.tensor([0.85])
+    dist = ops_ref.kept_distribution(probs, ks, ps)[0]
+    u = torch.rand(n, generator=g)
+    ids = ops.top_k_top_p_min_p_sample(probs.expand(n, V).contiguous().to(DEV), ks.expand(n).contiguous().to(DEV),
+                                       ps.expand(n).contiguous().to(DEV), None, u.to(DEV)).cpu()
+    emp = torch.bincount(ids.long(), minlength=V).float() / n
+    assert (emp[dist == 0] == 0).all()
+    assert (emp - dist).abs().sum() < 0.05
+    # same uniforms => same draws (deterministic given u)
+    ids2 = ops.top_k_top_p_min_p_sample(probs.expand(n, V).contiguous().to(DEV), ks.expand(n).contiguous().to(DEV),
+                                        ps.expand(n).contiguous().to(DEV), None, u.to(DEV)).cpu()
+    assert torch.equal(ids, ids2)
+
+
+def test_errors_are_reported_not_thrown_by_the_library(ops):
+    from sglang_custom_amd._lib import Mi355Error
+
+    x = torch.randn(4, 64, device=DEV).to(torch.float64)
+    with pytest.raises(TypeError):
+        ops.rmsnorm(x, torch.ones(64, device=DEV, dtype=torch.float64), 1e-5)
+    q = torch.randn(2, 8, 64, device=DEV)
+    kb = torch.randn(10, 3, 64, device=DEV)
+    with pytest.raises(Mi355Error):  # 8 q heads are not a multiple of 3 kv heads
+        ops.decode_attention_paged(q, kb, kb, torch.empty_like(q), torch.zeros(2, 8, dtype=torch.int32, device=DEV),
+                                   torch.zeros(2, dtype=torch.int64, device=DEV), torch.ones(2, dtype=torch.int64, device=DEV),
+                                   None, None, 1, 0.125)
+    with pytest.raises(RuntimeError):
+        ops.silu_and_mul(torch.randn(2, 8))  # CPU tensor: no fallback
