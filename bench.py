@@ -69,25 +69,25 @@ def gemm_shapes(cfg, tp):
 
 
 def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
-    """Average duration of the decode projection kernel (gemm_skinny_kernel) over one step's worth
-    of launches -- every layer's real weights in order, M = bs -- bracketed by HIP events on the
-    stream the kernels are launched on."""
-    from sglang_custom_amd import ops
+    """Average duration of the decode projection kernel (gemm_ring_kernel) over one step's worth
+    of launches -- every layer's real weights in order, M = bs, through the same call the model
+    makes -- bracketed by HIP events on the stream the kernels are launched on."""
+    from sglang_custom_amd.layers.quantization.unquant import decode_linear
 
     dev = mr.device
     layers = mr.model.model.layers
     x_h = torch.randn(bs, cfg["hidden_size"], device=dev).to(mr.dtype)
     x_attn = torch.randn(bs, layers[0].self_attn.o_proj.weight.shape[1], device=dev).to(mr.dtype)
     x_mlp = torch.randn(bs, layers[0].mlp.down_proj.weight.shape[1], device=dev).to(mr.dtype)
-    head = mr.model.lm_head.weight
+    head = mr.model.lm_head
 
     def one_pass():
         for layer in layers:
-            ops.linear(x_h, layer.self_attn.qkv_proj.weight)
-            ops.linear(x_attn, layer.self_attn.o_proj.weight)
-            ops.linear(x_h, layer.mlp.gate_up_proj.weight)
-            ops.linear(x_mlp, layer.mlp.down_proj.weight)
-        ops.linear(x_h, head, None, out_dtype=torch.float32)
+            decode_linear(layer.self_attn.qkv_proj, x_h, None)
+            decode_linear(layer.self_attn.o_proj, x_attn, None)
+            decode_linear(layer.mlp.gate_up_proj, x_h, None)
+            decode_linear(layer.mlp.down_proj, x_mlp, None)
+        decode_linear(head, x_h, None, out_dtype=torch.float32)
 
     stream = torch.cuda.current_stream()
     one_pass()
@@ -112,7 +112,7 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
         + bs * (cfg["hidden_size"] * dtype_bytes + cfg["vocab_size"] // tp * 4)
     bytes_per_launch = (wbytes + act) / launches
     dur_s = total_ms * 1e-3 / launches
-    return dict(kernel="gemm_skinny_kernel", launches_per_step=launches,
+    return dict(kernel="gemm_ring_kernel", launches_per_step=launches,
                 avg_duration_us=dur_s * 1e6, bytes_per_launch=bytes_per_launch,
                 achieved_gbs=bytes_per_launch / dur_s / 1e9)
 

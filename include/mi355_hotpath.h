@@ -186,6 +186,25 @@ int mi355_linear(void* y, const void* x, const void* w, const void* bias, int64_
                  int64_t k, int64_t x_stride, void* workspace, int64_t workspace_bytes,
                  int dtype, int out_dtype, void* stream);
 
+/* Decode-time weight layout.  mi355_pack_weight re-orders an [N, K] 16-bit weight into MFMA
+ * fragment order [ceil(N/16)][K/32][64][8] (mi355_packed_weight_elems(n,k) elements, zero padded),
+ * so that the weight-streaming kernel reads one contiguous 1-KiB block per wave-instruction;
+ * mi355_linear_packed is mi355_linear (M <= 64) on such a weight.  The packing plays the role of
+ * the reference's process_weights_after_loading hook, which repacks weights for its own CPU GEMM
+ * (python/sglang/srt/layers/amx_utils.py:_amx_process_weight_after_loading,
+ *  layers/quantization/unquant.py:105-108). */
+int64_t mi355_packed_weight_elems(int64_t n, int64_t k);
+int mi355_pack_weight(void* dst, const void* src, int64_t n, int64_t k, int dtype, void* stream);
+int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void* bias, int64_t m,
+                        int64_t n, int64_t k, int64_t x_stride, void* workspace,
+                        int64_t workspace_bytes, int dtype, int out_dtype, void* stream);
+
+/* Tuning / ablation switch (development only): key 0 selects the decode GEMM variant. */
+void mi355_debug_set(int key, int value);
+/* Read-bandwidth probe (development only): streams `bytes` from src with `grid` workgroups. */
+int mi355_debug_read_bw(const void* src, int64_t bytes, int grid, int unroll, void* sink,
+                        void* stream);
+
 /* ---- K14 fp8 W8A8 ------------------------------------------------------------------------------
  * Per-token dynamic quantisation to OCP e4m3fn (max 448): s[r] = max(absmax(x[r,:]), 1e-10)/448,
  * q = clamp(x/s, +-448) -> fp8.

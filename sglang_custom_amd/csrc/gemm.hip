@@ -11,6 +11,7 @@
 //    fp32 parity path and the fallback for shapes the skinny kernel does not take.
 #include "common.cuh"
 #include <algorithm>
+#include <cstdlib>
 
 namespace mi355 {
 
@@ -41,12 +42,13 @@ constexpr int SK_BK = 256;            // K elements per chunk
 constexpr int SK_LDS_ROW = SK_BK + 8; // padded LDS row (elements): 528 B rows spread banks
 
 // grid: (ceil(N / (64*NT)), splits).  block: 256.
-template <typename T, int MT, int NT, typename OUT>
+template <typename T, int MT, int NT, typename OUT, bool PACKED = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
     OUT* __restrict__ y, float* __restrict__ slab, int M, int N, int K, int64_t x_stride,
     int k_per_split) {
   using frag = typename Mfma<T>::frag;
+  constexpr int KMUL = PACKED ? 64 : 1;       // pointer advance per k element
   constexpr int R = 16 * MT;                  // activation rows held in LDS
   constexpr int XP = R * (SK_BK / 8) / 256;   // 16-B pieces of the x tile per thread (R/8)
   static_assert(XP >= 1, "tile too small");
@@ -55,7 +57,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int n_wave = blockIdx.x * (64 * NT) + wave * (16 * NT);
+  // 16-row weight tile of (wave, nt): the four waves of a workgroup own four adjacent tiles, so
+  // one instruction of the workgroup reads 4 KiB that are contiguous in the packed layout.
+  const int tile0 = blockIdx.x * (4 * NT) + wave;   // tile(nt) = tile0 + 4 * nt
+  const int ngroups = (N + 63) >> 6;
   const int ks = blockIdx.y * k_per_split;
   const int ke = min(K, ks + k_per_split);
   const int nchunks = (ke - ks + SK_BK - 1) / SK_BK;
@@ -64,9 +69,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
   const T* wrow[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    int n = n_wave + nt * 16 + r16;
+    int n = (tile0 + 4 * nt) * 16 + r16;
     n = n < N ? n : N - 1;
-    wrow[nt] = w + (int64_t)n * K + q * 8;
+    const int grp = min(blockIdx.x * NT + nt, ngroups - 1);
+    // packed: [N/64][K/32][4 tiles][64 lanes][8]
+    wrow[nt] = PACKED ? w + (((int64_t)grp * (K >> 5) * 4 + wave) * 64 + lane) * 8
+                      : w + (int64_t)n * K + q * 8;
   }
 
   f32x4 acc[NT][MT];
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
       for (int s = 0; s < 8; ++s) {
         const int k = kc + s * 32 + q * 8;
         if (k < ke) {
-          dst[nt][s] = *reinterpret_cast<const frag*>(wrow[nt] + kc + s * 32);
+          dst[nt][s] = *reinterpret_cast<const frag*>(wrow[nt] + (int64_t)(kc + s * 32) * KMUL);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) dst[nt][s][j] = (T)0.f;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
   // D[i = n (4q + r)][j = m (r16)]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n0 = n_wave + nt * 16 + q * 4;
+    const int n0 = (tile0 + 4 * nt) * 16 + q * 4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 16 + r16;
@@ -170,6 +178,247 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
       }
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Ring variant (K % 256 == 0): the decode-time kernel.
+//   * chunk = 256/NT k-elements; every wave keeps THREE chunks of its weight rows in VGPRs
+//     (computing / landed / in flight).  Queue order per iteration is x(c+1), W(c+2): the wait
+//     for the activation tile leaves W(c+2) in flight, so the HBM stream never drains at the
+//     per-chunk barrier.  All loads in the steady-state loop are unconditional, which lets the
+//     compiler emit counted s_waitcnt vmcnt(N) instead of vmcnt(0).
+//   * split-K partials are written in MFMA-fragment order (1-KiB coalesced stores) and the
+//     LAST workgroup to finish an output block sums all partials in split order and writes y:
+//     no second launch, deterministic, no spinning (the arrival counter is re-zeroed by the
+//     workgroup that consumes it).
+// grid: (ceil(N / (64*NT)), splits).  block: 256.
+// ------------------------------------------------------------------------------------------
+int g_gemm_variant = 0;   // tuning switches, see mi355_debug_set
+int g_force_splits = 0;
+
+template <typename T, int MT, int NT, typename OUT, bool PACKED>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
+    OUT* __restrict__ y, float* __restrict__ slab, unsigned* __restrict__ counters, int M, int N,
+    int K, int64_t x_stride, int k_per_split) {
+  using frag = typename Mfma<T>::frag;
+  constexpr int BK = 256 / NT;                // k elements per chunk
+  constexpr int S = BK / 32;                  // MFMA k-steps per chunk
+  constexpr int ROW = BK + 8;                 // padded LDS row: bank = 4 * row (mod 64)
+  constexpr int KMUL = PACKED ? 64 : 1;
+  constexpr int R = 16 * MT;
+  constexpr int XP = R * (BK / 8) / 256;      // 16-B pieces of the x tile per thread
+  static_assert(XP >= 1, "tile too small");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* xs = reinterpret_cast<T*>(smem_raw);     // [2][R][ROW]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int tile0 = blockIdx.x * (4 * NT) + wave;   // tile(nt) = tile0 + 4 * nt
+  const int ngroups = (N + 63) >> 6;
+  const int ks = blockIdx.y * k_per_split;
+  const int ke = min(K, ks + k_per_split);
+  const int nchunks = (ke - ks) / BK;               // host guarantees divisibility, >= 1
+
+  const T* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = (tile0 + 4 * nt) * 16 + r16;
+    n = n < N ? n : N - 1;
+    const int grp = min(blockIdx.x * NT + nt, ngroups - 1);
+    wrow[nt] = PACKED ? w + (((int64_t)grp * (K >> 5) * 4 + wave) * 64 + lane) * 8 + (int64_t)ks * KMUL
+                      : w + (int64_t)n * K + ks + q * 8;
+  }
+  // x tile piece p -> (row, 16-B column)
+  const T* xsrc[XP];
+  int xdst[XP];
+  bool xok[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int p = threadIdx.x + i * 256;
+    const int row = p / (BK / 8), c16 = p % (BK / 8);
+    xok[i] = row < M;
+    xsrc[i] = x + (int64_t)(row < M ? row : 0) * x_stride + ks + c16 * 8;
+    xdst[i] = row * ROW + c16 * 8;
+  }
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  frag w0[NT][S], w1[NT][S], w2[NT][S];
+  Vec<T, 8> xreg[XP];
+
+  auto load_w = [&](frag (&dst)[NT][S], int chunk) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const frag* src = reinterpret_cast<const frag*>(wrow[nt] + (int64_t)(chunk * BK + s * 32) * KMUL);
+        // packed weights are read exactly once, in whole lines: stream them past the caches
+        dst[nt][s] = PACKED ? __builtin_nontemporal_load(src) : *src;
+      }
+  };
+  auto load_x = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < XP; ++i) xreg[i] = ldvec<T, 8>(xsrc[i] + chunk * BK);
+  };
+  auto store_x = [&](int buf) {
+    T* dst = xs + buf * (R * ROW);
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      if (!xok[i]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xreg[i].v[j] = (T)0.f;
+      }
+      stvec<T, 8>(dst + xdst[i], xreg[i]);
+    }
+  };
+  auto compute = [&](const frag (&wc)[NT][S], int buf) {
+    const T* xt = xs + buf * (R * ROW) + r16 * ROW + q * 8;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      frag xf[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const frag*>(xt + mt * 16 * ROW + s * 32);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = Mfma<T>::run(wc[nt][s], xf[mt], acc[nt][mt]);
+    }
+  };
+  auto rotate = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        w0[nt][s] = w1[nt][s];
+        w1[nt][s] = w2[nt][s];
+      }
+  };
+
+  load_w(w0, 0);
+  load_x(0);
+  load_w(w1, nchunks > 1 ? 1 : 0);   // unconditional (clamped) so the wait below stays counted
+  store_x(0);
+  __syncthreads();
+
+  int c = 0;
+  for (; c + 2 < nchunks; ++c) {
+    load_x(c + 1);
+    load_w(w2, c + 2);
+    compute(w0, c & 1);
+    store_x((c + 1) & 1);
+    __syncthreads();
+    rotate();
+  }
+  if (c + 1 < nchunks) {
+    load_x(c + 1);
+    compute(w0, c & 1);
+    store_x((c + 1) & 1);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < S; ++s) w0[nt][s] = w1[nt][s];
+    ++c;
+  }
+  compute(w0, c & 1);
+
+  const int splits = gridDim.y;
+  if (splits == 1) {
+    // D[i = n (4q + r)][j = m (r16)]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n0 = (tile0 + 4 * nt) * 16 + q * 4;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + r16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + r;
+          if (n < N) y[(int64_t)m * N + n] = finish<T, OUT>(acc[nt][mt][r], bias ? to_f32(bias[n]) : 0.f);
+        }
+      }
+    }
+    return;
+  }
+
+  // split-K: partial tile in fragment order, [n-block][split][wave][nt][mt][lane][4], stored
+  // write-through (sc1) so that no release fence is needed: once a wave's stores have drained
+  // they are visible to every XCD.  The reducer reads them with sc1 loads (never a stale line).
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int TILE_BYTES = 64 * NT * R * 4;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<char*>(slab) + (int64_t)blockIdx.x * splits * TILE_BYTES), 0,
+      splits * TILE_BYTES, 0x00020000);
+  const int frag_off = ((wave * NT * MT) * 256 + lane * 4) * 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt][mt]), rs,
+                                             (int)blockIdx.y * TILE_BYTES + frag_off + (nt * MT + mt) * 1024,
+                                             0, 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                    // all waves' stores drained; x tiles in LDS are dead
+  int* last_flag = reinterpret_cast<int*>(smem_raw);
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&counters[blockIdx.x], 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (old == (unsigned)(splits - 1));
+  }
+  __syncthreads();
+  if (!*last_flag) return;
+  // Sum in split order.  Four splits' loads are issued back to back without conditions (clamped
+  // address, masked value) so the reducer pays one memory round trip per four splits.
+  f32x4 red[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < splits; s0 += 4) {
+    u32x4 v[4][NT][MT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = min(s0 + u, splits - 1);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          v[u][nt][mt] = __builtin_amdgcn_raw_buffer_load_b128(
+              rs, s * TILE_BYTES + frag_off + (nt * MT + mt) * 1024, 0, 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 f = __builtin_bit_cast(f32x4, v[u][nt][mt]);
+          if (s0 + u < splits) red[nt][mt] += f;
+        }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n0 = (tile0 + 4 * nt) * 16 + q * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + r16;
+      if (m >= M) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r;
+        if (n < N) y[(int64_t)m * N + n] = finish<T, OUT>(red[nt][mt][r], bias ? to_f32(bias[n]) : 0.f);
+      }
+    }
+  }
+  if (threadIdx.x == 0) counters[blockIdx.x] = 0u;   // leave the counter zero for the next launch
 }
 
 template <typename T, typename OUT>
@@ -240,22 +489,69 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const T* __restrict__ x
   }
 }
 
+
+// Re-order an nn.Linear weight [N, K] into MFMA A-operand fragment order
+// [ceil(N/64)][K/32][4 tiles][64 lanes][8]: lane (r = l & 15, q = l >> 4) of block
+// (group, kstep, t) holds W[64*group + 16*t + r][32*kstep + 8*q .. +7].  Rows >= N are zero.
+// Every wave-instruction of the decode GEMM then reads one contiguous 1-KiB block, the four
+// waves of a workgroup read 4 KiB side by side, and a workgroup walks K in one contiguous run.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(T* __restrict__ dst, const T* __restrict__ src,
+                                                          int64_t N, int64_t K) {
+  const int64_t ksteps = K >> 5;
+  const int64_t nblocks = ((N + 63) >> 6) * ksteps * 4;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nblocks * 64; v += (int64_t)gridDim.x * 256) {
+    const int64_t blk = v >> 6;
+    const int l = (int)(v & 63);
+    const int64_t t = blk & 3, gk = blk >> 2;
+    const int64_t grp = gk / ksteps, kstep = gk - grp * ksteps;
+    const int64_t n = grp * 64 + t * 16 + (l & 15), k = kstep * 32 + (l >> 4) * 8;
+    Vec<T, 8> val;
+    if (n < N) {
+      val = ldvec<T, 8>(src + n * K + k);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) val.v[j] = (T)0.f;
+    }
+    stvec<T, 8>(dst + v * 8, val);
+  }
+}
+
+// The arrival counters always occupy the same leading bytes of the workspace, whatever the shape,
+// so partial sums of one call can never land where another call expects zeroed counters.
+constexpr int64_t SK_COUNTER_BYTES = 4096;
+
 struct SkinnyPlan {
   int nt, splits, k_per_split;
+  int64_t counter_bytes;   // arrival counters at the head of the workspace (must start zeroed)
+  int64_t slab_bytes;      // fp32 split-K partials behind them
 };
 
-static SkinnyPlan plan_skinny(int64_t n, int64_t k) {
+// Split-K plan.  A workgroup owns 64*NT output columns; 2 workgroups are resident per CU, so the
+// chip holds 512 of them.  Splitting K buys parallelism for narrow outputs at the price of fp32
+// partial traffic (splits * M * N * 8 bytes written + read), so wide outputs are never split.
+static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k) {
   SkinnyPlan p;
   p.nt = n >= 64 * 1024 ? 2 : 1;  // very wide outputs (lm_head): 128 columns per workgroup
   const int64_t wg_n = (n + 64 * p.nt - 1) / (64 * p.nt);
-  int64_t splits = (512 + wg_n - 1) / wg_n;
+  // Measured on MI355X: one workgroup per CU (256-384 in all) with >= 4 chunks each beats 512
+  // shorter ones for narrow outputs; deep K (down_proj) takes 8.
+  int64_t splits = 1;
+  if (wg_n < 384 && wg_n <= SK_COUNTER_BYTES / 4) {
+    splits = (320 + wg_n - 1) / wg_n;
+    if (k / splits > 2048) splits = std::min<int64_t>((k + 1791) / 1792, 16);
+  }
   const int64_t max_splits = std::max<int64_t>(1, k / 512);
   splits = std::min(splits, max_splits);
   splits = std::max<int64_t>(splits, 1);
+  if (g_force_splits > 0) splits = std::min<int64_t>(g_force_splits, max_splits);
   int64_t kps = (k + splits - 1) / splits;
   kps = (kps + SK_BK - 1) / SK_BK * SK_BK;
   p.k_per_split = (int)kps;
   p.splits = (int)((k + kps - 1) / kps);
+  p.counter_bytes = p.splits > 1 ? SK_COUNTER_BYTES : 0;
+  const int64_t rows = (m + 15) / 16 * 16;
+  p.slab_bytes = p.splits > 1 ? (int64_t)p.splits * wg_n * 64 * p.nt * rows * (int64_t)sizeof(float) : 0;
   return p;
 }
 
@@ -265,34 +561,41 @@ static bool skinny_ok(int64_t m, int64_t n, int64_t k, int64_t x_stride, const v
          x_stride % 8 == 0 && aligned16(x) && aligned16(w) && n >= 1 && k >= 8;
 }
 
-template <typename T, int MT, int NT, typename OUT>
-static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, float* slab, int M,
+template <typename T, int MT, int NT, typename OUT, bool PACKED>
+static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, char* ws, int M,
                               int N, int K, int64_t x_stride, const SkinnyPlan& p,
                               hipStream_t st) {
   const dim3 grid((unsigned)((N + 64 * NT - 1) / (64 * NT)), (unsigned)p.splits);
+  unsigned* counters = p.splits > 1 ? reinterpret_cast<unsigned*>(ws) : nullptr;
+  float* slab = p.splits > 1 ? reinterpret_cast<float*>(ws + p.counter_bytes) : nullptr;
+  if (K % SK_BK == 0 && g_gemm_variant == 0) {
+    const size_t lds = 2 * (16 * MT) * (256 / NT + 8) * sizeof(T);
+    hipLaunchKernelGGL((gemm_ring_kernel<T, MT, NT, OUT, PACKED>), grid, dim3(256), lds, st, x, w, bias, y,
+                       slab, counters, M, N, K, x_stride, p.k_per_split);
+    return;
+  }
   const size_t lds = 2 * (16 * MT) * SK_LDS_ROW * sizeof(T);
-  hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, NT, OUT>), grid, dim3(256), lds, st, x, w, bias, y,
+  hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, NT, OUT, PACKED>), grid, dim3(256), lds, st, x, w, bias, y,
                      slab, M, N, K, x_stride, p.k_per_split);
+  if (p.splits > 1) {
+    const int64_t mn = (int64_t)M * N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T, OUT>), dim3((unsigned)((mn + 255) / 256)),
+                       dim3(256), 0, st, slab, bias, y, mn, N, p.splits);
+  }
 }
 
-template <typename T, typename OUT>
-static void launch_skinny(const T* x, const T* w, const T* bias, OUT* y, float* ws, int M, int N,
+template <typename T, typename OUT, bool PACKED = false>
+static void launch_skinny(const T* x, const T* w, const T* bias, OUT* y, void* ws, int M, int N,
                           int K, int64_t x_stride, hipStream_t st) {
-  const SkinnyPlan p = plan_skinny(N, K);
-  float* slab = p.splits > 1 ? ws : nullptr;
+  const SkinnyPlan p = plan_skinny(M, N, K);
   const int mt = (M + 15) / 16;
-#define SK(MT_, NT_) launch_skinny_cfg<T, MT_, NT_, OUT>(x, w, bias, y, slab, M, N, K, x_stride, p, st)
+#define SK(MT_, NT_) launch_skinny_cfg<T, MT_, NT_, OUT, PACKED>(x, w, bias, y, (char*)ws, M, N, K, x_stride, p, st)
   if (p.nt == 2) {
     if (mt <= 1) SK(1, 2); else if (mt <= 2) SK(2, 2); else SK(4, 2);
   } else {
     if (mt <= 1) SK(1, 1); else if (mt <= 2) SK(2, 1); else SK(4, 1);
   }
 #undef SK
-  if (p.splits > 1) {
-    const int64_t mn = (int64_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T, OUT>), dim3((unsigned)((mn + 255) / 256)),
-                       dim3(256), 0, st, slab, bias, y, mn, N, p.splits);
-  }
 }
 
 template <typename T, typename OUT>
@@ -301,8 +604,8 @@ static void launch_linear_t(void* y, const void* x, const void* w, const void* b
                             hipStream_t st) {
   if constexpr (!std::is_same<T, float>::value) {
     if (skinny) {
-      launch_skinny<T, OUT>((const T*)x, (const T*)w, (const T*)bias, (OUT*)y, (float*)ws, (int)m,
-                            (int)n, (int)k, x_stride, st);
+      launch_skinny<T, OUT>((const T*)x, (const T*)w, (const T*)bias, (OUT*)y, ws, (int)m, (int)n,
+                            (int)k, x_stride, st);
       return;
     }
   }
@@ -325,10 +628,68 @@ using namespace mi355;
 
 extern "C" {
 
+void mi355_debug_set(int key, int value) {
+  if (key == 0) g_gemm_variant = value;   // 0 = ring kernel (default), 1 = two-launch kernel
+  if (key == 2) g_force_splits = value;   // > 0 overrides the split-K plan
+}
+
 int64_t mi355_linear_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   if (m < 1 || m > 64 || n < 1 || k < 1) return 0;
-  const SkinnyPlan p = plan_skinny(n, k);
-  return p.splits > 1 ? (int64_t)p.splits * m * n * (int64_t)sizeof(float) : 0;
+  const SkinnyPlan p = plan_skinny(m, n, k);
+  return p.counter_bytes + p.slab_bytes;
+}
+
+int64_t mi355_packed_weight_elems(int64_t n, int64_t k) { return ((n + 63) / 64) * 64 * k; }
+
+int mi355_pack_weight(void* dst, const void* src, int64_t n, int64_t k, int dtype, void* stream) {
+  MI355_REQUIRE(dst && src, MI355_ERR_INVALID, "pack_weight: null pointer");
+  MI355_REQUIRE(n > 0 && k > 0 && k % 32 == 0, MI355_ERR_INVALID,
+                "pack_weight: K (%lld) must be a positive multiple of 32", (long long)k);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "pack_weight: only 16-bit weights are packed");
+  MI355_REQUIRE(aligned16(dst) && aligned16(src), MI355_ERR_INVALID, "pack_weight: pointers must be 16-B aligned");
+  const int64_t vecs = ((n + 63) / 64) * 4 * (k / 32) * 64;
+  const int grid = (int)std::min<int64_t>((vecs + 255) / 256, 256 * 32);
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)dst, (const bf16_t*)src, n, k);
+  else
+    hipLaunchKernelGGL((pack_weight_kernel<f16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (f16_t*)dst, (const f16_t*)src, n, k);
+  MI355_CHECK_LAUNCH("pack_weight");
+  return MI355_OK;
+}
+
+int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void* bias, int64_t m,
+                        int64_t n, int64_t k, int64_t x_stride, void* workspace,
+                        int64_t workspace_bytes, int dtype, int out_dtype, void* stream) {
+  MI355_REQUIRE(y && x && w_packed, MI355_ERR_INVALID, "linear_packed: null pointer");
+  MI355_REQUIRE(m >= 0 && m <= 64 && n > 0 && k > 0 && k % 32 == 0 && x_stride >= k && x_stride % 8 == 0,
+                MI355_ERR_INVALID, "linear_packed: needs 0 <= M <= 64, K %% 32 == 0 (m=%lld n=%lld k=%lld)",
+                (long long)m, (long long)n, (long long)k);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "linear_packed: only 16-bit dtypes");
+  MI355_REQUIRE(out_dtype == dtype || out_dtype == MI355_F32, MI355_ERR_UNSUPPORTED,
+                "linear_packed: out_dtype must equal dtype or be fp32");
+  MI355_REQUIRE(aligned16(x) && aligned16(w_packed), MI355_ERR_INVALID, "linear_packed: misaligned pointer");
+  if (m == 0) return MI355_OK;
+  const int64_t need = mi355_linear_workspace_bytes(m, n, k);
+  if (need > 0 && (!workspace || workspace_bytes < need || !aligned16(workspace))) {
+    set_error("linear_packed: workspace of %lld bytes (16-B aligned) required, got %lld", (long long)need,
+              (long long)workspace_bytes);
+    return MI355_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bool f32o = out_dtype == MI355_F32;
+  if (dtype == MI355_BF16) {
+    if (f32o) launch_skinny<bf16_t, float, true>((const bf16_t*)x, (const bf16_t*)w_packed, (const bf16_t*)bias, (float*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
+    else launch_skinny<bf16_t, bf16_t, true>((const bf16_t*)x, (const bf16_t*)w_packed, (const bf16_t*)bias, (bf16_t*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
+  } else {
+    if (f32o) launch_skinny<f16_t, float, true>((const f16_t*)x, (const f16_t*)w_packed, (const f16_t*)bias, (float*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
+    else launch_skinny<f16_t, f16_t, true>((const f16_t*)x, (const f16_t*)w_packed, (const f16_t*)bias, (f16_t*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
+  }
+  MI355_CHECK_LAUNCH("linear_packed");
+  return MI355_OK;
 }
 
 int mi355_linear(void* y, const void* x, const void* w, const void* bias, int64_t m, int64_t n,

@@ -12,6 +12,7 @@ from ..distributed.parallel_state import (
     tensor_model_parallel_all_gather,
 )
 from ..ops_backend import get_ops
+from .quantization.unquant import decode_linear
 
 
 @dataclasses.dataclass
@@ -43,16 +44,15 @@ class LogitsProcessor(nn.Module):
         return LogitsProcessorOutput(next_token_logits=logits)
 
     def _get_logits(self, hidden_states: torch.Tensor, lm_head) -> torch.Tensor:
-        ops = get_ops()
         w = lm_head.weight
         single = not self.do_tensor_parallel_all_gather and self.logit_scale is None
         x = hidden_states.to(w.dtype)
         if single and (x.shape[0] <= 64 or x.dtype == torch.float32 or not x.is_cuda):
             # T-rounded logits widened to fp32 in the GEMM epilogue (= matmul(...).float())
-            logits = ops.linear(x, w, None, out_dtype=torch.float32)
+            logits = decode_linear(lm_head, x, None, out_dtype=torch.float32)
             return logits[:, : self.config.vocab_size]
         if x.shape[0] <= 64 or x.dtype == torch.float32 or not x.is_cuda:
-            logits = ops.linear(x, w, None)
+            logits = decode_linear(lm_head, x, None)
         else:
             logits = torch.matmul(x, w.T)
         if self.logit_scale is not None:

@@ -14,15 +14,34 @@ from ...ops_backend import get_ops
 SKINNY_MAX_M = 64
 
 
+def pack_for_decode(layer) -> None:
+    """Keep a second copy of a 16-bit weight in the decode GEMM's streaming order (MFMA-fragment
+    blocks, ops.pack_weight).  The row-major copy stays: prefill GEMMs, the embedding gather and
+    checkpoint loading use it.  2x weight bytes is the price of reading decode weights as whole
+    contiguous lines; at 288 GB of HBM per GPU it is not the binding constraint."""
+    w = layer.weight
+    layer.weight_packed = None
+    if w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and w.shape[1] % 32 == 0:
+        layer.weight_packed = get_ops().pack_weight(w.data)
+
+
+def decode_linear(layer, x2: torch.Tensor, bias: Optional[torch.Tensor], out_dtype=None) -> torch.Tensor:
+    """M <= 64 rows (or fp32): the hand-written kernels, on the packed copy when there is one."""
+    ops = get_ops()
+    wp = getattr(layer, "weight_packed", None)
+    if wp is not None and x2.shape[0] <= SKINNY_MAX_M and x2.stride(0) % 8 == 0:
+        return ops.linear_packed(x2, wp, layer.weight.shape[0], bias, out_dtype=out_dtype)
+    return ops.linear(x2, layer.weight, bias, out_dtype=out_dtype)
+
+
 class UnquantizedLinearMethod:
     def process_weights_after_loading(self, layer) -> None:
-        pass
+        pack_for_decode(layer)
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        ops = get_ops()
         x2 = x.view(-1, x.shape[-1])
         if x2.shape[0] <= SKINNY_MAX_M or x2.dtype == torch.float32 or not x2.is_cuda:
-            y = ops.linear(x2, layer.weight, bias)
+            y = decode_linear(layer, x2, bias)
         else:
             y = F.linear(x2, layer.weight, bias)
         return y.view(*x.shape[:-1], y.shape[-1])

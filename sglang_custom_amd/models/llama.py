@@ -18,6 +18,7 @@ from ..layers.activation import SiluAndMul
 from ..layers.layernorm import RMSNorm
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from ..layers.logits_processor import LogitsProcessor
+from ..layers.quantization.unquant import pack_for_decode
 from ..layers.radix_attention import RadixAttention
 from ..layers.rotary_embedding import get_rope
 from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
@@ -130,8 +131,6 @@ class LlamaForCausalLM(nn.Module):
         for m in self.modules():
             if isinstance(m, RMSNorm):
                 m.weight.data = m.weight.data.to(dtype=dtype, device=device)
-        for name, buf in list(self.named_buffers()):
-            pass
         self.to(device)
 
     @torch.no_grad()
@@ -170,6 +169,7 @@ class LlamaForCausalLM(nn.Module):
             for lin in (layer.self_attn.qkv_proj, layer.self_attn.o_proj, layer.mlp.gate_up_proj,
                         layer.mlp.down_proj):
                 lin.quant_method.process_weights_after_loading(lin)
+        pack_for_decode(self.lm_head)
 
     @torch.no_grad()
     def init_random_weights(self, seed: int = 0, std: float = 0.02) -> None:

@@ -300,13 +300,16 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
 _WS = {}
 
 
-def _workspace(device, nbytes: int) -> torch.Tensor:
-    """Per-device grow-only scratch for split-K slabs (allocated outside graph capture by the
-    first eager call of each shape; ModelRunner warms every shape up before capturing)."""
-    ws = _WS.get(device)
+def _workspace(device, nbytes: int, tag: str = "linear") -> torch.Tensor:
+    """Per-device, per-kernel-family grow-only scratch for split-K partials (allocated outside
+    graph capture by the first eager call of each shape; ModelRunner warms every shape up before
+    capturing).  Zero-filled at allocation: the 16-bit GEMM keeps its arrival counters at the head
+    of the buffer and hands them back zeroed after every launch.  Launches that share a buffer
+    must be ordered on one stream."""
+    ws = _WS.get((device, tag))
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = ws
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[(device, tag)] = ws
     return ws
 
 
@@ -329,6 +332,38 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     check(lib.mi355_linear(y.data_ptr(), x.data_ptr(), weight.data_ptr(), _p(bias), M, N, K,
                            x.stride(0), _p(ws), ws.numel() if ws is not None else 0, _dt(x),
                            _DT[out_dtype], _stream(x)), "linear")
+    return y
+
+
+def pack_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[N, K] 16-bit weight -> MFMA-fragment-ordered copy for linear_packed (decode GEMMs)."""
+    _gpu(weight)
+    assert weight.dim() == 2 and weight.is_contiguous() and weight.dtype in (torch.bfloat16, torch.float16)
+    N, K = weight.shape
+    lib = _lib_()
+    out = torch.empty(lib.mi355_packed_weight_elems(N, K), dtype=weight.dtype, device=weight.device)
+    check(lib.mi355_pack_weight(out.data_ptr(), weight.data_ptr(), N, K, _dt(weight), _stream(weight)),
+          "pack_weight")
+    return out
+
+
+def linear_packed(x: torch.Tensor, weight_packed: torch.Tensor, n: int, bias: Optional[torch.Tensor] = None,
+                  out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """linear() for M <= 64 on a weight produced by pack_weight (n = number of output features)."""
+    _gpu(x, weight_packed, bias)
+    assert x.dim() == 2 and x.stride(1) == 1 and weight_packed.dtype == x.dtype
+    M, K = x.shape
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((M, n), dtype=out_dtype, device=x.device)
+    if M == 0:
+        return y
+    lib = _lib_()
+    assert weight_packed.numel() == lib.mi355_packed_weight_elems(n, K)
+    need = lib.mi355_linear_workspace_bytes(M, n, K)
+    ws = _workspace(x.device, need) if need > 0 else None
+    check(lib.mi355_linear_packed(y.data_ptr(), x.data_ptr(), weight_packed.data_ptr(), _p(bias), M, n, K,
+                                  x.stride(0), _p(ws), ws.numel() if ws is not None else 0, _dt(x),
+                                  _DT[out_dtype], _stream(x)), "linear_packed")
     return y
 
 
@@ -358,7 +393,7 @@ def fp8_scaled_mm(xq: torch.Tensor, wq: torch.Tensor, x_scale: torch.Tensor, w_s
     y = torch.empty((M, N), dtype=out_dtype, device=xq.device)
     lib = _lib_()
     need = lib.mi355_fp8_workspace_bytes(M, N, K)
-    ws = _workspace(xq.device, need) if need > 0 else None
+    ws = _workspace(xq.device, need, "fp8") if need > 0 else None
     check(lib.mi355_fp8_scaled_mm(y.data_ptr(), xq.data_ptr(), wq.data_ptr(), x_scale.data_ptr(),
                                   w_scale.data_ptr(), _p(bias), M, N, K, _p(ws),
                                   ws.numel() if ws is not None else 0, _DT[out_dtype],

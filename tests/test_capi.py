@@ -69,6 +69,10 @@ def test_planner_is_pure_host_logic(lib):
     assert lib.mi355_decode_num_splits(1, 8, 1100, 64) == 8
     assert lib.mi355_decode_num_splits(1, 8, 100000, 16) == 16
     assert lib.mi355_decode_num_splits(256, 8, 50, 64) == 1
-    assert lib.mi355_linear_workspace_bytes(64, 4096, 4096) == 8 * 64 * 4096 * 4
+    # o_proj at batch 64: 64 column blocks x 4 K-splits -> 4 KiB of arrival counters + fp32 partials
+    assert lib.mi355_linear_workspace_bytes(64, 4096, 4096) == 4096 + 4 * 64 * 4096 * 4
+    # partial tiles are whole 16-row MFMA tiles
+    assert lib.mi355_linear_workspace_bytes(5, 4096, 4096) == 4096 + 4 * 16 * 4096 * 4
+    assert lib.mi355_linear_workspace_bytes(64, 28672, 4096) == 0    # wide outputs are never split
     assert lib.mi355_linear_workspace_bytes(64, 128256, 4096) == 0
     assert lib.mi355_linear_workspace_bytes(65, 4096, 4096) == 0

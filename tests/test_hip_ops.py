@@ -318,6 +318,45 @@ def test_linear(ops, dtn):
     assert torch.equal(got, got.bfloat16().float()), "fp32 output must hold bf16-rounded values"
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+def test_linear_packed_and_split_k(ops, dtn):
+    """The packed-weight decode GEMM against the exact product, across the shapes that pick each
+    split-K plan (none / in-launch combine of 2..16 partials), ragged N, every M tile count, bias,
+    fp32 output; repeated calls on one workspace must give identical bits (the arrival counters
+    come back zeroed) and a second, smaller call right after a larger one must not see its data."""
+    dt = DT[dtn]
+    shapes = [(64, 4096, 4096), (64, 1024, 14336), (33, 6144, 2048), (17, 28672 // 4, 1024), (1, 512, 512),
+              (64, 1000, 256), (48, 200, 7168), (5, 70000, 256), (16, 4100, 1024), (64, 64, 32)]
+    prev = None
+    for i, (M, N, K) in enumerate(shapes):
+        x = cases.randn((M, K), 70 + i, dt)
+        w = cases.randn((N, K), 90 + i, dt, 1.0 / math.sqrt(K))
+        b = cases.randn((N,), 110 + i, dt) if i % 2 else None
+        exact = x.double() @ w.double().t() + (b.double() if b is not None else 0.0)
+        ref = torch.nn.functional.linear(x.float(), w.float(), b.float() if b is not None else None).to(dt)
+        wd = w.to(DEV)
+        wp = ops.pack_weight(wd)
+        assert wp.numel() == (N + 63) // 64 * 64 * K
+        bd = b.to(DEV) if b is not None else None
+        got = ops.linear_packed(x.to(DEV), wp, N, bd)
+        assert got.shape == (M, N) and got.dtype == dt
+        assert maxdiff(got, exact) <= max(1.5 * maxdiff(ref, exact), ROUND_TOL[dtn] / 2), (M, N, K)
+        # same bits as the row-major kernel (same accumulation order), and on every repeat
+        assert torch.equal(got, ops.linear(x.to(DEV), wd, bd)), (M, N, K)
+        for _ in range(3):
+            assert torch.equal(got, ops.linear_packed(x.to(DEV), wp, N, bd))
+        if prev is not None:
+            px, pwp, pN, pb, pgot = prev
+            assert torch.equal(pgot, ops.linear_packed(px, pwp, pN, pb))
+        prev = (x.to(DEV), wp, N, bd, got)
+        got32 = ops.linear_packed(x.to(DEV), wp, N, bd, out_dtype=torch.float32)
+        assert got32.dtype == torch.float32 and torch.equal(got32, got.float())
+    # strided activations (a column slice of a wider buffer)
+    x = cases.randn((9, 1024), 9, dt).to(DEV)
+    w = cases.randn((300, 512), 10, dt, 0.05).to(DEV)
+    assert torch.equal(ops.linear_packed(x[:, :512], ops.pack_weight(w), 300), ops.linear(x[:, :512].contiguous(), w))
+
+
 def test_fp8_quant_and_gemm(ops, golden_ops):
     for dtn in ("bf16", "f16", "f32"):
         for (M, K) in ((5, 256), (64, 4096), (3, 1000)):
