@@ -11,6 +11,7 @@
 // No MFMA here on purpose: at G <= 8 the kernel sits on the HBM roof with VALU to spare.
 #include "common.cuh"
 #include <math.h>
+#include <type_traits>
 
 namespace mi355 {
 
@@ -43,8 +44,50 @@ __device__ __forceinline__ void seq_range(const DecodeParams& p, int b, int64_t&
 
 __device__ __forceinline__ float safe_m(float m) { return m == -INFINITY ? 0.f : m; }
 
+// Sum over the LPR consecutive lanes that hold one K row.  Up to 16 lanes the exchange is done
+// with DPP row operations (no LDS crossbar traffic); wider groups finish with xor-shuffles.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int LPR> __device__ __forceinline__ float group_sum(float x) {
+  if (LPR >= 2) x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
+  if (LPR >= 4) x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
+  if (LPR >= 8) x = dpp_add<0x141>(x);   // row_half_mirror
+  if (LPR >= 16) x = dpp_add<0x140>(x);  // row_mirror
+  if (LPR >= 32) x += __shfl_xor(x, 16, 64);
+  if (LPR >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// q . k over one 16-byte vector pair, fp32 accumulate.  16-bit types use the packed dot
+// instructions (two MACs per lane-instruction, no widening of K).
+__device__ __forceinline__ float dot16(const Vec<bf16_t, 8>& a, const Vec<bf16_t, 8>& b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  float d = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    d = __builtin_amdgcn_fdot2_f32_bf16(bf2{a.v[2 * j], a.v[2 * j + 1]}, bf2{b.v[2 * j], b.v[2 * j + 1]}, d, false);
+  return d;
+}
+__device__ __forceinline__ float dot16(const Vec<f16_t, 8>& a, const Vec<f16_t, 8>& b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  float d = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    d = __builtin_amdgcn_fdot2(h2{a.v[2 * j], a.v[2 * j + 1]}, h2{b.v[2 * j], b.v[2 * j + 1]}, d, false);
+  return d;
+}
+__device__ __forceinline__ float dot16(const Vec<float, 4>& a, const Vec<float, 4>& b) {
+  float d = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d = fmaf(a.v[j], b.v[j], d);
+  return d;
+}
+
 // grid: (hkv * (gtotal / G), num_splits, B); block 256 = 4 waves.
-template <typename T, int D, int G, int U>
+// Each wave walks its keys in steps of KPI*U rows.  The loop is software-pipelined: the K/V rows
+// of step i+1 and the page-table entries of step i+2 are in flight while step i is computed.
+template <typename T, int D, int G, int U, bool CAP>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ q,
                                                           const T* __restrict__ kbuf,
                                                           const T* __restrict__ vbuf,
@@ -52,6 +95,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   constexpr int VE = V16<T>::n;   // elements per 16-B access
   constexpr int LPR = D / VE;     // lanes per K/V row
   constexpr int KPI = 64 / LPR;   // rows per wave-instruction
+  constexpr int KPW = KPI * U;    // rows per wave per step
   static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "head_dim not supported");
   __shared__ float sm_acc[4][G][D];
   __shared__ float sm_m[4][G];
@@ -59,8 +103,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 
   const int gtotal = p.hq / p.hkv;
   const int groups_per_kv = gtotal / G;
-  const int kvh = blockIdx.x / groups_per_kv;
-  const int head0 = kvh * gtotal + (blockIdx.x % groups_per_kv) * G;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id, so with 8 kv heads a plain
+  // blockIdx.x -> head map would pin each head (one 256-B slice of every 2-KiB token row) to one
+  // XCD and funnel that XCD's traffic through a fraction of its L2 channels.  Rotating the head
+  // by (sequence + split) gives every XCD every slice.
+  const int xrot = (blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x;
+  const int kvh = xrot / groups_per_kv;
+  const int head0 = kvh * gtotal + (xrot % groups_per_kv) * G;
   const int split = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kslot = lane / LPR, dchunk = lane % LPR;
@@ -71,17 +120,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
 
-  // q for this lane's d-chunk, pre-scaled.  Without a logit cap the softmax runs in the
-  // log2 domain, so fold log2(e) in as well.
-  const bool cap = p.logit_cap > 0.f;
-  const float qmul = cap ? p.sm_scale : p.sm_scale * kLog2e;
-  float qf[G][VE];
+  // Scores are (q . k) * sm_scale; without a logit cap the softmax runs in the log2 domain, so
+  // log2(e) is folded into the multiplier.
+  const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+  Vec<T, VE> qv[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    Vec<T, VE> qv = ldvec<T, VE>(q + (int64_t)b * p.q_stride + (int64_t)(head0 + g) * D + dchunk * VE);
-#pragma unroll
-    for (int j = 0; j < VE; ++j) qf[g][j] = to_f32(qv.v[j]) * qmul;
-  }
+  for (int g = 0; g < G; ++g)
+    qv[g] = ldvec<T, VE>(q + (int64_t)b * p.q_stride + (int64_t)(head0 + g) * D + dchunk * VE);
 
   float m[G], l[G], acc[G][VE];
 #pragma unroll
@@ -96,52 +141,49 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const int64_t row_stride = (int64_t)p.hkv * D;
   const T* kbase = kbuf + (int64_t)kvh * D + dchunk * VE;
   const T* vbase = vbuf + (int64_t)kvh * D + dchunk * VE;
-  constexpr int KEYS_PER_WAVE_ITER = KPI * U;
 
-  for (int64_t base = k0 + (int64_t)wave * KEYS_PER_WAVE_ITER; base < k1;
-       base += 4 * KEYS_PER_WAVE_ITER) {
-    int64_t slot[U];
-    bool valid[U];
+  const int64_t first = k0 + (int64_t)wave * KPW + kslot;   // this lane's row in step 0, u = 0
+  const int64_t wave_first = k0 + (int64_t)wave * KPW;
+  const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 4 * KPW - 1) / (4 * KPW)) : 0;
+  const int64_t last_key = len - 1;
+
+  // Page-table reads are clamped to the sequence, never predicated: unconditional loads keep the
+  // compiler's s_waitcnt counted, so the prefetches below really stay in flight.
+  auto load_slots = [&](int it, int32_t (&slot)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t key = base + u * KPI + kslot;
-      valid[u] = key < k1;
-      slot[u] = valid[u] ? (int64_t)pt[key] : 0;  // slot 0 always exists (padding sink row)
+      int64_t key = first + (int64_t)it * (4 * KPW) + u * KPI;
+      key = key < last_key ? key : last_key;
+      slot[u] = pt[key];
     }
-    Vec<T, VE> kv[U], vv[U];
+  };
+  auto load_kv = [&](const int32_t (&slot)[U], Vec<T, VE> (&kv)[U], Vec<T, VE> (&vv)[U]) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) kv[u] = ldvec<T, VE>(kbase + slot[u] * row_stride);
+    for (int u = 0; u < U; ++u) kv[u] = ldvec<T, VE>(kbase + (int64_t)slot[u] * row_stride);
 #pragma unroll
-    for (int u = 0; u < U; ++u) vv[u] = ldvec<T, VE>(vbase + slot[u] * row_stride);
-
+    for (int u = 0; u < U; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)slot[u] * row_stride);
+  };
+  auto compute = [&](int it, const Vec<T, VE> (&kv)[U], const Vec<T, VE> (&vv)[U]) {
     float s[U][G];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float kf[VE];
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int j = 0; j < VE; ++j) kf[j] = to_f32(kv[u].v[j]);
+      for (int g = 0; g < G; ++g) s[u][g] = group_sum<LPR>(dot16(qv[g], kv[u]));
+    bool valid[U];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float d = 0.f;
+    for (int u = 0; u < U; ++u) valid[u] = first + (int64_t)it * (4 * KPW) + u * KPI < k1;
+    float vf[U][VE];
 #pragma unroll
-        for (int j = 0; j < VE; ++j) d = fmaf(qf[g][j], kf[j], d);
-        s[u][g] = d;
-      }
-    }
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1)
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int g = 0; g < G; ++g) s[u][g] += __shfl_xor(s[u][g], off, 64);
-
+      for (int j = 0; j < VE; ++j) vf[u][j] = to_f32(vv[u].v[j]);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float mx = m[g];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        float x = s[u][g];
-        if (cap) x = p.logit_cap * tanhf(x / p.logit_cap) * kLog2e;
+        float x = s[u][g] * qmul;
+        if (CAP) x = p.logit_cap * tanhf(x / p.logit_cap) * kLog2e;
         x = valid[u] ? x : -INFINITY;
         s[u][g] = x;
         mx = fmaxf(mx, x);
@@ -160,10 +202,29 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       for (int j = 0; j < VE; ++j) {
         float a = acc[g][j] * alpha;
 #pragma unroll
-        for (int u = 0; u < U; ++u) a = fmaf(pu[u], to_f32(vv[u].v[j]), a);
+        for (int u = 0; u < U; ++u) a = fmaf(pu[u], vf[u][j], a);
         acc[g][j] = a;
       }
     }
+  };
+
+  if (n_iter > 0) {
+    Vec<T, VE> kvA[U], vvA[U], kvB[U], vvB[U];
+    int32_t slotA[U], slotB[U];
+    load_slots(0, slotA);
+    load_slots(1, slotB);
+    load_kv(slotA, kvA, vvA);
+    for (int it = 0; it + 1 < n_iter; ++it) {
+      load_kv(slotB, kvB, vvB);
+      load_slots(it + 2, slotB);
+      compute(it, kvA, vvA);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        kvA[u] = kvB[u];
+        vvA[u] = vvB[u];
+      }
+    }
+    compute(n_iter - 1, kvA, vvA);
   }
 
   // merge the KPI row-groups of this wave
@@ -196,6 +257,226 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   }
   __syncthreads();
   // merge the 4 waves and write out
+  for (int idx = threadIdx.x; idx < G * D; idx += 256) {
+    const int g = idx / D, d = idx - g * D;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mx = fmaxf(mx, sm_m[w][g]);
+    const float ms = safe_m(mx);
+    float lt = 0.f, at = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = exp2f(sm_m[w][g] - ms);
+      lt += sm_l[w][g] * f;
+      at += sm_acc[w][g][d] * f;
+    }
+    const float val = lt > 0.f ? at / lt : 0.f;
+    const int head = head0 + g;
+    if (p.num_splits == 1) {
+      o[((int64_t)b * p.hq + head) * D + d] = from_f32<T>(val);
+    } else {
+      const int64_t ph = ((int64_t)b * p.hq + head) * p.num_splits + split;
+      p.part_o[ph * D + d] = val;
+      if (d == 0) p.part_lse[ph] = lt > 0.f ? mx * kLn2 + logf(lt) : -INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// head_dim 128, 16-bit: Q.K^T on the matrix cores, P.V on the vector ALU.
+//
+// A wave takes 16 keys per step.  K rows are loaded straight into MFMA A-fragments (lane
+// (r = l & 15, c = l >> 4) reads 16 B of key r at feature 32*s + 8*c for s = 0..3), the G query
+// heads sit in the B operand (columns >= G are zero), so four v_mfma_f32_16x16x32 give the whole
+// 16 x G score tile and lane (g, c) ends up with the scores of head g for keys 4c..4c+3 -- with no
+// cross-lane reduction at all.  That lane runs the online softmax for its four keys and hands
+// p[0..3] and the rescale factor to the 16 lanes of ITS OWN row c through LDS; those lanes hold
+// V rows 4c..4c+3 (16 B of each) and the fp32 accumulators for their 8 features.  Every row c
+// therefore keeps an independent softmax state; rows and waves are merged once at the end.
+// The vector ALU does only the P.V multiply-adds: a wave64 VALU instruction costs 4 cycles, and
+// the all-VALU kernel above spends about as long issuing them as the chip needs to stream K/V.
+// ------------------------------------------------------------------------------------------
+template <typename T, int G, bool CAP>
+__global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const T* __restrict__ q,
+                                                               const T* __restrict__ kbuf,
+                                                               const T* __restrict__ vbuf,
+                                                               T* __restrict__ o, DecodeParams p) {
+  constexpr int D = 128, VE = 8;
+  using frag = typename Mfma<T>::frag;
+  __shared__ float sm_acc[4][G][D];
+  __shared__ float sm_m[4][G];
+  __shared__ float sm_l[4][G];
+  __shared__ __attribute__((aligned(16))) float sm_p[4][4][G][8];   // [wave][row c][g]{p0..p3, alpha, m, l, -}
+
+  const int gtotal = p.hq / p.hkv;
+  const int groups_per_kv = gtotal / G;
+  const int xrot = (blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x;
+  const int kvh = xrot / groups_per_kv;
+  const int head0 = kvh * gtotal + (xrot % groups_per_kv) * G;
+  const int split = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, c4 = lane >> 4;
+
+  int64_t page_off, len;
+  seq_range(p, b, page_off, len);
+  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t k0 = (int64_t)split * chunk;
+  const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
+  const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  // B operand: Q[head0 + j][32 s + 8 c + 0..7] in lane (j = r16, c); zero columns for j >= G
+  frag qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (r16 < G) {
+      qf[s] = *reinterpret_cast<const frag*>(q + (int64_t)b * p.q_stride + (int64_t)(head0 + r16) * D + 32 * s + 8 * c4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
+    }
+  }
+
+  float m = -INFINITY, l = 0.f;   // softmax state of lane (g = r16, row c4); meaningful for r16 < G
+  float acc[G][VE];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int j = 0; j < VE; ++j) acc[g][j] = 0.f;
+
+  const int32_t* pt = p.page_table + page_off;
+  const int64_t row_stride = (int64_t)p.hkv * D;
+  const T* kbase = kbuf + (int64_t)kvh * D + 8 * c4;     // + slot * row_stride + 32 s
+  const T* vbase = vbuf + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
+  const int64_t wave_first = k0 + (int64_t)wave * 16;
+  const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 63) / 64) : 0;
+  const int64_t last_key = len - 1;
+  float* my_p = &sm_p[wave][c4][0][0];
+
+  auto load_slots = [&](int it, int32_t& sk, int32_t (&sv)[4]) {
+    const int64_t tb = wave_first + (int64_t)it * 64;
+    int64_t key = tb + r16;
+    sk = pt[key < last_key ? key : last_key];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      key = tb + 4 * c4 + u;
+      sv[u] = pt[key < last_key ? key : last_key];
+    }
+  };
+
+  auto load_kv = [&](int32_t sk, const int32_t (&sv)[4], frag (&kf)[4], Vec<T, VE> (&vv)[4]) {
+    const T* krow = kbase + (int64_t)sk * row_stride;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)sv[u] * row_stride);
+  };
+
+  if (n_iter > 0) {
+    // The page-table entries of step it+1 are fetched while step it is computed.  Reads past the
+    // range are clamped to the last key, never predicated, so the compiler's waits stay counted.
+    // K/V are not double-buffered: with >= 8 waves per CU the other waves' loads cover this
+    // wave's arithmetic (measured: a second K/V buffer bought nothing and costs 32 VGPRs).
+    int32_t sk, sv[4];
+    frag kf[4];
+    Vec<T, VE> vv[4];
+    load_slots(0, sk, sv);
+    for (int it = 0; it < n_iter; ++it) {
+      load_kv(sk, sv, kf, vv);
+      load_slots(it + 1, sk, sv);
+
+      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sc = Mfma<T>::run(kf[s], qf[s], sc);
+
+      // lane (g = r16, c4): keys tb + 4 c4 + r
+      const int64_t kb0 = wave_first + (int64_t)it * 64 + 4 * c4;
+      float x[4], mx = m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = sc[r] * qmul;
+        if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
+        x[r] = kb0 + r < k1 ? v : -INFINITY;
+        mx = fmaxf(mx, x[r]);
+      }
+      const float ms = safe_m(mx);
+      const float alpha = exp2f(m - ms);
+      f32x4 pr;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = exp2f(x[r] - ms);
+        psum += pr[r];
+      }
+      l = l * alpha + psum;
+      m = mx;
+      if (r16 < G) {
+        *reinterpret_cast<f32x4*>(my_p + r16 * 8) = pr;
+        my_p[r16 * 8 + 4] = alpha;
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      float vf[4][VE];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VE; ++j) vf[u][j] = to_f32(vv[u].v[j]);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 pg = *reinterpret_cast<const f32x4*>(my_p + g * 8);
+        const float ag = my_p[g * 8 + 4];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          float a = acc[g][j] * ag;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a = fmaf(pg[u], vf[u][j], a);
+          acc[g][j] = a;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // hand the rows' (m, l) to their accumulator lanes
+  if (r16 < G) {
+    my_p[r16 * 8 + 5] = m;
+    my_p[r16 * 8 + 6] = l;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float mg[G], lg[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    mg[g] = my_p[g * 8 + 5];
+    lg[g] = my_p[g * 8 + 6];
+  }
+  // merge the 4 rows of this wave
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float mo = __shfl_xor(mg[g], off, 64), lo = __shfl_xor(lg[g], off, 64);
+      const float mx = fmaxf(mg[g], mo), ms = safe_m(mx);
+      const float a = exp2f(mg[g] - ms), bb = exp2f(mo - ms);
+      lg[g] = lg[g] * a + lo * bb;
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        const float ao = __shfl_xor(acc[g][j], off, 64);
+        acc[g][j] = acc[g][j] * a + ao * bb;
+      }
+      mg[g] = mx;
+    }
+  }
+  if (c4 == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) sm_acc[wave][g][r16 * VE + j] = acc[g][j];
+      if (r16 == 0) {
+        sm_m[wave][g] = mg[g];
+        sm_l[wave][g] = lg[g];
+      }
+    }
+  }
+  __syncthreads();
   for (int idx = threadIdx.x; idx < G * D; idx += 256) {
     const int g = idx / D, d = idx - g * D;
     float mx = -INFINITY;
@@ -302,19 +583,35 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const float* __restri
   }
 }
 
-template <typename T, int D, int U>
-static bool launch_decode_d(const T* q, const T* kb, const T* vb, T* o, const DecodeParams& p,
-                            int64_t bs, hipStream_t st) {
+template <typename T, int D, int U, bool CAP>
+static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const DecodeParams& p,
+                             int64_t bs, hipStream_t st) {
   const int gtotal = p.hq / p.hkv;
   const int G = gtotal % 8 == 0 ? 8 : gtotal % 4 == 0 ? 4 : gtotal % 2 == 0 ? 2 : 1;
   const dim3 grid((unsigned)(p.hkv * (gtotal / G)), (unsigned)p.num_splits, (unsigned)bs);
   const dim3 block(256);
-  switch (G) {
-    case 8: hipLaunchKernelGGL((decode_attn_kernel<T, D, 8, (U > 2 ? 2 : U)>), grid, block, 0, st, q, kb, vb, o, p); break;
-    case 4: hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, U>), grid, block, 0, st, q, kb, vb, o, p); break;
-    case 2: hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, U>), grid, block, 0, st, q, kb, vb, o, p); break;
-    default: hipLaunchKernelGGL((decode_attn_kernel<T, D, 1, U>), grid, block, 0, st, q, kb, vb, o, p); break;
+  if constexpr (D == 128 && !std::is_same<T, float>::value) {
+    switch (G) {
+      case 8: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 8, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+      case 4: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 4, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+      case 2: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 2, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+      default: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 1, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+    }
+    return;
   }
+  switch (G) {
+    case 8: hipLaunchKernelGGL((decode_attn_kernel<T, D, 8, (U > 2 ? 2 : U), CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+    case 4: hipLaunchKernelGGL((decode_attn_kernel<T, D, 4, U, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+    case 2: hipLaunchKernelGGL((decode_attn_kernel<T, D, 2, U, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+    default: hipLaunchKernelGGL((decode_attn_kernel<T, D, 1, U, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+  }
+}
+
+template <typename T, int D, int U>
+static bool launch_decode_d(const T* q, const T* kb, const T* vb, T* o, const DecodeParams& p,
+                            int64_t bs, hipStream_t st) {
+  if (p.logit_cap > 0.f) launch_decode_dc<T, D, U, true>(q, kb, vb, o, p, bs, st);
+  else launch_decode_dc<T, D, U, false>(q, kb, vb, o, p, bs, st);
   return true;
 }
 
@@ -353,9 +650,11 @@ extern "C" {
 
 int mi355_decode_num_splits(int64_t bs, int hkv, int64_t max_seq_len, int max_splits) {
   if (bs <= 0 || hkv <= 0 || max_splits <= 1) return 1;
-  // Aim for >= 4 workgroups per CU (256 CUs) while keeping >= 128 keys per split.
+  // Aim for >= 2 workgroups (8 waves) per CU (256 CUs) while keeping >= 128 keys per split: the
+  // key loop is software-pipelined, so 8 waves per CU already saturate HBM, and every extra split
+  // costs partial-result traffic and the merge launch.
   const int64_t wgs = bs * hkv;
-  int64_t want = (4 * 256 + wgs - 1) / wgs;
+  int64_t want = (2 * 256 + wgs - 1) / wgs;
   const int64_t by_len = max_seq_len / 128 > 0 ? max_seq_len / 128 : 1;
   if (want > by_len) want = by_len;
   if (want > max_splits) want = max_splits;

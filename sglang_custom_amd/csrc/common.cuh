@@ -103,4 +103,24 @@ __host__ __device__ static inline bool aligned16(const void* p) { return (reinte
       return MI355_ERR_UNSUPPORTED;                                          \
   }
 
+// v_mfma_f32_16x16x32 on 16-bit operands.  Lane l holds A[i = l & 15][k = 8 * (l >> 4) + 0..7] and
+// B[k = 8 * (l >> 4) + 0..7][j = l & 15]; the result lane holds D[i = 4 * (l >> 4) + r][j = l & 15].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<f16_t> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
 }  // namespace mi355

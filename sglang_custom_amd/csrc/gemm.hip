@@ -15,24 +15,6 @@
 
 namespace mi355 {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-template <typename T> struct Mfma;
-template <> struct Mfma<bf16_t> {
-  using frag = bf16x8;
-  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mfma<f16_t> {
-  using frag = f16x8;
-  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-};
-
 // Epilogue store of one value with optional bias; OUT is T or float (float = T-rounded).
 template <typename T, typename OUT> __device__ __forceinline__ OUT finish(float acc, float bias) {
   return (OUT)round_to<T>(acc + bias);

@@ -1,0 +1,51 @@
+"""Dev tool: decode attention micro-benchmark at the bench shape (bs=64, ctx~1064, 32q/8kv x128)."""
+import ctypes, sys, torch
+sys.path.insert(0, '.')
+from sglang_custom_amd import ops, _lib
+lib = _lib.load()
+lib.mi355_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
+bs, ctx, hq, hkv, D = 64, 1064, 32, 8, 128
+if len(sys.argv) > 3: bs, hq, hkv = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+if len(sys.argv) > 4: ctx = int(sys.argv[4])
+SP = int(sys.argv[5]) if len(sys.argv) > 5 else 1024   # slot spacing between sequences' prompt regions
+NL = 3
+slots = bs * max(1100, SP + 80) + 16
+torch.manual_seed(0)
+kb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
+vb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
+q = torch.randn(bs, hq, D, device='cuda').bfloat16()
+o = torch.empty_like(q)
+# prompt tokens contiguous per request, decode tokens interleaved across requests (as the allocator hands them out)
+r2t = torch.zeros(bs, 1200, dtype=torch.int32, device='cuda')
+for b in range(bs):
+    r2t[b, :min(ctx, 1024)] = torch.arange(1 + b * SP, 1 + b * SP + min(ctx, 1024))
+    if ctx > 1024: r2t[b, 1024:ctx] = 1 + bs * SP + torch.arange(ctx - 1024) * bs + b
+rpi = torch.arange(bs, dtype=torch.int64, device='cuda')
+sl = torch.full((bs,), ctx, dtype=torch.int64, device='cuda')
+MAXS = 16
+logits = torch.empty(bs, hq, MAXS, D, dtype=torch.float32, device='cuda'); lse = torch.empty(bs, hq, MAXS, dtype=torch.float32, device='cuda')
+def timeit(fn, reps=12):
+    fn(0); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(reps): fn(i)
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
+# reference
+idx = r2t[:, :ctx].long()
+K = kb[0][idx].float(); V = vb[0][idx].float()            # [bs, ctx, hkv, D]
+qg = q.float().view(bs, hkv, hq // hkv, D)
+s = torch.einsum('bhgd,bkhd->bhgk', qg, K) * D ** -0.5
+ref = torch.einsum('bhgk,bkhd->bhgd', s.softmax(-1), V).reshape(bs, hq, D)
+nbytes = bs * ctx * hkv * D * 2 * 2
+for dbg in (0,):
+    if dbg and hq // hkv != 4: continue
+    for ns in (1, 2, 3, 4):
+        ops.decode_attention_paged(q, kb[0], vb[0], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5)
+        err = (o.float() - ref).abs().max().item()
+        t = timeit(lambda i: ops.decode_attention_paged(q, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5))
+        print(f"dbg={dbg} splits={ns}: {t:6.1f} us  {nbytes / t / 1e6:5.2f} TB/s  err={err:.4f}", flush=True)
