@@ -117,6 +117,26 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
                 achieved_gbs=bytes_per_launch / dur_s / 1e9)
 
 
+def committed_pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc FETCH_SIZE pass
+    over this same command (profiles/rNN_pmc_fetch.csv, already x2-corrected for gfx950's 64-B
+    tally of 128-B requests).  PMC counters cannot be read from inside the process, so this is the
+    profile's number, not a live one; None when no pass is committed."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch.csv")))
+    if not files:
+        return None, None
+    tot = n = 0
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if kernel in row["kernel"] and row["counter"] == "FETCH_SIZE":
+                tot += float(row["avg_bytes_x2_corrected"]) * int(row["launches"])
+                n += int(row["launches"])
+    return (int(tot / n), os.path.basename(files[-1])) if n else (None, None)
+
+
 def cpu_baseline(cfg, bs, ctx, dtype):
     """Oracle decode step on the host cores: time `nl` layers + the LM head and scale to the full
     depth (every layer does identical work)."""
@@ -271,9 +291,10 @@ def main():
     }
     if rank == 0 and not args.no_roofline and args.quantization is None and tp == 1:
         k = measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes)
+        traffic, traffic_src = committed_pmc_traffic(k["kernel"])
         out["roofline"] = {"bound": "hbm", "achieved": round(k["achieved_gbs"], 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(k["achieved_gbs"] / HBM_PEAK_GBS, 4),
-                           "traffic": None, "kernel": k["kernel"],
+                           "traffic": traffic, "traffic_source": traffic_src, "kernel": k["kernel"],
                            "avg_duration_us": round(k["avg_duration_us"], 2),
                            "bytes_per_launch": int(k["bytes_per_launch"]),
                            "launches_per_step": k["launches_per_step"]}

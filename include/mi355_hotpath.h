@@ -175,10 +175,13 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
 
 /* ---- K12/K13 dense projection y = x @ W^T ------------------------------------------------------
  * x [M, K] (row stride x_stride), W [N, K] contiguous (nn.Linear layout), y [M, N] contiguous.
- * M <= 64 uses the weight-streaming MFMA kernel (bf16/f16) -- `workspace` must hold
- * mi355_linear_workspace_bytes(M,N,K) bytes for its split-K slabs; fp32 uses an exact-fp32
- * tiled kernel for any M.  out_dtype = dtype, or MI355_F32 to get T-rounded values widened to
- * fp32 (the `.float()` of LogitsProcessor).  bias may be NULL.
+ * M <= 64 uses the weight-streaming MFMA kernel (bf16/f16); fp32 uses an exact-fp32 tiled kernel
+ * for any M.  out_dtype = dtype, or MI355_F32 to get T-rounded values widened to fp32 (the
+ * `.float()` of LogitsProcessor).  bias may be NULL.
+ * Workspace contract (split-K): `workspace` must hold mi355_linear_workspace_bytes(M,N,K) bytes,
+ * 16-B aligned.  Its first 4096 bytes are arrival counters: the caller zeroes them ONCE when it
+ * allocates the buffer, every launch leaves them zero again, the rest needs no initialisation.
+ * Launches that share a workspace must be ordered on one stream; nothing else may write to it.
  * replaces: UnquantizedLinearMethod.apply / F.linear (layers/quantization/unquant.py:110-122),
  *           LogitsProcessor._get_logits matmul (layers/logits_processor.py:453-455,490). */
 int64_t mi355_linear_workspace_bytes(int64_t m, int64_t n, int64_t k);
@@ -187,8 +190,9 @@ int mi355_linear(void* y, const void* x, const void* w, const void* bias, int64_
                  int dtype, int out_dtype, void* stream);
 
 /* Decode-time weight layout.  mi355_pack_weight re-orders an [N, K] 16-bit weight into MFMA
- * fragment order [ceil(N/16)][K/32][64][8] (mi355_packed_weight_elems(n,k) elements, zero padded),
- * so that the weight-streaming kernel reads one contiguous 1-KiB block per wave-instruction;
+ * fragment order [ceil(N/64)][K/32][4][64][8] (mi355_packed_weight_elems(n,k) elements, zero
+ * padded): one wave-instruction reads a contiguous 1-KiB block, the four waves of a workgroup
+ * read 4 KiB side by side, and a workgroup walks K as one contiguous stream;
  * mi355_linear_packed is mi355_linear (M <= 64) on such a weight.  The packing plays the role of
  * the reference's process_weights_after_loading hook, which repacks weights for its own CPU GEMM
  * (python/sglang/srt/layers/amx_utils.py:_amx_process_weight_after_loading,
@@ -199,7 +203,8 @@ int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void
                         int64_t n, int64_t k, int64_t x_stride, void* workspace,
                         int64_t workspace_bytes, int dtype, int out_dtype, void* stream);
 
-/* Tuning / ablation switch (development only): key 0 selects the decode GEMM variant. */
+/* Tuning / ablation switches (development only): key 0 selects the decode GEMM variant
+ * (0 = single-launch ring kernel, 1 = two-launch kernel), key 2 overrides the split-K plan. */
 void mi355_debug_set(int key, int value);
 /* Read-bandwidth probe (development only): streams `bytes` from src with `grid` workgroups. */
 int mi355_debug_read_bw(const void* src, int64_t bytes, int grid, int unroll, void* sink,

@@ -62,9 +62,10 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
     if dim < 0:
         dim += x.dim()
     x = x.contiguous()
-    out = torch.empty((_TP_SIZE,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    # rank-major concatenation along dim 0: the one output layout every backend accepts
+    out = torch.empty((_TP_SIZE * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x, group=_TP_GROUP)
-    out = out.movedim(0, dim)
+    out = out.view((_TP_SIZE,) + tuple(x.shape)).movedim(0, dim)
     shape = list(x.shape)
     shape[dim] *= _TP_SIZE
     return out.reshape(shape)
