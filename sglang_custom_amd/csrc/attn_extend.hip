@@ -10,6 +10,7 @@
 // every dtype -- this is also the fp32 parity path.  Row max uses xor-shuffles across the 16
 // lanes that share a row; the row sum is reduced once at the end.
 #include "common.cuh"
+#include <type_traits>
 #include <math.h>
 
 namespace mi355 {
@@ -295,6 +296,202 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA flash-attention tile for the common prefill case: head_dim = v_head_dim = 128, 16-bit,
+// causal or full, no custom mask / sliding window / logit cap.
+//
+// grid (q blocks of 64 rows, longest first; Hq; B), block 256 = 4 waves x 16 query rows.
+// Per 64-key tile (K and V rows staged once in LDS for the 4 waves, next tile prefetched into
+// registers while this one is computed):
+//   S^T = K . Q^T   : A = K rows from LDS (ds_read_b128), B = Q^T kept in registers.  With the keys
+//                     on the MFMA row axis, lane (query j = l & 15, c = l >> 4) owns the scores of
+//                     ITS query for keys 16t + 4c + r: the softmax is lane-local apart from two
+//                     cross-row maxima, and the probabilities are ALREADY the B operand of the
+//                     next product (k index (c, e) <-> key 16 (e >> 2) + 4c + (e & 3)).
+//   O^T += V^T . P^T: A = V^T fetched from the row-major V tile with ds_read_b64_tr_b16 (hardware
+//                     transpose: 4 key rows x 16 features per 16 lanes), in the same key order.
+// The output accumulator holds O^T[d = 16 dt + 4c + r][query j] and is rescaled per lane.
+// ------------------------------------------------------------------------------------------
+constexpr int XK_ROW = 128 + 8;    // K tile row (elements): 272 B -> conflict-free ds_read_b128
+constexpr int XV_ROW = 128 + 16;   // V tile row: 288 B -> conflict-free transposed reads
+
+// ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x 16 columns of 16-bit elements, delivered
+// column-major -- lane i of the group receives column i of the four rows.  Lane 4 q + pp supplies
+// the address of row q, columns 4 pp .. 4 pp + 3 (8-byte aligned).  EXEC must be all ones.
+template <typename T> struct TrRead {
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef T v4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ v4 run(const T* lds) {
+    const s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(lds));
+    return __builtin_bit_cast(v4, r);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restrict__ q_ext,
+                                                               const T* __restrict__ k_ext,
+                                                               const T* __restrict__ v_ext,
+                                                               T* __restrict__ o_ext,
+                                                               const T* __restrict__ kbuf,
+                                                               const T* __restrict__ vbuf,
+                                                               ExtendParams p) {
+  constexpr int D = 128;
+  using frag = typename Mfma<T>::frag;
+  __shared__ __attribute__((aligned(16))) T ks[64 * XK_ROW];
+  __shared__ __attribute__((aligned(16))) T vs[64 * XV_ROW];
+
+  const int qb = gridDim.x - 1 - blockIdx.x;   // long (late) blocks first
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kvh = h / (p.hq / p.hkv);
+  const int q_start = p.qo_indptr[b];
+  const int ext = p.qo_indptr[b + 1] - q_start;
+  const int kv_start = p.kv_indptr[b];
+  const int prefix = p.kv_indptr[b + 1] - kv_start;
+  const int r0 = qb * 64;
+  if (r0 >= ext) return;   // whole workgroup: EXEC stays full for the transposed reads below
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j16 = lane & 15, c4 = lane >> 4;
+  const int qrow = r0 + wave * 16 + j16;                  // this lane's query (row of the extend part)
+  const int qrow_c = qrow < ext ? qrow : ext - 1;
+  const float qmul = p.sm_scale * kLog2eE;
+
+  // B operand of S^T: Q[qrow][32 s + 8 c + 0..7]
+  frag qf[4];
+  {
+    const T* qp = q_ext + (int64_t)(q_start + qrow_c) * p.q_stride + (int64_t)h * D + 8 * c4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 32 * s);
+  }
+
+  // keys this workgroup needs: [0, total) in the logical order prefix | extend
+  const int last_row = min(r0 + 63, ext - 1);
+  const int total = p.is_causal ? prefix + last_row + 1 : prefix + ext;
+  const int n_tiles = (total + 63) / 64;
+  const int my_limit = p.is_causal ? prefix + qrow_c : prefix + ext - 1;   // last visible key of this lane's query
+  const int wave_min_limit = p.is_causal ? prefix + min(r0 + wave * 16, ext - 1) : prefix + ext - 1;
+
+  // tile staging: thread -> rows (threadIdx.x >> 4) + 16 i, 16-B chunk (threadIdx.x & 15)
+  const int srow = threadIdx.x >> 4, sch = threadIdx.x & 15;
+  Vec<T, 8> kreg[4], vreg[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = kt * 64 + srow + 16 * i;
+      key = key < total ? key : total - 1;
+      const T *kp, *vp;
+      if (key < prefix) {
+        const int64_t slot = p.kv_indices[kv_start + key];
+        kp = kbuf + (slot * p.hkv + kvh) * D;
+        vp = vbuf + (slot * p.hkv + kvh) * D;
+      } else {
+        const int64_t tok = q_start + key - prefix;
+        kp = k_ext + tok * p.k_stride + (int64_t)kvh * D;
+        vp = v_ext + tok * p.v_stride + (int64_t)kvh * D;
+      }
+      kreg[i] = ldvec<T, 8>(kp + sch * 8);
+      vreg[i] = ldvec<T, 8>(vp + sch * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      stvec<T, 8>(ks + (srow + 16 * i) * XK_ROW + sch * 8, kreg[i]);
+      stvec<T, 8>(vs + (srow + 16 * i) * XV_ROW + sch * 8, vreg[i]);
+    }
+  };
+
+  f32x4 ot[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+
+  // LDS read bases
+  const T* k_rd = ks + j16 * XK_ROW + 8 * c4;                          // + (16 t) rows, + 32 s
+  // transposed read: lane 16 c + 4 q + pp supplies row (4 c + q), columns 4 pp .. 4 pp + 3
+  const T* v_rd = vs + (4 * c4 + (j16 >> 2)) * XV_ROW + 4 * (j16 & 3);  // + (32 ks2 + 16 half) rows, + 16 dt
+
+  load_tile(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();            // previous tile fully consumed
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
+
+    // S^T tile: st[t][r] = score of key 64 kt + 16 t + 4 c + r for this lane's query
+    f32x4 st[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const frag kf = *reinterpret_cast<const frag*>(k_rd + (16 * t) * XK_ROW + 32 * s);
+        st[t] = Mfma<T>::run(kf, qf[s], st[t]);
+      }
+    }
+    const bool need_mask = kt * 64 + 63 > wave_min_limit;   // wave-uniform
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = st[t][r] * qmul;
+        if (need_mask && kt * 64 + 16 * t + 4 * c4 + r > my_limit) x = -INFINITY;
+        st[t][r] = x;
+        mloc = fmaxf(mloc, x);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m, mloc);
+    const float ms = mnew == -INFINITY ? 0.f : mnew;
+    const float alpha = exp2f(m - ms);
+    m = mnew;
+    float psum = 0.f;
+    frag pb[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = exp2f(st[t][r] - ms);
+        const T pt = (T)pe;                 // probabilities enter P.V in the value dtype
+        psum += (float)pt;
+        pb[t >> 1][(t & 1) * 4 + r] = pt;
+      }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) ot[dt] *= alpha;
+
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const auto lo = TrRead<T>::run(v_rd + (32 * k2) * XV_ROW + 16 * dt);
+        const auto hi = TrRead<T>::run(v_rd + (32 * k2 + 16) * XV_ROW + 16 * dt);
+        frag va;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          va[e] = lo[e];
+          va[4 + e] = hi[e];
+        }
+        ot[dt] = Mfma<T>::run(va, pb[k2], ot[dt]);
+      }
+  }
+
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (qrow < ext) {
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    T* op = o_ext + ((int64_t)(q_start + qrow) * p.hq + h) * D + 4 * c4;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      Vec<T, 4> w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.v[r] = from_f32<T>(ot[dt][r] * inv);
+      stvec<T, 4>(op + 16 * dt, w);
+    }
+  }
+}
+
 template <typename T, int DP, int BN>
 static int launch_extend_cfg(const void* q, const void* k, const void* v, void* o, const void* kb,
                              const void* vb, const ExtendParams& p, int64_t bs,
@@ -331,6 +528,14 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
   const bool vec = p.D % VE == 0 && p.Dv % VE == 0 && p.q_stride % VE == 0 &&
                    p.k_stride % VE == 0 && p.v_stride % VE == 0 && aligned16(q) && aligned16(k) &&
                    aligned16(v) && aligned16(o) && aligned16(kb) && aligned16(vb);
+  if constexpr (!std::is_same<T, float>::value) {
+    if (vec && p.D == 128 && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 && p.logit_cap <= 0.f) {
+      const dim3 grid((unsigned)((max_len_extend + 63) / 64), (unsigned)p.hq, (unsigned)bs);
+      hipLaunchKernelGGL((extend_attn_mfma_kernel<T>), grid, dim3(256), 0, st, (const T*)q, (const T*)k,
+                         (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p);
+      return MI355_OK;
+    }
+  }
   if (dmax <= 64) return launch_extend_cfg<T, 64, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
   if (dmax <= 128) return launch_extend_cfg<T, 128, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
   if (dmax <= 256) {

@@ -263,6 +263,48 @@ def test_extend_attention_reference_test_shapes(ops):
                 p += ext[b]
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+def test_extend_attention_matrix_core_tile(ops, dtn):
+    """head_dim 128, 16-bit goes through the MFMA flash-attention tile: ragged lengths around the
+    64-row / 64-key tile edges, long prefixes with extend length 1 (the MIXED-batch row), MHA and
+    GQA, causal and full attention."""
+    dt = DT[dtn]
+    for (Hq, Hkv), (pre, ext) in [((8, 2), ([0, 63, 64, 300], [64, 65, 1, 129])),
+                                  ((4, 4), ([129, 0], [1, 257])),
+                                  ((16, 2), ([17], [200]))]:
+        seq = [a + b for a, b in zip(pre, ext)]
+        kc, vc, r2t, pool = cases.paged_inputs(55, dt, len(seq), Hkv, 128, seq)
+        q = cases.randn((sum(ext), Hq, 128), 56, dt)
+        o = _extend_run(ops, q, kc, vc, r2t, pool, torch.tensor(seq), torch.tensor(pre), torch.tensor(ext), Hkv, 128)
+        p = 0
+        for b in range(len(seq)):
+            toks = r2t[pool[b], : seq[b]].long()
+            ref = ops_ref.attention_fp64(q[p: p + ext[b]].transpose(0, 1), kc[toks].transpose(0, 1),
+                                         vc[toks].transpose(0, 1), 128 ** -0.5, pre[b]).transpose(0, 1)
+            assert maxdiff(o[p: p + ext[b]], ref) <= ATTN_TOL[dtn], (Hq, Hkv, b)
+            p += ext[b]
+    # full (non-causal) attention over prefix + extend
+    Hq, Hkv, pre, ext = 8, 2, [40, 0], [70, 33]
+    seq = [a + b for a, b in zip(pre, ext)]
+    kc, vc, r2t, pool = cases.paged_inputs(57, dt, 2, Hkv, 128, seq)
+    q = cases.randn((sum(ext), Hq, 128), 58, dt)
+    kext = torch.cat([kc[r2t[pool[b], pre[b]: seq[b]].long()] for b in range(2)])
+    vext = torch.cat([vc[r2t[pool[b], pre[b]: seq[b]].long()] for b in range(2)])
+    qo = torch.tensor([0, ext[0], sum(ext)], dtype=torch.int32)
+    kvp = torch.tensor([0, pre[0], sum(pre)], dtype=torch.int32)
+    kvi = ops_ref.create_kv_indices(r2t, pool, torch.tensor(pre))
+    o = torch.empty((sum(ext), Hq, 128), dtype=dt, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), kext.to(DEV), vext.to(DEV), o, kc.to(DEV), vc.to(DEV), qo.to(DEV), kvp.to(DEV),
+                             kvi.to(DEV), None, False, None, max(ext), 128 ** -0.5)
+    p = 0
+    for b in range(2):
+        toks = r2t[pool[b], : seq[b]].long()
+        ref = ops_ref.attention_fp64(q[p: p + ext[b]].transpose(0, 1), kc[toks].transpose(0, 1),
+                                     vc[toks].transpose(0, 1), 128 ** -0.5, None).transpose(0, 1)
+        assert maxdiff(o[p: p + ext[b]], ref) <= ATTN_TOL[dtn], b
+        p += ext[b]
+
+
 def test_extend_attention_custom_mask_equals_causal(ops):
     # the reference checks causal flag == explicit lower-triangular custom mask (same file :120-181)
     Hq, Hkv, D = 8, 2, 64
