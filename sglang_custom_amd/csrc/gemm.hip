@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 int g_gemm_variant = 0;   // tuning switches, see mi355_debug_set
 int g_force_splits = 0;
 
-template <typename T, int MT, int NT, typename OUT, bool PACKED>
-__global__ __launch_bounds__(256) void gemm_ring_kernel(
+template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
     OUT* __restrict__ y, float* __restrict__ slab, unsigned* __restrict__ counters, int M, int N,
     int K, int64_t x_stride, int k_per_split) {
@@ -190,15 +190,19 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(
   constexpr int ROW = BK + 8;                 // padded LDS row: bank = 4 * row (mod 64)
   constexpr int KMUL = PACKED ? 64 : 1;
   constexpr int R = 16 * MT;
-  constexpr int XP = R * (BK / 8) / 256;      // 16-B pieces of the x tile per thread
-  static_assert(XP >= 1, "tile too small");
+  constexpr int THREADS = 64 * WAVES;
+  constexpr int PIECES = R * (BK / 8);        // 16-B pieces of the x tile
+  constexpr int XP = (PIECES + THREADS - 1) / THREADS;   // per thread (the last ones may repeat a piece)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* xs = reinterpret_cast<T*>(smem_raw);     // [2][R][ROW]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int tile0 = blockIdx.x * (4 * NT) + wave;   // tile(nt) = tile0 + 4 * nt
-  const int ngroups = (N + 63) >> 6;
+  // 16-row weight tile of (wave, nt): tile(nt) = tile0 + WAVES * nt.  WAVES tiles side by side per
+  // workgroup share one activation tile; with WAVES = 4 they are one 64-row group of the packed
+  // layout (4 KiB contiguous per instruction of the workgroup).
+  const int tile0 = blockIdx.x * (WAVES * NT) + wave;
+  const int ntiles = ((N + 63) >> 6) * 4;     // tiles that exist in the packed image
   const int ks = blockIdx.y * k_per_split;
   const int ke = min(K, ks + k_per_split);
   const int nchunks = (ke - ks) / BK;               // host guarantees divisibility, >= 1
@@ -206,10 +210,10 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(
   const T* wrow[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    int n = (tile0 + 4 * nt) * 16 + r16;
+    const int tile = min(tile0 + WAVES * nt, ntiles - 1);
+    int n = tile * 16 + r16;
     n = n < N ? n : N - 1;
-    const int grp = min(blockIdx.x * NT + nt, ngroups - 1);
-    wrow[nt] = PACKED ? w + (((int64_t)grp * (K >> 5) * 4 + wave) * 64 + lane) * 8 + (int64_t)ks * KMUL
+    wrow[nt] = PACKED ? w + (((int64_t)(tile >> 2) * (K >> 5) * 4 + (tile & 3)) * 64 + lane) * 8 + (int64_t)ks * KMUL
                       : w + (int64_t)n * K + ks + q * 8;
   }
   // x tile piece p -> (row, 16-B column)
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(
   bool xok[XP];
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
-    const int p = threadIdx.x + i * 256;
+    int p = threadIdx.x + i * THREADS;
+    p = p < PIECES ? p : PIECES - 1;            // clamp, never predicate: the loads stay unconditional
     const int row = p / (BK / 8), c16 = p % (BK / 8);
     xok[i] = row < M;
     xsrc[i] = x + (int64_t)(row < M ? row : 0) * x_stride + ks + c16 * 8;
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(
     // D[i = n (4q + r)][j = m (r16)]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int n0 = (tile0 + 4 * nt) * 16 + q * 4;
+      const int n0 = (tile0 + WAVES * nt) * 16 + q * 4;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + r16;
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(
   // write-through (sc1) so that no release fence is needed: once a wave's stores have drained
   // they are visible to every XCD.  The reducer reads them with sc1 loads (never a stale line).
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int TILE_BYTES = 64 * NT * R * 4;
+  constexpr int TILE_BYTES = 16 * WAVES * NT * R * 4;
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<char*>(slab) + (int64_t)blockIdx.x * splits * TILE_BYTES), 0,
       splits * TILE_BYTES, 0x00020000);
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n0 = (tile0 + 4 * nt) * 16 + q * 4;
+    const int n0 = (tile0 + WAVES * nt) * 16 + q * 4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 16 + r16;
@@ -504,23 +509,49 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(T* __restrict__ dst, c
 constexpr int64_t SK_COUNTER_BYTES = 4096;
 
 struct SkinnyPlan {
-  int nt, splits, k_per_split;
+  int nt, waves, splits, k_per_split;
+  int64_t nblocks;
   int64_t counter_bytes;   // arrival counters at the head of the workspace (must start zeroed)
   int64_t slab_bytes;      // fp32 split-K partials behind them
 };
 
-// Split-K plan.  A workgroup owns 64*NT output columns; 2 workgroups are resident per CU, so the
-// chip holds 512 of them.  Splitting K buys parallelism for narrow outputs at the price of fp32
-// partial traffic (splits * M * N * 8 bytes written + read), so wide outputs are never split.
-static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k) {
+int g_force_waves = 0;
+
+// Decomposition of y[M, N] = x W^T over workgroups: `waves` 16-row weight tiles (x NT) side by
+// side per workgroup share one activation tile, K is split `splits` ways.  Aim: one or two
+// workgroups per CU (256 CUs) with equal work, >= 2 chunks each; splitting K costs fp32 partial
+// traffic (splits * M * N * 8 bytes written + read), so wide outputs are never split.
+static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k, bool ring) {
   SkinnyPlan p;
-  p.nt = n >= 64 * 1024 ? 2 : 1;  // very wide outputs (lm_head): 128 columns per workgroup
-  const int64_t wg_n = (n + 64 * p.nt - 1) / (64 * p.nt);
-  // Measured on MI355X: one workgroup per CU (256-384 in all) with >= 4 chunks each beats 512
-  // shorter ones for narrow outputs; deep K (down_proj) takes 8.
+  p.nt = n >= 64 * 1024 ? 2 : 1;  // very wide outputs (lm_head): two tiles per wave
+  p.waves = 4;
+  const int64_t tiles = (n + 15) / 16;
+  const int64_t kchunks = (k + SK_BK - 1) / SK_BK;
   int64_t splits = 1;
-  if (wg_n < 384 && wg_n <= SK_COUNTER_BYTES / 4) {
-    splits = (320 + wg_n - 1) / wg_n;
+  if (ring && p.nt == 1) {
+    // Cost model fitted to MI355X measurements (microseconds): a CU streams one 16-row x 256-k
+    // weight tile in ~0.30, staging one activation chunk costs ~0.35, a launch ~4.5, a split-K
+    // combine ~3 + 0.25 per split; workgroups beyond 256 queue up behind each other on a CU.
+    double best = 1e30;
+    for (int w : {4, 6, 7, 8}) {
+      if (g_force_waves > 0 && w != g_force_waves) continue;
+      const int64_t nb = (tiles + w - 1) / w;
+      const int64_t smax = std::min<int64_t>(16, std::max<int64_t>(1, k / 512));
+      for (int64_t s = 1; s <= smax; ++s) {
+        if (s > 1 && nb > SK_COUNTER_BYTES / 4) break;
+        const int64_t chunks = (kchunks + s - 1) / s;
+        const int64_t real_s = (kchunks + chunks - 1) / chunks;
+        if (real_s != s) continue;
+        const int64_t per_cu = (nb * s + 255) / 256;
+        const double cost = per_cu * (w * chunks * 0.30 + chunks * 0.35) + 4.5 + (s > 1 ? 3.0 + 0.25 * s : 0.0);
+        if (cost < best - 1e-9) { best = cost; p.waves = w; splits = s; }
+      }
+    }
+  }
+  const int64_t per = 16 * p.waves * p.nt;
+  p.nblocks = (n + per - 1) / per;
+  if (!(ring && p.nt == 1) && p.nblocks < 384 && p.nblocks <= SK_COUNTER_BYTES / 4) {
+    splits = (320 + p.nblocks - 1) / p.nblocks;
     if (k / splits > 2048) splits = std::min<int64_t>((k + 1791) / 1792, 16);
   }
   const int64_t max_splits = std::max<int64_t>(1, k / 512);
@@ -533,7 +564,7 @@ static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k) {
   p.splits = (int)((k + kps - 1) / kps);
   p.counter_bytes = p.splits > 1 ? SK_COUNTER_BYTES : 0;
   const int64_t rows = (m + 15) / 16 * 16;
-  p.slab_bytes = p.splits > 1 ? (int64_t)p.splits * wg_n * 64 * p.nt * rows * (int64_t)sizeof(float) : 0;
+  p.slab_bytes = p.splits > 1 ? (int64_t)p.splits * p.nblocks * per * rows * (int64_t)sizeof(float) : 0;
   return p;
 }
 
@@ -543,19 +574,35 @@ static bool skinny_ok(int64_t m, int64_t n, int64_t k, int64_t x_stride, const v
          x_stride % 8 == 0 && aligned16(x) && aligned16(w) && n >= 1 && k >= 8;
 }
 
+static bool use_ring(int64_t k) { return k % SK_BK == 0 && g_gemm_variant == 0; }
+
+template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES>
+static void launch_ring(const T* x, const T* w, const T* bias, OUT* y, float* slab, unsigned* counters,
+                        int M, int N, int K, int64_t x_stride, const SkinnyPlan& p, hipStream_t st) {
+  const dim3 grid((unsigned)p.nblocks, (unsigned)p.splits);
+  const size_t lds = 2 * (16 * MT) * (256 / NT + 8) * sizeof(T);
+  auto kern = gemm_ring_kernel<T, MT, NT, OUT, PACKED, WAVES>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, st, x, w, bias, y, slab, counters, M, N, K,
+                     x_stride, p.k_per_split);
+}
+
 template <typename T, int MT, int NT, typename OUT, bool PACKED>
 static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, char* ws, int M,
                               int N, int K, int64_t x_stride, const SkinnyPlan& p,
                               hipStream_t st) {
-  const dim3 grid((unsigned)((N + 64 * NT - 1) / (64 * NT)), (unsigned)p.splits);
   unsigned* counters = p.splits > 1 ? reinterpret_cast<unsigned*>(ws) : nullptr;
   float* slab = p.splits > 1 ? reinterpret_cast<float*>(ws + p.counter_bytes) : nullptr;
-  if (K % SK_BK == 0 && g_gemm_variant == 0) {
-    const size_t lds = 2 * (16 * MT) * (256 / NT + 8) * sizeof(T);
-    hipLaunchKernelGGL((gemm_ring_kernel<T, MT, NT, OUT, PACKED>), grid, dim3(256), lds, st, x, w, bias, y,
-                       slab, counters, M, N, K, x_stride, p.k_per_split);
-    return;
+  if (use_ring(K)) {
+    if constexpr (PACKED && NT == 1) {
+      if (p.waves == 8) return launch_ring<T, MT, NT, OUT, PACKED, 8>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+      if (p.waves == 7) return launch_ring<T, MT, NT, OUT, PACKED, 7>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+      if (p.waves == 6) return launch_ring<T, MT, NT, OUT, PACKED, 6>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+    }
+    return launch_ring<T, MT, NT, OUT, PACKED, 4>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
   }
+  const dim3 grid((unsigned)p.nblocks, (unsigned)p.splits);
   const size_t lds = 2 * (16 * MT) * SK_LDS_ROW * sizeof(T);
   hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, NT, OUT, PACKED>), grid, dim3(256), lds, st, x, w, bias, y,
                      slab, M, N, K, x_stride, p.k_per_split);
@@ -569,7 +616,7 @@ static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, cha
 template <typename T, typename OUT, bool PACKED = false>
 static void launch_skinny(const T* x, const T* w, const T* bias, OUT* y, void* ws, int M, int N,
                           int K, int64_t x_stride, hipStream_t st) {
-  const SkinnyPlan p = plan_skinny(M, N, K);
+  const SkinnyPlan p = plan_skinny(M, N, K, use_ring(K) && PACKED);
   const int mt = (M + 15) / 16;
 #define SK(MT_, NT_) launch_skinny_cfg<T, MT_, NT_, OUT, PACKED>(x, w, bias, y, (char*)ws, M, N, K, x_stride, p, st)
   if (p.nt == 2) {
@@ -613,12 +660,14 @@ extern "C" {
 void mi355_debug_set(int key, int value) {
   if (key == 0) g_gemm_variant = value;   // 0 = ring kernel (default), 1 = two-launch kernel
   if (key == 2) g_force_splits = value;   // > 0 overrides the split-K plan
+  if (key == 4) g_force_waves = value;    // 4 | 6 | 7 | 8 overrides the tiles-per-workgroup plan
 }
 
 int64_t mi355_linear_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   if (m < 1 || m > 64 || n < 1 || k < 1) return 0;
-  const SkinnyPlan p = plan_skinny(m, n, k);
-  return p.counter_bytes + p.slab_bytes;
+  // the larger of the two layouts (packed / row-major weights plan differently)
+  const SkinnyPlan a = plan_skinny(m, n, k, use_ring(k)), b = plan_skinny(m, n, k, false);
+  return std::max(a.counter_bytes + a.slab_bytes, b.counter_bytes + b.slab_bytes);
 }
 
 int64_t mi355_packed_weight_elems(int64_t n, int64_t k) { return ((n + 63) / 64) * 64 * k; }

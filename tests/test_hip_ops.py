@@ -383,8 +383,9 @@ def test_linear_packed_and_split_k(ops, dtn):
         got = ops.linear_packed(x.to(DEV), wp, N, bd)
         assert got.shape == (M, N) and got.dtype == dt
         assert maxdiff(got, exact) <= max(1.5 * maxdiff(ref, exact), ROUND_TOL[dtn] / 2), (M, N, K)
-        # same bits as the row-major kernel (same accumulation order), and on every repeat
-        assert torch.equal(got, ops.linear(x.to(DEV), wd, bd)), (M, N, K)
+        # the row-major kernel may split K differently (other summation order): same value to one
+        # rounding; repeats of the same call give the same bits
+        assert maxdiff(got, ops.linear(x.to(DEV), wd, bd)) <= ROUND_TOL[dtn], (M, N, K)
         for _ in range(3):
             assert torch.equal(got, ops.linear_packed(x.to(DEV), wp, N, bd))
         if prev is not None:
@@ -396,7 +397,7 @@ def test_linear_packed_and_split_k(ops, dtn):
     # strided activations (a column slice of a wider buffer)
     x = cases.randn((9, 1024), 9, dt).to(DEV)
     w = cases.randn((300, 512), 10, dt, 0.05).to(DEV)
-    assert torch.equal(ops.linear_packed(x[:, :512], ops.pack_weight(w), 300), ops.linear(x[:, :512].contiguous(), w))
+    assert maxdiff(ops.linear_packed(x[:, :512], ops.pack_weight(w), 300), ops.linear(x[:, :512].contiguous(), w)) <= ROUND_TOL[dtn]
 
 
 def test_fp8_quant_and_gemm(ops, golden_ops):
