@@ -72,7 +72,7 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
     """Average duration of the decode projection kernel (gemm_ring_kernel) over one step's worth
     of launches -- every layer's real weights in order, M = bs, through the same call the model
     makes -- bracketed by HIP events on the stream the kernels are launched on."""
-    from sglang_custom_amd.layers.quantization.unquant import decode_linear
+    from sglang_custom_amd.layers.quantization.unquant import decode_linear, gate_up_silu_mul
 
     dev = mr.device
     layers = mr.model.model.layers
@@ -85,7 +85,7 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
         for layer in layers:
             decode_linear(layer.self_attn.qkv_proj, x_h, None)
             decode_linear(layer.self_attn.o_proj, x_attn, None)
-            decode_linear(layer.mlp.gate_up_proj, x_h, None)
+            gate_up_silu_mul(layer.mlp.gate_up_proj, layer.mlp.act_fn, x_h)
             decode_linear(layer.mlp.down_proj, x_mlp, None)
         decode_linear(head, x_h, None, out_dtype=torch.float32)
 

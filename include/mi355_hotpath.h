@@ -203,8 +203,18 @@ int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void
                         int64_t n, int64_t k, int64_t x_stride, void* workspace,
                         int64_t workspace_bytes, int dtype, int out_dtype, void* stream);
 
+/* gate_up projection with SiLU-and-mul fused into the epilogue: y[m, j] = T(silu(g_j)) * u_j with
+ * g = x W_gate^T, u = x W_up^T each rounded to T first (the rounding points of the unfused ops).
+ * w_packed = mi355_pack_weight of the [2d, K] matrix whose 16-row tile t holds gate rows
+ * 8t..8t+7 followed by up rows 8t..8t+7; n = 2d; y is [m, d].  Needs K % 256 == 0, n < 65536.
+ * replaces: LlamaMLP.forward gate_up_proj + act_fn (python/sglang/srt/models/llama.py:94-98,
+ *           layers/activation.py:55-65). */
+int mi355_linear_packed_silu_mul(void* y, const void* x, const void* w_packed, int64_t m, int64_t n,
+                                 int64_t k, int64_t x_stride, void* workspace,
+                                 int64_t workspace_bytes, int dtype, void* stream);
+
 /* Tuning / ablation switches (development only): key 0 selects the decode GEMM variant
- * (0 = single-launch ring kernel, 1 = two-launch kernel), key 2 overrides the split-K plan. */
+ * (0 = single-launch ring kernel, 1 = two-launch kernel), key 2 overrides the split-K plan, key 4 the weight tiles per workgroup. */
 void mi355_debug_set(int key, int value);
 /* Read-bandwidth probe (development only): streams `bytes` from src with `grid` workgroups. */
 int mi355_debug_read_bw(const void* src, int64_t bytes, int grid, int unroll, void* sink,

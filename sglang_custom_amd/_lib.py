@@ -39,6 +39,7 @@ _SIGNATURES = {
     "mi355_packed_weight_elems": (L, [L, L]),
     "mi355_pack_weight": (I, [P, P, L, L, I, P]),
     "mi355_linear_packed": (I, [P, P, P, P, L, L, L, L, P, L, I, I, P]),
+    "mi355_linear_packed_silu_mul": (I, [P, P, P, L, L, L, L, P, L, I, P]),
     "mi355_debug_set": (None, [I, I]),
     "mi355_debug_read_bw": (I, [P, L, I, I, P, P]),
     "mi355_per_token_quant_fp8": (I, [P, P, P, L, L, L, I, P]),

@@ -103,6 +103,13 @@ __host__ __device__ static inline bool aligned16(const void* p) { return (reinte
       return MI355_ERR_UNSUPPORTED;                                          \
   }
 
+// silu(a) * b with the rounding points of F.silu(a) * b on dtype T (layers/activation.py:55-58).
+template <typename T> __device__ __forceinline__ T silu_mul_one(T a, T b) {
+  const float x = to_f32(a);
+  const float s = round_to<T>(x / (1.0f + expf(-x)));  // F.silu on dtype T rounds here
+  return from_f32<T>(s * to_f32(b));
+}
+
 // v_mfma_f32_16x16x32 on 16-bit operands.  Lane l holds A[i = l & 15][k = 8 * (l >> 4) + 0..7] and
 // B[k = 8 * (l >> 4) + 0..7][j = l & 15]; the result lane holds D[i = 4 * (l >> 4) + r][j = l & 15].
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -152,12 +152,6 @@ static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, i
 // ------------------------------------------------------------------------------------------
 // SiLU-and-mul
 // ------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T silu_mul_one(T a, T b) {
-  const float x = to_f32(a);
-  const float s = round_to<T>(x / (1.0f + expf(-x)));  // F.silu on dtype T rounds here
-  return from_f32<T>(s * to_f32(b));
-}
-
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void silu_and_mul_kernel(T* __restrict__ out,
                                                            const T* __restrict__ x, int64_t rows,
@@ -195,6 +189,9 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
   // Every product and sum below must round on its own (torch evaluates x1*cos, x2*sin and their
   // difference as separate elementwise ops): no fused multiply-add contraction in this kernel.
 #pragma clang fp contract(off)
+  // grid (tokens, chunks): chunk y < rot_chunks rotates 256 (head, pair) items, the remaining
+  // chunks copy the pass-through part of k and all of v into the cache -- one memory round trip
+  // per workgroup instead of a serial loop per token.
   const int64_t t = blockIdx.x;
   const int64_t pos = positions[t];
   const CT* cs = cache + pos * rotary_dim;
@@ -204,8 +201,11 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
   const int nheads = hq + hkv;
   const int64_t slot = k_buffer ? (int64_t)loc[t] : 0;
   T* kdst = k_buffer ? k_buffer + slot * (int64_t)hkv * head_dim : nullptr;
+  const int rot_chunks = (nheads * half + 255) / 256;
 
-  for (int w = threadIdx.x; w < nheads * half; w += 256) {
+  if ((int)blockIdx.y < rot_chunks) {
+    const int w = blockIdx.y * 256 + threadIdx.x;
+    if (w >= nheads * half) return;
     const int h = w / half, i = w - h * half;
     T* base = (h < hq) ? qt + (int64_t)h * head_dim : kt + (int64_t)(h - hq) * head_dim;
     const int i1 = is_neox ? i : 2 * i, i2 = is_neox ? i + half : 2 * i + 1;
@@ -220,17 +220,20 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
       d[i1] = from_f32<T>(o1);
       d[i2] = from_f32<T>(o2);
     }
+    return;
   }
   if (k_buffer) {
     // pass-through part of k (rotary_dim < head_dim) and all of v
+    const int cw = (blockIdx.y - rot_chunks) * 256 + threadIdx.x;
     const int pass = head_dim - rotary_dim;
-    for (int w = threadIdx.x; w < hkv * pass; w += 256) {
-      const int h = w / pass, i = rotary_dim + (w - h * pass);
+    if (cw < hkv * pass) {
+      const int h = cw / pass, i = rotary_dim + (cw - h * pass);
       kdst[(int64_t)h * head_dim + i] = kt[(int64_t)h * head_dim + i];
     }
-    T* vdst = v_buffer + slot * (int64_t)hkv * head_dim;
-    const T* vt = v + t * v_stride;
-    for (int w = threadIdx.x; w < hkv * head_dim; w += 256) vdst[w] = vt[w];
+    if (cw < hkv * head_dim) {
+      T* vdst = v_buffer + slot * (int64_t)hkv * head_dim;
+      vdst[cw] = v[t * v_stride + cw];
+    }
   }
 }
 
@@ -287,7 +290,9 @@ static void rope_launch(void* q, void* k, const void* v, const int64_t* position
                         int head_dim, int rotary_dim, int64_t q_stride, int64_t k_stride,
                         int64_t v_stride, int is_neox, void* k_buffer, void* v_buffer,
                         const void* loc, int loc_itype, hipStream_t st) {
-  const dim3 grid((unsigned)tokens), block(256);
+  const int rot_chunks = ((hq + hkv) * (rotary_dim / 2) + 255) / 256;
+  const int copy_chunks = k_buffer ? (hkv * head_dim + 255) / 256 : 0;
+  const dim3 grid((unsigned)tokens, (unsigned)(rot_chunks + copy_chunks)), block(256);
   const bool f32cache = cache_dtype == MI355_F32 && DType<T>::code != MI355_F32;
   const bool i32 = loc_itype == MI355_I32;
 #define ROPE_ARGS(CT, LT)                                                                    \

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 int g_gemm_variant = 0;   // tuning switches, see mi355_debug_set
 int g_force_splits = 0;
 
-template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES = 4>
+template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES = 4, bool ACT = false>
 __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
     OUT* __restrict__ y, float* __restrict__ slab, unsigned* __restrict__ counters, int M, int N,
@@ -315,23 +315,46 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   }
   compute(w0, c & 1);
 
-  const int splits = gridDim.y;
-  if (splits == 1) {
-    // D[i = n (4q + r)][j = m (r16)]
+  // Final value of one accumulator fragment: D[i = 16 tile + 4q + r][j = m (r16)].
+  // ACT (SiLU-and-mul fused, weights packed with gate/up rows interleaved 8 + 8 per tile): rows
+  // 0..7 of a tile are gate features 8 tile .. 8 tile + 7, rows 8..15 the matching up features, so
+  // lane (m, q < 2) holds gate values whose up partners sit 32 lanes higher.
+  auto emit = [&](int nt, int mt, f32x4 v) {
+    const int tile = tile0 + WAVES * nt;
+    const int m = mt * 16 + r16;
+    if constexpr (ACT) {
+      float mine[4], other[4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n0 = (tile0 + WAVES * nt) * 16 + q * 4;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 16 + r16;
-        if (m >= M) continue;
+      for (int r = 0; r < 4; ++r) {
+        mine[r] = round_to<T>(v[r]);
+        other[r] = __shfl_xor(mine[r], 32, 64);
+      }
+      if (q < 2 && m < M) {
+        const int half_n = N >> 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = n0 + r;
-          if (n < N) y[(int64_t)m * N + n] = finish<T, OUT>(acc[nt][mt][r], bias ? to_f32(bias[n]) : 0.f);
+          const int n = tile * 8 + 4 * q + r;
+          if (n < half_n)
+            y[(int64_t)m * half_n + n] = (OUT)silu_mul_one<T>(from_f32<T>(mine[r]), from_f32<T>(other[r]));
         }
       }
+    } else {
+      if (m >= M) return;
+      const int n0 = tile * 16 + q * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r;
+        if (n < N) y[(int64_t)m * N + n] = finish<T, OUT>(v[r], bias ? to_f32(bias[n]) : 0.f);
+      }
     }
+  };
+
+  const int splits = gridDim.y;
+  if (splits == 1) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) emit(nt, mt, acc[nt][mt]);
     return;
   }
 
@@ -392,19 +415,9 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
     }
   }
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n0 = (tile0 + WAVES * nt) * 16 + q * 4;
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mt * 16 + r16;
-      if (m >= M) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + r;
-        if (n < N) y[(int64_t)m * N + n] = finish<T, OUT>(red[nt][mt][r], bias ? to_f32(bias[n]) : 0.f);
-      }
-    }
-  }
+    for (int mt = 0; mt < MT; ++mt) emit(nt, mt, red[nt][mt]);
   if (threadIdx.x == 0) counters[blockIdx.x] = 0u;   // leave the counter zero for the next launch
 }
 
@@ -576,32 +589,36 @@ static bool skinny_ok(int64_t m, int64_t n, int64_t k, int64_t x_stride, const v
 
 static bool use_ring(int64_t k) { return k % SK_BK == 0 && g_gemm_variant == 0; }
 
-template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES>
+template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES, bool ACT = false>
 static void launch_ring(const T* x, const T* w, const T* bias, OUT* y, float* slab, unsigned* counters,
                         int M, int N, int K, int64_t x_stride, const SkinnyPlan& p, hipStream_t st) {
   const dim3 grid((unsigned)p.nblocks, (unsigned)p.splits);
   const size_t lds = 2 * (16 * MT) * (256 / NT + 8) * sizeof(T);
-  auto kern = gemm_ring_kernel<T, MT, NT, OUT, PACKED, WAVES>;
+  auto kern = gemm_ring_kernel<T, MT, NT, OUT, PACKED, WAVES, ACT>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, st, x, w, bias, y, slab, counters, M, N, K,
                      x_stride, p.k_per_split);
 }
 
-template <typename T, int MT, int NT, typename OUT, bool PACKED>
+template <typename T, int MT, int NT, typename OUT, bool PACKED, bool ACT = false>
 static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, char* ws, int M,
                               int N, int K, int64_t x_stride, const SkinnyPlan& p,
                               hipStream_t st) {
   unsigned* counters = p.splits > 1 ? reinterpret_cast<unsigned*>(ws) : nullptr;
   float* slab = p.splits > 1 ? reinterpret_cast<float*>(ws + p.counter_bytes) : nullptr;
-  if (use_ring(K)) {
+  if (use_ring(K) || ACT) {
     if constexpr (PACKED && NT == 1) {
-      if (p.waves == 8) return launch_ring<T, MT, NT, OUT, PACKED, 8>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
-      if (p.waves == 7) return launch_ring<T, MT, NT, OUT, PACKED, 7>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
-      if (p.waves == 6) return launch_ring<T, MT, NT, OUT, PACKED, 6>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+      if (p.waves == 8) return launch_ring<T, MT, NT, OUT, PACKED, 8, ACT>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+      if (p.waves == 7) return launch_ring<T, MT, NT, OUT, PACKED, 7, ACT>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+      if (p.waves == 6) return launch_ring<T, MT, NT, OUT, PACKED, 6, ACT>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+      return launch_ring<T, MT, NT, OUT, PACKED, 4, ACT>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
     }
-    return launch_ring<T, MT, NT, OUT, PACKED, 4>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
+    if constexpr (!ACT)
+      return launch_ring<T, MT, NT, OUT, PACKED, 4>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
   }
+  if constexpr (ACT) return;   // callers check the preconditions (ring kernel, one tile per wave)
+  else {
   const dim3 grid((unsigned)p.nblocks, (unsigned)p.splits);
   const size_t lds = 2 * (16 * MT) * SK_LDS_ROW * sizeof(T);
   hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, NT, OUT, PACKED>), grid, dim3(256), lds, st, x, w, bias, y,
@@ -611,15 +628,18 @@ static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, cha
     hipLaunchKernelGGL((splitk_reduce_kernel<T, OUT>), dim3((unsigned)((mn + 255) / 256)),
                        dim3(256), 0, st, slab, bias, y, mn, N, p.splits);
   }
+  }
 }
 
-template <typename T, typename OUT, bool PACKED = false>
+template <typename T, typename OUT, bool PACKED = false, bool ACT = false>
 static void launch_skinny(const T* x, const T* w, const T* bias, OUT* y, void* ws, int M, int N,
                           int K, int64_t x_stride, hipStream_t st) {
   const SkinnyPlan p = plan_skinny(M, N, K, use_ring(K) && PACKED);
   const int mt = (M + 15) / 16;
-#define SK(MT_, NT_) launch_skinny_cfg<T, MT_, NT_, OUT, PACKED>(x, w, bias, y, (char*)ws, M, N, K, x_stride, p, st)
-  if (p.nt == 2) {
+#define SK(MT_, NT_) launch_skinny_cfg<T, MT_, NT_, OUT, PACKED, ACT>(x, w, bias, y, (char*)ws, M, N, K, x_stride, p, st)
+  if constexpr (ACT) {
+    if (mt <= 1) SK(1, 1); else if (mt <= 2) SK(2, 1); else SK(4, 1);
+  } else if (p.nt == 2) {
     if (mt <= 1) SK(1, 2); else if (mt <= 2) SK(2, 2); else SK(4, 2);
   } else {
     if (mt <= 1) SK(1, 1); else if (mt <= 2) SK(2, 1); else SK(4, 1);
@@ -720,6 +740,36 @@ int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void
     else launch_skinny<f16_t, f16_t, true>((const f16_t*)x, (const f16_t*)w_packed, (const f16_t*)bias, (f16_t*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
   }
   MI355_CHECK_LAUNCH("linear_packed");
+  return MI355_OK;
+}
+
+int mi355_linear_packed_silu_mul(void* y, const void* x, const void* w_packed, int64_t m, int64_t n,
+                                 int64_t k, int64_t x_stride, void* workspace,
+                                 int64_t workspace_bytes, int dtype, void* stream) {
+  MI355_REQUIRE(y && x && w_packed, MI355_ERR_INVALID, "linear_packed_silu_mul: null pointer");
+  MI355_REQUIRE(m >= 0 && m <= 64 && n > 0 && n % 16 == 0 && k > 0 && x_stride >= k && x_stride % 8 == 0,
+                MI355_ERR_INVALID, "linear_packed_silu_mul: needs 0 <= M <= 64, N %% 16 == 0 (m=%lld n=%lld k=%lld)",
+                (long long)m, (long long)n, (long long)k);
+  MI355_REQUIRE(k % SK_BK == 0 && n < 64 * 1024 && g_gemm_variant == 0, MI355_ERR_UNSUPPORTED,
+                "linear_packed_silu_mul: needs K %% 256 == 0 and N < 65536 (k=%lld n=%lld)", (long long)k,
+                (long long)n);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "linear_packed_silu_mul: only 16-bit dtypes");
+  MI355_REQUIRE(aligned16(x) && aligned16(w_packed), MI355_ERR_INVALID,
+                "linear_packed_silu_mul: misaligned pointer");
+  if (m == 0) return MI355_OK;
+  const int64_t need = mi355_linear_workspace_bytes(m, n, k);
+  if (need > 0 && (!workspace || workspace_bytes < need || !aligned16(workspace))) {
+    set_error("linear_packed_silu_mul: workspace of %lld bytes (16-B aligned) required, got %lld",
+              (long long)need, (long long)workspace_bytes);
+    return MI355_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI355_BF16)
+    launch_skinny<bf16_t, bf16_t, true, true>((const bf16_t*)x, (const bf16_t*)w_packed, nullptr, (bf16_t*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
+  else
+    launch_skinny<f16_t, f16_t, true, true>((const f16_t*)x, (const f16_t*)w_packed, nullptr, (f16_t*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
+  MI355_CHECK_LAUNCH("linear_packed_silu_mul");
   return MI355_OK;
 }
 

@@ -34,6 +34,31 @@ def decode_linear(layer, x2: torch.Tensor, bias: Optional[torch.Tensor], out_dty
     return ops.linear(x2, layer.weight, bias, out_dtype=out_dtype)
 
 
+def pack_gate_up_for_decode(layer) -> None:
+    """gate_up_proj: the decode copy interleaves gate and up rows (8 + 8 per MFMA tile) so that the
+    GEMM epilogue can apply SiLU-and-mul in registers (ops.linear_packed_silu_mul).  It replaces
+    the plain packed copy: the unfused GEMM + activation remains the path for large M."""
+    w = layer.weight
+    layer.weight_packed = None
+    layer.weight_packed_gate_up = None
+    if (w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and w.shape[1] % 256 == 0
+            and w.shape[0] % 16 == 0 and w.shape[0] < 65536):
+        layer.weight_packed_gate_up = get_ops().pack_weight_gate_up(w.data)
+    else:
+        pack_for_decode(layer)
+
+
+def gate_up_silu_mul(layer, act_fn, x: torch.Tensor) -> torch.Tensor:
+    """act_fn(gate_up_proj(x)) (models/llama.py:94-98), fused for decode-sized inputs."""
+    x2 = x.view(-1, x.shape[-1])
+    wp = getattr(layer, "weight_packed_gate_up", None)
+    if wp is not None and x2.shape[0] <= SKINNY_MAX_M and x2.stride(0) % 8 == 0:
+        y = get_ops().linear_packed_silu_mul(x2, wp, layer.weight.shape[0])
+        return y.view(*x.shape[:-1], y.shape[-1])
+    gate_up, _ = layer(x)
+    return act_fn(gate_up)
+
+
 class UnquantizedLinearMethod:
     def process_weights_after_loading(self, layer) -> None:
         pack_for_decode(layer)

@@ -18,7 +18,12 @@ from ..layers.activation import SiluAndMul
 from ..layers.layernorm import RMSNorm
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from ..layers.logits_processor import LogitsProcessor
-from ..layers.quantization.unquant import pack_for_decode
+from ..layers.quantization.unquant import (
+    UnquantizedLinearMethod,
+    gate_up_silu_mul,
+    pack_for_decode,
+    pack_gate_up_for_decode,
+)
 from ..layers.radix_attention import RadixAttention
 from ..layers.rotary_embedding import get_rope
 from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
@@ -34,8 +39,11 @@ class LlamaMLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
-        gate_up, _ = self.gate_up_proj(x)
-        x = self.act_fn(gate_up)
+        if isinstance(self.gate_up_proj.quant_method, UnquantizedLinearMethod):
+            x = gate_up_silu_mul(self.gate_up_proj, self.act_fn, x)
+        else:
+            gate_up, _ = self.gate_up_proj(x)
+            x = self.act_fn(gate_up)
         x, _ = self.down_proj(x)
         return x
 
@@ -169,6 +177,9 @@ class LlamaForCausalLM(nn.Module):
             for lin in (layer.self_attn.qkv_proj, layer.self_attn.o_proj, layer.mlp.gate_up_proj,
                         layer.mlp.down_proj):
                 lin.quant_method.process_weights_after_loading(lin)
+            gu = layer.mlp.gate_up_proj
+            if isinstance(gu.quant_method, UnquantizedLinearMethod):
+                pack_gate_up_for_decode(gu)
         pack_for_decode(self.lm_head)
 
     @torch.no_grad()

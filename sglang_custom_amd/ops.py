@@ -298,6 +298,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
 
 # ---------------------------------------------------------------------------------- linear
 _WS = {}
+_WS_RETIRED = []
 
 
 def _workspace(device, nbytes: int, tag: str = "linear") -> torch.Tensor:
@@ -308,7 +309,10 @@ def _workspace(device, nbytes: int, tag: str = "linear") -> torch.Tensor:
     must be ordered on one stream."""
     ws = _WS.get((device, tag))
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            # a captured HIP graph may still hold the old pointer: outgrown buffers stay alive
+            _WS_RETIRED.append(ws)
+        ws = torch.zeros(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)
         _WS[(device, tag)] = ws
     return ws
 
@@ -364,6 +368,35 @@ def linear_packed(x: torch.Tensor, weight_packed: torch.Tensor, n: int, bias: Op
     check(lib.mi355_linear_packed(y.data_ptr(), x.data_ptr(), weight_packed.data_ptr(), _p(bias), M, n, K,
                                   x.stride(0), _p(ws), ws.numel() if ws is not None else 0, _dt(x),
                                   _DT[out_dtype], _stream(x)), "linear_packed")
+    return y
+
+
+def pack_weight_gate_up(weight: torch.Tensor) -> torch.Tensor:
+    """[2d, K] = [gate rows | up rows] -> packed copy for linear_packed_silu_mul: every 16-row MFMA
+    tile holds 8 gate rows followed by the 8 up rows of the same output features."""
+    n2, K = weight.shape
+    d = n2 // 2
+    assert n2 % 16 == 0
+    inter = torch.stack([weight[:d].view(d // 8, 8, K), weight[d:].view(d // 8, 8, K)], dim=1)
+    return pack_weight(inter.reshape(n2, K).contiguous())
+
+
+def linear_packed_silu_mul(x: torch.Tensor, weight_packed: torch.Tensor, n: int) -> torch.Tensor:
+    """SiluAndMul(x @ W_gate_up^T) in one kernel (models/llama.py:94-98) for M <= 64 rows;
+    weight_packed from pack_weight_gate_up, n = 2d rows, returns [M, d]."""
+    _gpu(x, weight_packed)
+    assert x.dim() == 2 and x.stride(1) == 1 and weight_packed.dtype == x.dtype
+    M, K = x.shape
+    y = torch.empty((M, n // 2), dtype=x.dtype, device=x.device)
+    if M == 0:
+        return y
+    lib = _lib_()
+    assert weight_packed.numel() == lib.mi355_packed_weight_elems(n, K)
+    need = lib.mi355_linear_workspace_bytes(M, n, K)
+    ws = _workspace(x.device, need) if need > 0 else None
+    check(lib.mi355_linear_packed_silu_mul(y.data_ptr(), x.data_ptr(), weight_packed.data_ptr(), M, n, K,
+                                           x.stride(0), _p(ws), ws.numel() if ws is not None else 0,
+                                           _dt(x), _stream(x)), "linear_packed_silu_mul")
     return y
 
 

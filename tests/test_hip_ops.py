@@ -400,6 +400,25 @@ def test_linear_packed_and_split_k(ops, dtn):
     assert maxdiff(ops.linear_packed(x[:, :512], ops.pack_weight(w), 300), ops.linear(x[:, :512].contiguous(), w)) <= ROUND_TOL[dtn]
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+def test_gate_up_projection_with_fused_silu_mul(ops, dtn):
+    """SiLU-and-mul in the GEMM epilogue must give the bits of GEMM -> silu_and_mul (same
+    accumulation order, same rounding points), for every M tile count and for split and
+    unsplit plans; and match the oracle's silu_and_mul of the exact product to one rounding."""
+    dt = DT[dtn]
+    for i, (M, d, K) in enumerate([(64, 14336, 4096), (33, 1024, 512), (1, 256, 256), (17, 3584, 1024), (64, 72, 768)]):
+        x = cases.randn((M, K), 300 + i, dt).to(DEV)
+        w = cases.randn((2 * d, K), 320 + i, dt, 1.0 / math.sqrt(K)).to(DEV)
+        fused = ops.linear_packed_silu_mul(x, ops.pack_weight_gate_up(w), 2 * d)
+        unfused = ops.silu_and_mul(ops.linear_packed(x, ops.pack_weight(w), 2 * d))
+        assert fused.shape == (M, d)
+        assert torch.equal(fused, unfused), (M, d, K)
+        exact = x.double().cpu() @ w.double().cpu().t()
+        ref = ops_ref.silu_and_mul(exact.to(dt))
+        assert maxdiff(fused, ref) <= 2 * ROUND_TOL[dtn]
+        assert torch.equal(fused, ops.linear_packed_silu_mul(x, ops.pack_weight_gate_up(w), 2 * d))
+
+
 def test_fp8_quant_and_gemm(ops, golden_ops):
     for dtn in ("bf16", "f16", "f32"):
         for (M, K) in ((5, 256), (64, 4096), (3, 1000)):
