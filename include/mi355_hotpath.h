@@ -173,6 +173,21 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
                            int64_t num_slots, float sm_scale, float logit_cap,
                            int sliding_window_size, int dtype, void* stream);
 
+/* MLA (compressed-KV) decode: every query head attends over ONE latent row per token,
+ * kv_buffer [num_slots, 1, kv_lora_rank + rope_dim]; the key is the whole row, the value its first
+ * kv_lora_rank features (read from the same buffer, never materialised).  q [B, hq, rank + rope],
+ * o [B, hq, kv_lora_rank]; addressing modes and split scratch as mi355_decode_attention.
+ * replaces: attn_mqa = RadixAttention(H, 576, scaling, num_kv_heads=1, v_head_dim=512) on
+ *           MLATokenToKVPool (python/sglang/srt/models/deepseek_v2.py:866-875,
+ *           mem_cache/memory_pool.py:769-970: get_value_buffer = kv_buffer[..., :kv_lora_rank]). */
+int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
+                               const int32_t* page_table, int mode,
+                               const int64_t* req_pool_indices, const int64_t* seq_lens,
+                               const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
+                               float* attn_lse, int num_splits, int64_t bs, int hq,
+                               int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
+                               float sm_scale, float logit_cap, int dtype, void* stream);
+
 /* ---- K12/K13 dense projection y = x @ W^T ------------------------------------------------------
  * x [M, K] (row stride x_stride), W [N, K] contiguous (nn.Linear layout), y [M, N] contiguous.
  * M <= 64 uses the weight-streaming MFMA kernel (bf16/f16); fp32 uses an exact-fp32 tiled kernel

@@ -29,6 +29,7 @@ struct DecodeParams {
   float* part_lse;  // [B, Hq, S]
   int mode, num_splits, hq, hkv;
   float sm_scale, logit_cap;
+  int64_t k_slot_stride, v_slot_stride;  // elements between consecutive slots (generic kernel)
 };
 
 __device__ __forceinline__ void seq_range(const DecodeParams& p, int b, int64_t& page_off,
@@ -525,8 +526,8 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
   float m = -INFINITY, l = 0.f;
   for (int64_t key = k0; key < k1; ++key) {
     const int64_t slot = p.page_table[page_off + key];
-    const T* kr = kbuf + (slot * p.hkv + kvh) * (int64_t)D;
-    const T* vr = vbuf + (slot * p.hkv + kvh) * (int64_t)Dv;
+    const T* kr = kbuf + slot * p.k_slot_stride + (int64_t)kvh * D;
+    const T* vr = vbuf + slot * p.v_slot_stride + (int64_t)kvh * Dv;
     float d = 0.f;
     for (int i = lane; i < D; i += 64) d = fmaf(to_f32(qh[i]), to_f32(kr[i]), d);
     d = wave_sum(d) * p.sm_scale;
@@ -704,12 +705,66 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   p.hkv = hkv;
   p.sm_scale = sm_scale;
   p.logit_cap = logit_cap;
+  p.k_slot_stride = (int64_t)hkv * head_dim;
+  p.v_slot_stride = (int64_t)hkv * v_head_dim;
   int rc = MI355_OK;
   MI355_DISPATCH_DTYPE(dtype, "decode_attention",
                        rc = launch_decode<T>(q, k_buffer, v_buffer, o, p, bs, head_dim, v_head_dim,
                                              (hipStream_t)stream));
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("decode_attention");
+  return MI355_OK;
+}
+
+int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
+                               const int32_t* page_table, int mode,
+                               const int64_t* req_pool_indices, const int64_t* seq_lens,
+                               const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
+                               float* attn_lse, int num_splits, int64_t bs, int hq,
+                               int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
+                               float sm_scale, float logit_cap, int dtype, void* stream) {
+  MI355_REQUIRE(q && kv_buffer && o && page_table, MI355_ERR_INVALID, "decode_attention_mla: null pointer");
+  MI355_REQUIRE(mode == 0 || mode == 1, MI355_ERR_INVALID, "decode_attention_mla: mode must be 0|1");
+  if (mode == 0)
+    MI355_REQUIRE(req_pool_indices && seq_lens && table_stride > 0, MI355_ERR_INVALID,
+                  "decode_attention_mla: mode 0 needs req_pool_indices, seq_lens, table_stride");
+  else
+    MI355_REQUIRE(kv_indptr, MI355_ERR_INVALID, "decode_attention_mla: mode 1 needs kv_indptr");
+  const int D = kv_lora_rank + rope_dim;
+  MI355_REQUIRE(bs >= 0 && bs <= 65535 && hq > 0 && kv_lora_rank > 0 && rope_dim >= 0 && num_slots > 0 &&
+                    q_stride >= (int64_t)hq * D,
+                MI355_ERR_INVALID, "decode_attention_mla: bad shape hq=%d rank=%d rope=%d", hq, kv_lora_rank, rope_dim);
+  MI355_REQUIRE(D <= 1024, MI355_ERR_UNSUPPORTED, "decode_attention_mla: latent row of %d > 1024", D);
+  MI355_REQUIRE(num_splits >= 1 && num_splits <= 65535 && (num_splits == 1 || (attn_logits && attn_lse)),
+                MI355_ERR_INVALID, "decode_attention_mla: bad num_splits / missing scratch");
+  if (bs == 0) return MI355_OK;
+  DecodeParams p;
+  p.page_table = page_table;
+  p.req_pool_indices = req_pool_indices;
+  p.seq_lens = seq_lens;
+  p.kv_indptr = kv_indptr;
+  p.table_stride = table_stride;
+  p.q_stride = q_stride;
+  p.part_o = attn_logits;
+  p.part_lse = attn_lse;
+  p.mode = mode;
+  p.num_splits = num_splits;
+  p.hq = hq;
+  p.hkv = 1;
+  p.sm_scale = sm_scale;
+  p.logit_cap = logit_cap;
+  p.k_slot_stride = D;   // one latent row per slot; the value is its first kv_lora_rank features
+  p.v_slot_stride = D;
+  hipStream_t st = (hipStream_t)stream;
+  MI355_DISPATCH_DTYPE(dtype, "decode_attention_mla", {
+    hipLaunchKernelGGL((decode_attn_generic_kernel<T>), dim3((unsigned)hq, (unsigned)num_splits, (unsigned)bs),
+                       dim3(64), 0, st, (const T*)q, (const T*)kv_buffer, (const T*)kv_buffer, (T*)o, p, D,
+                       kv_lora_rank);
+    if (num_splits > 1)
+      hipLaunchKernelGGL((decode_merge_kernel<T>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,
+                         p.part_lse, (T*)o, num_splits, kv_lora_rank);
+  });
+  MI355_CHECK_LAUNCH("decode_attention_mla");
   return MI355_OK;
 }
 

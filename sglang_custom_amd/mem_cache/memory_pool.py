@@ -83,3 +83,54 @@ class MHATokenToKVPool:
             cache_k = cache_k.to(self.dtype)
             cache_v = cache_v.to(self.dtype)
         get_ops().set_kv_buffer(self.k_buffer[layer_id], self.v_buffer[layer_id], loc, cache_k, cache_v)
+
+
+class MLATokenToKVPool:
+    """Compressed KV cache of multi-head latent attention
+    (python/sglang/srt/mem_cache/memory_pool.py:769-970): one row of kv_lora_rank + qk_rope_head_dim
+    features per token per layer, [size + page_size, 1, rank + rope]; slot 0 is the sink row.  The
+    value "buffer" is the first kv_lora_rank features of the same rows (:863-871) -- a view, never
+    a copy, which is what lets the attention kernel read each row once for both K and V."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, kv_lora_rank: int,
+                 qk_rope_head_dim: int, layer_num: int, device: str):
+        self.size = size
+        self.page_size = page_size
+        self.dtype = dtype
+        self.store_dtype = dtype
+        self.kv_lora_rank = kv_lora_rank
+        self.qk_rope_head_dim = qk_rope_head_dim
+        self.head_num = 1
+        self.head_dim = kv_lora_rank + qk_rope_head_dim
+        self.v_head_dim = kv_lora_rank
+        self.layer_num = layer_num
+        self.device = device
+        self._kv_all = torch.zeros((layer_num, size + page_size, 1, self.head_dim), dtype=dtype, device=device)
+        self.kv_buffer = [self._kv_all[i] for i in range(layer_num)]
+
+    def get_kv_size_bytes(self) -> int:
+        return self._kv_all.numel() * self._kv_all.element_size()
+
+    def get_key_buffer(self, layer_id: int) -> torch.Tensor:
+        return self.kv_buffer[layer_id]
+
+    def get_value_buffer(self, layer_id: int) -> torch.Tensor:
+        return self.kv_buffer[layer_id][..., : self.kv_lora_rank]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
+
+    def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor = None,
+                      layer_id_override: Optional[int] = None):
+        """cache_k [T, 1, rank + rope] is the whole latent row; cache_v is ignored (:895-909)."""
+        layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
+        buf = self.kv_buffer[layer_id]
+        row = cache_k.to(self.dtype).reshape(loc.numel(), 1, self.head_dim)
+        # the generic scatter kernel copies a K row and a V row per token: hand it the row twice
+        get_ops().set_kv_buffer(buf, buf, loc, row, row)
+
+    def set_mla_kv_buffer(self, layer, loc: torch.Tensor, cache_k_nope: torch.Tensor, cache_k_rope: torch.Tensor):
+        """Latent part and rope part arrive separately (:911-930)."""
+        T = loc.numel()
+        row = torch.cat([cache_k_nope.reshape(T, 1, -1), cache_k_rope.reshape(T, 1, -1)], dim=-1)
+        self.set_kv_buffer(layer, loc, row)

@@ -265,6 +265,25 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
         "decode_attention")
 
 
+def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
+                         attn_lse, num_kv_splits: int, kv_lora_rank: int, sm_scale: float,
+                         logit_cap: float = 0.0) -> None:
+    """MQA over the compressed MLA cache (deepseek_v2.py:866-875): kv_buffer [slots, 1, rank + rope],
+    q [B, H, rank + rope], o [B, H, rank]; the value is kv_buffer[..., :rank]."""
+    _gpu(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    B, Hq, D = q.shape
+    assert kv_buffer.is_contiguous() and kv_buffer.shape[1] == 1 and kv_buffer.shape[2] == D
+    assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous() and o.shape == (B, Hq, kv_lora_rank)
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    check(_lib_().mi355_decode_attention_mla(
+        q.data_ptr(), kv_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
+        req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0),
+        _p(attn_logits), _p(attn_lse), num_kv_splits, B, Hq, kv_lora_rank, D - kv_lora_rank,
+        q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap), _dt(q), _stream(q)),
+        "decode_attention_mla")
+
+
 def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
                          kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr,
                          max_len_extend, sm_scale=None, logit_cap=0.0,

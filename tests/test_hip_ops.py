@@ -212,6 +212,50 @@ def test_decode_attention_shapes_and_logit_cap(ops):
                     assert maxdiff(o[b], ref) <= ATTN_TOL[dtn], (B, Hq, Hkv, D, S, cap, splits)
 
 
+def test_mla_compressed_kv_decode(ops):
+    """DeepSeek-style MQA over the compressed cache (deepseek_v2.py:866-875): 16 local heads, latent
+    row 512 + 64, value = first 512 features of the same row; pool writes go through
+    MLATokenToKVPool; checked against the float64 softmax(q k^T) v of the oracle."""
+    from sglang_custom_amd.mem_cache.memory_pool import MLATokenToKVPool
+
+    class _L:
+        layer_id = 0
+
+    H, rank, rope = 16, 512, 64
+    D = rank + rope
+    for dtn in ("bf16", "f32"):
+        dt = DT[dtn]
+        lens = [200, 1, 77]
+        pool = MLATokenToKVPool(400, 1, dt, rank, rope, 1, DEV)
+        g = torch.Generator().manual_seed(11)
+        slots = (torch.randperm(399, generator=g)[: sum(lens)] + 1)
+        rows = cases.randn((sum(lens), 1, D), 12, dt)
+        half = sum(lens) // 2
+        pool.set_kv_buffer(_L, slots[:half].to(DEV), rows[:half].to(DEV))
+        pool.set_mla_kv_buffer(_L, slots[half:].to(DEV), rows[half:, :, :rank].to(DEV), rows[half:, :, rank:].to(DEV))
+        assert torch.equal(pool.get_key_buffer(0)[slots.to(DEV)].cpu(), rows)
+        assert pool.get_value_buffer(0).shape[-1] == rank and pool.get_key_buffer(0)[0].abs().sum() == 0
+        r2t = torch.zeros((4, 256), dtype=torch.int32)
+        p = 0
+        for b, n in enumerate(lens):
+            r2t[b + 1, :n] = slots[p: p + n].int()
+            p += n
+        rpi = torch.tensor([1, 2, 3], dtype=torch.int64)
+        q = cases.randn((3, H, D), 13, dt)
+        for splits in (1, 3):
+            o = torch.empty((3, H, rank), dtype=dt, device=DEV)
+            lg = torch.empty(3 * H * splits * rank, dtype=torch.float32, device=DEV)
+            ls = torch.empty(3 * H * splits, dtype=torch.float32, device=DEV)
+            ops.decode_attention_mla(q.to(DEV), pool.get_key_buffer(0), o, r2t.to(DEV), rpi.to(DEV),
+                                     torch.tensor(lens, dtype=torch.int64).to(DEV), lg, ls, splits, rank, D ** -0.5)
+            p = 0
+            for b, n in enumerate(lens):
+                kv = rows[p: p + n, 0]
+                ref = ops_ref.attention_fp64(q[b][:, None], kv[None], kv[None, :, :rank], D ** -0.5, None)[:, 0]
+                assert maxdiff(o[b], ref) <= ATTN_TOL[dtn], (dtn, b, splits)
+                p += n
+
+
 def _extend_run(ops, q, kc, vc, r2t, pool, seq, pre, ext, Hkv, D):
     """New-token K/V are read from the cache rows (they are already there) as k_extend/v_extend."""
     T = q.shape[0]
