@@ -275,6 +275,16 @@ int mi355_top_k_top_p_min_p_sample(int32_t* ids, const float* probs, const int32
                                    const float* top_ps, const float* min_ps, const float* uniform,
                                    int64_t rows, int64_t vocab, int64_t row_stride, void* stream);
 
+/* fp8_scaled_mm for M <= 64 on a weight packed by mi355_pack_weight (pass the fp8 bytes as an
+ * [N, K/2] 16-bit matrix: the packed layout is defined on 16-byte fragments): the bf16 decode GEMM's
+ * single-launch weight-streaming kernel with fp8 MFMA and the scale epilogue.  K % 512 == 0,
+ * N < 65536.  Workspace contract as mi355_linear (first 4096 bytes zero at rest).
+ * replaces: apply_fp8_linear (layers/quantization/fp8_utils.py:510-749) at decode batch sizes. */
+int64_t mi355_fp8_packed_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int mi355_fp8_scaled_mm_packed(void* y, const uint8_t* xq, const uint8_t* wq_packed, const float* x_scale,
+                               const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
+                               void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,22 @@ template <> struct Mfma<bf16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
+// fp8 (OCP e4m3fn): a 16-byte fragment feeds TWO k = 32 steps -- within a 64-wide K block lane
+// group c owns bytes [16c, 16c + 16) and step h uses its bytes [8h, 8h + 8); the other operand
+// uses the same map, so products pair up.
+typedef unsigned char fp8_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <> struct Mfma<fp8_t> {
+  using frag = i32x4;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    const long a0 = (long)(((unsigned long)(unsigned)a[1] << 32) | (unsigned)a[0]);
+    const long a1 = (long)(((unsigned long)(unsigned)a[3] << 32) | (unsigned)a[2]);
+    const long b0 = (long)(((unsigned long)(unsigned)b[1] << 32) | (unsigned)b[0]);
+    const long b1 = (long)(((unsigned long)(unsigned)b[3] << 32) | (unsigned)b[2]);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+  }
+};
 template <> struct Mfma<f16_t> {
   using frag = f16x8;
   static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {

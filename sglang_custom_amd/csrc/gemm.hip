@@ -12,6 +12,7 @@
 #include "common.cuh"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mi355 {
 
@@ -181,17 +182,21 @@ int g_force_splits = 0;
 
 template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES = 4, bool ACT = false>
 __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
-    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
+    const T* __restrict__ x, const T* __restrict__ w, const void* __restrict__ bias_,
     OUT* __restrict__ y, float* __restrict__ slab, unsigned* __restrict__ counters, int M, int N,
-    int K, int64_t x_stride, int k_per_split) {
+    int K, int64_t x_stride, int k_per_split, const float* __restrict__ x_scale,
+    const float* __restrict__ w_scale) {
   using frag = typename Mfma<T>::frag;
-  constexpr int BK = 256 / NT;                // k elements per chunk
-  constexpr int S = BK / 32;                  // MFMA k-steps per chunk
-  constexpr int ROW = BK + 8;                 // padded LDS row: bank = 4 * row (mod 64)
+  constexpr bool FP8 = std::is_same<T, fp8_t>::value;
+  constexpr int VE = 16 / sizeof(T);          // elements per 16-byte fragment (8, or 16 for fp8)
+  constexpr int KSTEP = 4 * VE;               // k covered by one fragment row (4 lane groups)
+  constexpr int BK = 8 * KSTEP / NT;          // k elements per chunk (256 / NT; fp8: 512 / NT)
+  constexpr int S = BK / KSTEP;               // fragment steps per chunk
+  constexpr int ROW = BK + VE;                // padded LDS row (+16 B): bank = 4 * row (mod 64)
   constexpr int KMUL = PACKED ? 64 : 1;
   constexpr int R = 16 * MT;
   constexpr int THREADS = 64 * WAVES;
-  constexpr int PIECES = R * (BK / 8);        // 16-B pieces of the x tile
+  constexpr int PIECES = R * (BK / VE);        // 16-B pieces of the x tile
   constexpr int XP = (PIECES + THREADS - 1) / THREADS;   // per thread (the last ones may repeat a piece)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* xs = reinterpret_cast<T*>(smem_raw);     // [2][R][ROW]
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
     const int tile = min(tile0 + WAVES * nt, ntiles - 1);
     int n = tile * 16 + r16;
     n = n < N ? n : N - 1;
-    wrow[nt] = PACKED ? w + (((int64_t)(tile >> 2) * (K >> 5) * 4 + (tile & 3)) * 64 + lane) * 8 + (int64_t)ks * KMUL
-                      : w + (int64_t)n * K + ks + q * 8;
+    wrow[nt] = PACKED ? w + (((int64_t)(tile >> 2) * (K / KSTEP) * 4 + (tile & 3)) * 64 + lane) * VE + (int64_t)ks * KMUL
+                      : w + (int64_t)n * K + ks + q * VE;
   }
   // x tile piece p -> (row, 16-B column)
   const T* xsrc[XP];
@@ -224,10 +229,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   for (int i = 0; i < XP; ++i) {
     int p = threadIdx.x + i * THREADS;
     p = p < PIECES ? p : PIECES - 1;            // clamp, never predicate: the loads stay unconditional
-    const int row = p / (BK / 8), c16 = p % (BK / 8);
+    const int row = p / (BK / VE), c16 = p % (BK / VE);
     xok[i] = row < M;
-    xsrc[i] = x + (int64_t)(row < M ? row : 0) * x_stride + ks + c16 * 8;
-    xdst[i] = row * ROW + c16 * 8;
+    xsrc[i] = x + (int64_t)(row < M ? row : 0) * x_stride + ks + c16 * VE;
+    xdst[i] = row * ROW + c16 * VE;
   }
 
   f32x4 acc[NT][MT];
@@ -237,21 +242,21 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
     for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   frag w0[NT][S], w1[NT][S], w2[NT][S];
-  Vec<T, 8> xreg[XP];
+  Vec<T, VE> xreg[XP];
 
   auto load_w = [&](frag (&dst)[NT][S], int chunk) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const frag* src = reinterpret_cast<const frag*>(wrow[nt] + (int64_t)(chunk * BK + s * 32) * KMUL);
+        const frag* src = reinterpret_cast<const frag*>(wrow[nt] + (int64_t)(chunk * BK + s * KSTEP) * KMUL);
         // packed weights are read exactly once, in whole lines: stream them past the caches
         dst[nt][s] = PACKED ? __builtin_nontemporal_load(src) : *src;
       }
   };
   auto load_x = [&](int chunk) {
 #pragma unroll
-    for (int i = 0; i < XP; ++i) xreg[i] = ldvec<T, 8>(xsrc[i] + chunk * BK);
+    for (int i = 0; i < XP; ++i) xreg[i] = ldvec<T, VE>(xsrc[i] + chunk * BK);
   };
   auto store_x = [&](int buf) {
     T* dst = xs + buf * (R * ROW);
@@ -259,18 +264,18 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
     for (int i = 0; i < XP; ++i) {
       if (!xok[i]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xreg[i].v[j] = (T)0.f;
+        for (int j = 0; j < VE; ++j) xreg[i].v[j] = T(0);
       }
-      stvec<T, 8>(dst + xdst[i], xreg[i]);
+      stvec<T, VE>(dst + xdst[i], xreg[i]);
     }
   };
   auto compute = [&](const frag (&wc)[NT][S], int buf) {
-    const T* xt = xs + buf * (R * ROW) + r16 * ROW + q * 8;
+    const T* xt = xs + buf * (R * ROW) + r16 * ROW + q * VE;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       frag xf[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const frag*>(xt + mt * 16 * ROW + s * 32);
+      for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const frag*>(xt + mt * 16 * ROW + s * KSTEP);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   auto emit = [&](int nt, int mt, f32x4 v) {
     const int tile = tile0 + WAVES * nt;
     const int m = mt * 16 + r16;
-    if constexpr (ACT) {
+    if constexpr (ACT && !FP8) {
       float mine[4], other[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -344,7 +349,16 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + r;
-        if (n < N) y[(int64_t)m * N + n] = finish<T, OUT>(v[r], bias ? to_f32(bias[n]) : 0.f);
+        if (n >= N) continue;
+        if constexpr (FP8) {
+          // apply_fp8_linear's epilogue: (acc * x_scale[m]) * w_scale[n] (+ bias), cast once
+          float o = (v[r] * x_scale[m]) * w_scale[n];
+          if (bias_) o += (float)static_cast<const OUT*>(bias_)[n];
+          y[(int64_t)m * N + n] = (OUT)o;
+        } else {
+          const T* bias = static_cast<const T*>(bias_);
+          y[(int64_t)m * N + n] = finish<T, OUT>(v[r], bias ? to_f32(bias[n]) : 0.f);
+        }
       }
     }
   };
@@ -590,15 +604,16 @@ static bool skinny_ok(int64_t m, int64_t n, int64_t k, int64_t x_stride, const v
 static bool use_ring(int64_t k) { return k % SK_BK == 0 && g_gemm_variant == 0; }
 
 template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES, bool ACT = false>
-static void launch_ring(const T* x, const T* w, const T* bias, OUT* y, float* slab, unsigned* counters,
-                        int M, int N, int K, int64_t x_stride, const SkinnyPlan& p, hipStream_t st) {
+static void launch_ring(const T* x, const T* w, const void* bias, OUT* y, float* slab, unsigned* counters,
+                        int M, int N, int K, int64_t x_stride, const SkinnyPlan& p, hipStream_t st,
+                        const float* x_scale = nullptr, const float* w_scale = nullptr) {
   const dim3 grid((unsigned)p.nblocks, (unsigned)p.splits);
-  const size_t lds = 2 * (16 * MT) * (256 / NT + 8) * sizeof(T);
+  const size_t lds = 2 * (16 * MT) * (512 / NT + 16);   // bytes: same tile geometry for 16-bit and fp8
   auto kern = gemm_ring_kernel<T, MT, NT, OUT, PACKED, WAVES, ACT>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, st, x, w, bias, y, slab, counters, M, N, K,
-                     x_stride, p.k_per_split);
+                     x_stride, p.k_per_split, x_scale, w_scale);
 }
 
 template <typename T, int MT, int NT, typename OUT, bool PACKED, bool ACT = false>
@@ -669,6 +684,35 @@ static void launch_linear(void* y, const void* x, const void* w, const void* bia
                           bool out_f32, hipStream_t st) {
   if (out_f32) launch_linear_t<T, float>(y, x, w, bias, m, n, k, x_stride, ws, skinny, st);
   else launch_linear_t<T, T>(y, x, w, bias, m, n, k, x_stride, ws, skinny, st);
+}
+
+// ---- fp8 W8A8 on the ring kernel -------------------------------------------------------------
+// The packed image of an fp8 weight is the packed image of the same bytes viewed as [N, K/2]
+// 16-bit elements (the layout is defined on 16-byte fragments), so mi355_pack_weight serves both.
+static SkinnyPlan plan_fp8(int64_t m, int64_t n, int64_t k) {
+  SkinnyPlan p = plan_skinny(m, n, k / 2, true);   // same bytes per chunk as a 16-bit GEMM of K/2
+  p.k_per_split *= 2;
+  return p;
+}
+
+template <typename OUT, int MT>
+static void launch_fp8_mt(const fp8_t* x, const fp8_t* w, const void* bias, OUT* y, char* ws, int M, int N,
+                          int K, const SkinnyPlan& p, const float* xs, const float* wsc, hipStream_t st) {
+  unsigned* counters = p.splits > 1 ? reinterpret_cast<unsigned*>(ws) : nullptr;
+  float* slab = p.splits > 1 ? reinterpret_cast<float*>(ws + p.counter_bytes) : nullptr;
+#define F8R(W_) launch_ring<fp8_t, MT, 1, OUT, true, W_>(x, w, bias, y, slab, counters, M, N, K, K, p, st, xs, wsc)
+  if (p.waves == 8) F8R(8); else if (p.waves == 7) F8R(7); else if (p.waves == 6) F8R(6); else F8R(4);
+#undef F8R
+}
+
+template <typename OUT>
+static void launch_fp8(const fp8_t* x, const fp8_t* w, const void* bias, OUT* y, char* ws, int M, int N, int K,
+                       const float* xs, const float* wsc, hipStream_t st) {
+  const SkinnyPlan p = plan_fp8(M, N, K);
+  const int mt = (M + 15) / 16;
+  if (mt <= 1) launch_fp8_mt<OUT, 1>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st);
+  else if (mt <= 2) launch_fp8_mt<OUT, 2>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st);
+  else launch_fp8_mt<OUT, 4>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st);
 }
 
 }  // namespace mi355
@@ -800,6 +844,40 @@ int mi355_linear(void* y, const void* x, const void* w, const void* bias, int64_
                        launch_linear<T>(y, x, w, bias, m, n, k, x_stride, workspace, skinny,
                                         out_f32, (hipStream_t)stream));
   MI355_CHECK_LAUNCH("linear");
+  return MI355_OK;
+}
+
+int64_t mi355_fp8_packed_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m < 1 || m > 64 || n < 1 || k < 512) return 0;
+  const SkinnyPlan p = plan_fp8(m, n, k);
+  return p.counter_bytes + p.slab_bytes;
+}
+
+int mi355_fp8_scaled_mm_packed(void* y, const uint8_t* xq, const uint8_t* wq_packed, const float* x_scale,
+                               const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
+                               void* workspace, int64_t workspace_bytes, int out_dtype, void* stream) {
+  MI355_REQUIRE(y && xq && wq_packed && x_scale && w_scale, MI355_ERR_INVALID, "fp8_scaled_mm_packed: null pointer");
+  MI355_REQUIRE(m >= 0 && m <= 64 && n > 0 && k > 0, MI355_ERR_INVALID,
+                "fp8_scaled_mm_packed: needs 0 <= M <= 64 (m=%lld n=%lld k=%lld)", (long long)m, (long long)n,
+                (long long)k);
+  MI355_REQUIRE(k % 512 == 0 && n < 64 * 1024, MI355_ERR_UNSUPPORTED,
+                "fp8_scaled_mm_packed: needs K %% 512 == 0 and N < 65536 (k=%lld n=%lld)", (long long)k, (long long)n);
+  MI355_REQUIRE(aligned16(xq) && aligned16(wq_packed), MI355_ERR_INVALID, "fp8_scaled_mm_packed: misaligned pointer");
+  if (m == 0) return MI355_OK;
+  const int64_t need = mi355_fp8_packed_workspace_bytes(m, n, k);
+  if (need > 0 && (!workspace || workspace_bytes < need || !aligned16(workspace))) {
+    set_error("fp8_scaled_mm_packed: workspace of %lld bytes (16-B aligned) required, got %lld", (long long)need,
+              (long long)workspace_bytes);
+    return MI355_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (out_dtype) {
+    case MI355_BF16: launch_fp8<bf16_t>(xq, wq_packed, bias, (bf16_t*)y, (char*)workspace, (int)m, (int)n, (int)k, x_scale, w_scale, st); break;
+    case MI355_F16: launch_fp8<f16_t>(xq, wq_packed, bias, (f16_t*)y, (char*)workspace, (int)m, (int)n, (int)k, x_scale, w_scale, st); break;
+    case MI355_F32: launch_fp8<float>(xq, wq_packed, bias, (float*)y, (char*)workspace, (int)m, (int)n, (int)k, x_scale, w_scale, st); break;
+    default: set_error("fp8_scaled_mm_packed: unsupported out dtype %d", out_dtype); return MI355_ERR_UNSUPPORTED;
+  }
+  MI355_CHECK_LAUNCH("fp8_scaled_mm_packed");
   return MI355_OK;
 }
 

@@ -45,6 +45,57 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(uint8_t* __res
   }
 }
 
+// Vectorised form for 16-bit inputs with k % 8 == 0, k <= 16384: the row is read ONCE with
+// 16-byte loads and stays in registers between the absmax pass and the conversion (one memory
+// round trip, 8-byte stores).  Same arithmetic, element by element, as the kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void per_token_quant_fp8_vec_kernel(uint8_t* __restrict__ xq,
+                                                                      float* __restrict__ scales,
+                                                                      const T* __restrict__ x, int64_t k,
+                                                                      int64_t x_stride) {
+  constexpr int MAXV = 8;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const T* xr = x + row * x_stride;
+  uint8_t* qr = xq + row * k;
+  const int nvec = (int)(k >> 3);
+  Vec<T, 8> v[MAXV];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    if (idx < nvec) {
+      v[i] = ldvec<T, 8>(xr + (int64_t)idx * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(to_f32(v[i].v[j])));
+    }
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float s = fmaxf(amax, 1e-10f) / kFp8Max;
+  const float inv = 1.0f / s;
+  if (threadIdx.x == 0) scales[row] = s;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    if (idx < nvec) {
+      unsigned out[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = fminf(fmaxf(to_f32(v[i].v[4 * h + j]) * inv, -kFp8Max), kFp8Max);
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+        out[h] = (unsigned)pk;
+      }
+      *reinterpret_cast<uint2*>(qr + (int64_t)idx * 8) = uint2{out[0], out[1]};
+    }
+  }
+}
+
 // ---- skinny fp8 GEMM -------------------------------------------------------------------------
 constexpr int F8_BK = 512;             // fp8 elements (bytes) of K per chunk
 constexpr int F8_LDS_ROW = F8_BK + 16; // padded LDS row in bytes
@@ -252,10 +303,16 @@ int mi355_per_token_quant_fp8(uint8_t* xq, float* scales, const void* x, int64_t
   MI355_REQUIRE(rows >= 0 && k > 0 && x_stride >= k, MI355_ERR_INVALID,
                 "per_token_quant_fp8: bad shape");
   if (rows == 0) return MI355_OK;
-  MI355_DISPATCH_DTYPE(dtype, "per_token_quant_fp8",
-                       hipLaunchKernelGGL((per_token_quant_fp8_kernel<T>), dim3((unsigned)rows),
-                                          dim3(256), 0, (hipStream_t)stream, xq, scales,
-                                          (const T*)x, k, x_stride));
+  const bool vec = dtype != MI355_F32 && k % 8 == 0 && k <= 16384 && x_stride % 8 == 0 && aligned16(x) &&
+                   (reinterpret_cast<uintptr_t>(xq) & 7) == 0;
+  MI355_DISPATCH_DTYPE(dtype, "per_token_quant_fp8", {
+    if (vec)
+      hipLaunchKernelGGL((per_token_quant_fp8_vec_kernel<T>), dim3((unsigned)rows), dim3(256), 0,
+                         (hipStream_t)stream, xq, scales, (const T*)x, k, x_stride);
+    else
+      hipLaunchKernelGGL((per_token_quant_fp8_kernel<T>), dim3((unsigned)rows), dim3(256), 0,
+                         (hipStream_t)stream, xq, scales, (const T*)x, k, x_stride);
+  });
   MI355_CHECK_LAUNCH("per_token_quant_fp8");
   return MI355_OK;
 }

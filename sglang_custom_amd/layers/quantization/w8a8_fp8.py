@@ -27,16 +27,51 @@ def quantize_weight_per_channel(w: torch.Tensor):
     return q, scale
 
 
+SKINNY_MAX_M = 64
+_SCALED_MM_OK = None   # None = untried; torch._scaled_mm (hipBLASLt) with row-wise scales
+
+
+def _library_scaled_mm(xq, wq, xs, ws, out_dtype, bias):
+    """Large-M fp8 GEMM as a plain library call: torch._scaled_mm with per-row / per-column
+    scales, the call the reference itself makes (fp8_utils.py:720-749).  Returns None when this
+    torch build does not support it on the device."""
+    global _SCALED_MM_OK
+    if _SCALED_MM_OK is False:
+        return None
+    try:
+        y = torch._scaled_mm(xq, wq.t(), scale_a=xs, scale_b=ws.t(), out_dtype=out_dtype, bias=bias)
+        _SCALED_MM_OK = True
+        return y
+    except (RuntimeError, ValueError, NotImplementedError):
+        if _SCALED_MM_OK:   # it worked before: a real error, not a capability probe
+            raise
+        _SCALED_MM_OK = False
+        return None
+
+
 class W8A8Fp8LinearMethod:
     def process_weights_after_loading(self, layer) -> None:
         if layer.weight.dtype != FP8_DTYPE:
             q, s = quantize_weight_per_channel(layer.weight.data)
             layer.weight = torch.nn.Parameter(q, requires_grad=False)
             layer.weight_scale = torch.nn.Parameter(s.contiguous(), requires_grad=False)
+        # decode copy in the weight-streaming kernel's fragment order (the row-major one stays for
+        # the large-M library GEMM)
+        w = layer.weight
+        layer.weight_packed = None
+        if w.is_cuda and w.shape[1] % 512 == 0 and w.shape[0] < 65536:
+            layer.weight_packed = get_ops().pack_weight_fp8(w.data)
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         ops = get_ops()
         x2 = x.view(-1, x.shape[-1])
         xq, xs = ops.per_token_quant_fp8(x2)
-        y = ops.fp8_scaled_mm(xq, layer.weight, xs, layer.weight_scale, x.dtype, bias)
+        y = None
+        if x2.shape[0] > SKINNY_MAX_M and x2.is_cuda and x2.shape[1] % 16 == 0 and layer.weight.shape[0] % 16 == 0:
+            y = _library_scaled_mm(xq, layer.weight, xs, layer.weight_scale, x.dtype, bias)
+        wp = getattr(layer, "weight_packed", None)
+        if y is None and wp is not None and x2.shape[0] <= SKINNY_MAX_M:
+            y = ops.fp8_scaled_mm_packed(xq, wp, layer.weight.shape[0], xs, layer.weight_scale, x.dtype, bias)
+        if y is None:
+            y = ops.fp8_scaled_mm(xq, layer.weight, xs, layer.weight_scale, x.dtype, bias)
         return y.view(*x.shape[:-1], y.shape[-1])

@@ -453,6 +453,35 @@ def fp8_scaled_mm(xq: torch.Tensor, wq: torch.Tensor, x_scale: torch.Tensor, w_s
     return y
 
 
+def pack_weight_fp8(wq: torch.Tensor) -> torch.Tensor:
+    """[N, K] e4m3fn weight -> packed copy for fp8_scaled_mm_packed (same 16-byte-fragment layout
+    as pack_weight: the bytes are packed as an [N, K/2] 16-bit matrix)."""
+    assert wq.dtype == torch.float8_e4m3fn and wq.is_contiguous() and wq.shape[1] % 64 == 0
+    return pack_weight(wq.view(torch.bfloat16)).view(torch.float8_e4m3fn)
+
+
+def fp8_scaled_mm_packed(xq: torch.Tensor, wq_packed: torch.Tensor, n: int, x_scale: torch.Tensor,
+                         w_scale: torch.Tensor, out_dtype: torch.dtype,
+                         bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp8_scaled_mm for M <= 64 on a weight from pack_weight_fp8 (n output features)."""
+    _gpu(xq, wq_packed, x_scale, w_scale, bias)
+    M, K = xq.shape
+    assert xq.is_contiguous() and xq.dtype == torch.float8_e4m3fn and wq_packed.dtype == torch.float8_e4m3fn
+    assert x_scale.dtype == torch.float32 and x_scale.numel() == M and w_scale.dtype == torch.float32
+    assert w_scale.numel() == n and (bias is None or bias.dtype == out_dtype)
+    y = torch.empty((M, n), dtype=out_dtype, device=xq.device)
+    if M == 0:
+        return y
+    lib = _lib_()
+    need = lib.mi355_fp8_packed_workspace_bytes(M, n, K)
+    ws = _workspace(xq.device, need) if need > 0 else None
+    check(lib.mi355_fp8_scaled_mm_packed(y.data_ptr(), xq.data_ptr(), wq_packed.data_ptr(), x_scale.data_ptr(),
+                                         w_scale.data_ptr(), _p(bias), M, n, K, _p(ws),
+                                         ws.numel() if ws is not None else 0, _DT[out_dtype], _stream(xq)),
+          "fp8_scaled_mm_packed")
+    return y
+
+
 # ---------------------------------------------------------------------------------- sampling
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     """torch.argmax(logits, -1) on fp32 [B, V] (layers/sampler.py:74)."""

@@ -491,6 +491,31 @@ def test_fp8_quant_and_gemm(ops, golden_ops):
         assert maxdiff(y, exact) <= 1.6e-2, (M, N, K)
 
 
+def test_fp8_packed_weight_streaming_gemm(ops):
+    """fp8 W8A8 through the single-launch weight-streaming kernel (packed weight) against the
+    oracle's apply_fp8_linear restatement and the row-major fp8 kernel, for split and unsplit
+    plans, every M tile count, bias and fp32 output; repeats give identical bits."""
+    for i, (M, N, K) in enumerate([(64, 6144, 4096), (64, 4096, 14336), (17, 28672, 4096), (1, 512, 512), (33, 1000, 1024)]):
+        x = cases.randn((M, K), 400 + i, torch.bfloat16)
+        w = cases.randn((N, K), 420 + i, torch.bfloat16, 1.0 / math.sqrt(K))
+        b = cases.randn((N,), 440 + i, torch.bfloat16) if i % 2 else None
+        from sglang_custom_amd.layers.quantization.w8a8_fp8 import quantize_weight_per_channel
+        wq, ws = quantize_weight_per_channel(w)
+        ref = ops_ref.fp8_linear(x, wq, ws, b)
+        xq, xs = ops.per_token_quant_fp8(x.to(DEV))
+        wp = ops.pack_weight_fp8(wq.to(DEV))
+        bd = b.to(DEV) if b is not None else None
+        got = ops.fp8_scaled_mm_packed(xq, wp, N, xs, ws.to(DEV), torch.bfloat16, bd)
+        base = ops.fp8_scaled_mm(xq, wq.to(DEV), xs, ws.to(DEV), torch.bfloat16, bd)
+        assert got.shape == (M, N)
+        assert maxdiff(got, ref) <= ROUND_TOL["bf16"], (M, N, K)
+        assert maxdiff(got, base) <= ROUND_TOL["bf16"], (M, N, K)
+        assert (got != base).float().mean() < 0.01       # fp32 sums in another order: rare flips
+        assert torch.equal(got, ops.fp8_scaled_mm_packed(xq, wp, N, xs, ws.to(DEV), torch.bfloat16, bd))
+        g32 = ops.fp8_scaled_mm_packed(xq, wp, N, xs, ws.to(DEV), torch.float32, bd.float() if bd is not None else None)
+        assert maxdiff(g32, got) <= ROUND_TOL["bf16"]
+
+
 def test_sampling(ops, golden_ops):
     for i in range(len(cases.SAMPLING_CASES)):
         logits, temps, ks, ps, mps = cases.sampling_inputs(i)
