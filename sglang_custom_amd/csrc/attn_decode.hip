@@ -348,92 +348,108 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const T* __restri
   const int64_t row_stride = (int64_t)p.hkv * D;
   const T* kbase = kbuf + (int64_t)kvh * D + 8 * c4;     // + slot * row_stride + 32 s
   const T* vbase = vbuf + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
-  const int64_t wave_first = k0 + (int64_t)wave * 16;
-  const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 63) / 64) : 0;
+  // A wave takes TL tiles of 16 keys per step (all their K/V loads are issued before the first
+  // tile is computed); the 4 waves interleave steps.  Measured: TL = 2 (16 KiB per wave per memory
+  // round trip) is no faster than TL = 1 and costs 32 VGPRs.
+  constexpr int TL = 1;
+  constexpr int STEP = 16 * TL;
+  const int64_t wave_first = k0 + (int64_t)wave * STEP;
+  const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 4 * STEP - 1) / (4 * STEP)) : 0;
   const int64_t last_key = len - 1;
   float* my_p = &sm_p[wave][c4][0][0];
 
-  auto load_slots = [&](int it, int32_t& sk, int32_t (&sv)[4]) {
-    const int64_t tb = wave_first + (int64_t)it * 64;
-    int64_t key = tb + r16;
-    sk = pt[key < last_key ? key : last_key];
+  // Page-table reads are clamped to the sequence, never predicated: unconditional loads keep the
+  // compiler's s_waitcnt counted.
+  auto load_slots = [&](int it, int32_t (&sk)[TL], int32_t (&sv)[TL][4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      key = tb + 4 * c4 + u;
-      sv[u] = pt[key < last_key ? key : last_key];
+    for (int tl = 0; tl < TL; ++tl) {
+      const int64_t tb = wave_first + (int64_t)it * (4 * STEP) + tl * 16;
+      int64_t key = tb + r16;
+      sk[tl] = pt[key < last_key ? key : last_key];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        key = tb + 4 * c4 + u;
+        sv[tl][u] = pt[key < last_key ? key : last_key];
+      }
     }
   };
-
-  auto load_kv = [&](int32_t sk, const int32_t (&sv)[4], frag (&kf)[4], Vec<T, VE> (&vv)[4]) {
-    const T* krow = kbase + (int64_t)sk * row_stride;
+  auto load_kv = [&](const int32_t (&sk)[TL], const int32_t (&sv)[TL][4], frag (&kf)[TL][4],
+                     Vec<T, VE> (&vv)[TL][4]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+    for (int tl = 0; tl < TL; ++tl) {
+      const T* krow = kbase + (int64_t)sk[tl] * row_stride;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)sv[u] * row_stride);
+      for (int s = 0; s < 4; ++s) kf[tl][s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+    }
+#pragma unroll
+    for (int tl = 0; tl < TL; ++tl)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[tl][u] = ldvec<T, VE>(vbase + (int64_t)sv[tl][u] * row_stride);
   };
 
   if (n_iter > 0) {
-    // The page-table entries of step it+1 are fetched while step it is computed.  Reads past the
-    // range are clamped to the last key, never predicated, so the compiler's waits stay counted.
-    // K/V are not double-buffered: with >= 8 waves per CU the other waves' loads cover this
-    // wave's arithmetic (measured: a second K/V buffer bought nothing and costs 32 VGPRs).
-    int32_t sk, sv[4];
-    frag kf[4];
-    Vec<T, VE> vv[4];
+    // The page-table entries of step it+1 are fetched while step it is computed.  K/V are not
+    // double-buffered: with >= 8 waves per CU the other waves' loads cover this wave's
+    // arithmetic (measured: a second K/V buffer bought nothing).
+    int32_t sk[TL], sv[TL][4];
+    frag kf[TL][4];
+    Vec<T, VE> vv[TL][4];
     load_slots(0, sk, sv);
     for (int it = 0; it < n_iter; ++it) {
       load_kv(sk, sv, kf, vv);
       load_slots(it + 1, sk, sv);
+#pragma unroll
+      for (int tl = 0; tl < TL; ++tl) {
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sc = Mfma<T>::run(kf[tl][s], qf[s], sc);
 
-      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // lane (g = r16, c4): keys tb + 4 c4 + r
+        const int64_t kb0 = wave_first + (int64_t)it * (4 * STEP) + tl * 16 + 4 * c4;
+        float x[4], mx = m;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sc = Mfma<T>::run(kf[s], qf[s], sc);
-
-      // lane (g = r16, c4): keys tb + 4 c4 + r
-      const int64_t kb0 = wave_first + (int64_t)it * 64 + 4 * c4;
-      float x[4], mx = m;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = sc[r] * qmul;
-        if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
-        x[r] = kb0 + r < k1 ? v : -INFINITY;
-        mx = fmaxf(mx, x[r]);
-      }
-      const float ms = safe_m(mx);
-      const float alpha = exp2f(m - ms);
-      f32x4 pr;
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pr[r] = exp2f(x[r] - ms);
-        psum += pr[r];
-      }
-      l = l * alpha + psum;
-      m = mx;
-      if (r16 < G) {
-        *reinterpret_cast<f32x4*>(my_p + r16 * 8) = pr;
-        my_p[r16 * 8 + 4] = alpha;
-      }
-      __builtin_amdgcn_wave_barrier();
-
-      float vf[4][VE];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int j = 0; j < VE; ++j) vf[u][j] = to_f32(vv[u].v[j]);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const f32x4 pg = *reinterpret_cast<const f32x4*>(my_p + g * 8);
-        const float ag = my_p[g * 8 + 4];
-#pragma unroll
-        for (int j = 0; j < VE; ++j) {
-          float a = acc[g][j] * ag;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) a = fmaf(pg[u], vf[u][j], a);
-          acc[g][j] = a;
+        for (int r = 0; r < 4; ++r) {
+          float v = sc[r] * qmul;
+          if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
+          x[r] = kb0 + r < k1 ? v : -INFINITY;
+          mx = fmaxf(mx, x[r]);
         }
+        const float ms = safe_m(mx);
+        const float alpha = exp2f(m - ms);
+        f32x4 pr;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[r] = exp2f(x[r] - ms);
+          psum += pr[r];
+        }
+        l = l * alpha + psum;
+        m = mx;
+        if (r16 < G) {
+          *reinterpret_cast<f32x4*>(my_p + r16 * 8) = pr;
+          my_p[r16 * 8 + 4] = alpha;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        float vf[4][VE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < VE; ++j) vf[u][j] = to_f32(vv[tl][u].v[j]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const f32x4 pg = *reinterpret_cast<const f32x4*>(my_p + g * 8);
+          const float ag = my_p[g * 8 + 4];
+#pragma unroll
+          for (int j = 0; j < VE; ++j) {
+            float a = acc[g][j] * ag;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a = fmaf(pg[u], vf[u][j], a);
+            acc[g][j] = a;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
   }
 
