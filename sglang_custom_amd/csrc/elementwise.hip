@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(T* __restrict__ out,
 // cache.  Rounding mirrors torch elementwise ops on dtype T: cos,sin -> T; each product and
 // each sum rounds to T.
 // ------------------------------------------------------------------------------------------
-template <typename T, typename CT, typename LT>
+template <typename T, typename CT, typename LT, bool VEC = false>
 __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restrict__ k,
                                                    const T* __restrict__ v,
                                                    const int64_t* __restrict__ positions,
@@ -201,9 +201,35 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
   const int nheads = hq + hkv;
   const int64_t slot = k_buffer ? (int64_t)loc[t] : 0;
   T* kdst = k_buffer ? k_buffer + slot * (int64_t)hkv * head_dim : nullptr;
-  const int rot_chunks = (nheads * half + 255) / 256;
+  const int rot_chunks = VEC ? (nheads * (half / V16<T>::n) + 255) / 256 : (nheads * half + 255) / 256;
 
   if ((int)blockIdx.y < rot_chunks) {
+    if constexpr (VEC) {
+      // neox layout, 16-byte accesses: one item = VE consecutive pairs (i, i + half) of one head
+      constexpr int VE = V16<T>::n;
+      const int per_head = half / VE;
+      const int w = blockIdx.y * 256 + threadIdx.x;
+      if (w >= nheads * per_head) return;
+      const int h = w / per_head, i = (w - h * per_head) * VE;
+      T* base = (h < hq) ? qt + (int64_t)h * head_dim : kt + (int64_t)(h - hq) * head_dim;
+      const Vec<T, VE> a = ldvec<T, VE>(base + i), b = ldvec<T, VE>(base + i + half);
+      Vec<T, VE> o1v, o2v;
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        const float c = round_to<T>((float)cs[i + j]), sn = round_to<T>((float)cs[half + i + j]);
+        const float x1 = to_f32(a.v[j]), x2 = to_f32(b.v[j]);
+        o1v.v[j] = from_f32<T>(round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * sn)));
+        o2v.v[j] = from_f32<T>(round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * sn)));
+      }
+      stvec<T, VE>(base + i, o1v);
+      stvec<T, VE>(base + i + half, o2v);
+      if (kdst && h >= hq) {
+        T* d = kdst + (int64_t)(h - hq) * head_dim;
+        stvec<T, VE>(d + i, o1v);
+        stvec<T, VE>(d + i + half, o2v);
+      }
+      return;
+    }
     const int w = blockIdx.y * 256 + threadIdx.x;
     if (w >= nheads * half) return;
     const int h = w / half, i = w - h * half;
@@ -230,7 +256,13 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
       const int h = cw / pass, i = rotary_dim + (cw - h * pass);
       kdst[(int64_t)h * head_dim + i] = kt[(int64_t)h * head_dim + i];
     }
-    if (cw < hkv * head_dim) {
+    if constexpr (VEC) {
+      constexpr int VE = V16<T>::n;
+      if (cw * VE < hkv * head_dim) {
+        T* vdst = v_buffer + slot * (int64_t)hkv * head_dim;
+        stvec<T, VE>(vdst + cw * VE, ldvec<T, VE>(v + t * v_stride + cw * VE));
+      }
+    } else if (cw < hkv * head_dim) {
       T* vdst = v_buffer + slot * (int64_t)hkv * head_dim;
       vdst[cw] = v[t * v_stride + cw];
     }
@@ -290,22 +322,31 @@ static void rope_launch(void* q, void* k, const void* v, const int64_t* position
                         int head_dim, int rotary_dim, int64_t q_stride, int64_t k_stride,
                         int64_t v_stride, int is_neox, void* k_buffer, void* v_buffer,
                         const void* loc, int loc_itype, hipStream_t st) {
-  const int rot_chunks = ((hq + hkv) * (rotary_dim / 2) + 255) / 256;
-  const int copy_chunks = k_buffer ? (hkv * head_dim + 255) / 256 : 0;
+  constexpr int VE = V16<T>::n;
+  // 16-byte path: neox pairs, whole head rotated, everything 16-byte aligned
+  const bool vec = is_neox && rotary_dim == head_dim && (rotary_dim / 2) % VE == 0 && q_stride % VE == 0 &&
+                   k_stride % VE == 0 && aligned16(q) && aligned16(k) &&
+                   (!k_buffer || (v_stride % VE == 0 && aligned16(v) && aligned16(k_buffer) && aligned16(v_buffer)));
+  const int rot_items = vec ? (hq + hkv) * (rotary_dim / 2 / VE) : (hq + hkv) * (rotary_dim / 2);
+  const int copy_items = !k_buffer ? 0 : vec ? hkv * head_dim / VE : hkv * head_dim;
+  const int rot_chunks = (rot_items + 255) / 256;
+  const int copy_chunks = (copy_items + 255) / 256;
   const dim3 grid((unsigned)tokens, (unsigned)(rot_chunks + copy_chunks)), block(256);
   const bool f32cache = cache_dtype == MI355_F32 && DType<T>::code != MI355_F32;
   const bool i32 = loc_itype == MI355_I32;
 #define ROPE_ARGS(CT, LT)                                                                    \
   (T*)q, (T*)k, (const T*)v, positions, (const CT*)cache, hq, hkv, head_dim, rotary_dim,      \
       q_stride, k_stride, v_stride, is_neox, (T*)k_buffer, (T*)v_buffer, (const LT*)loc
-  if (f32cache && i32)
-    hipLaunchKernelGGL((rope_kernel<T, float, int32_t>), grid, block, 0, st, ROPE_ARGS(float, int32_t));
-  else if (f32cache)
-    hipLaunchKernelGGL((rope_kernel<T, float, int64_t>), grid, block, 0, st, ROPE_ARGS(float, int64_t));
-  else if (i32)
-    hipLaunchKernelGGL((rope_kernel<T, T, int32_t>), grid, block, 0, st, ROPE_ARGS(T, int32_t));
-  else
-    hipLaunchKernelGGL((rope_kernel<T, T, int64_t>), grid, block, 0, st, ROPE_ARGS(T, int64_t));
+#define ROPE_LAUNCH(CT, LT)                                                                              \
+  do {                                                                                                   \
+    if (vec) hipLaunchKernelGGL((rope_kernel<T, CT, LT, true>), grid, block, 0, st, ROPE_ARGS(CT, LT));  \
+    else hipLaunchKernelGGL((rope_kernel<T, CT, LT, false>), grid, block, 0, st, ROPE_ARGS(CT, LT));     \
+  } while (0)
+  if (f32cache && i32) ROPE_LAUNCH(float, int32_t);
+  else if (f32cache) ROPE_LAUNCH(float, int64_t);
+  else if (i32) ROPE_LAUNCH(T, int32_t);
+  else ROPE_LAUNCH(T, int64_t);
+#undef ROPE_LAUNCH
 #undef ROPE_ARGS
 }
 
