@@ -36,6 +36,15 @@ class Req:
         self.extend_input_len = len(self.fill_ids)
         self.cached_tokens = 0
         self.already_computed = 0
+        self.finished = False
+        self.is_chunked = 0   # > 0 while a prompt is being prefilled in chunks (schedule_batch.py Req.is_chunked)
+
+    def init_next_round_input(self, prefix_indices=None):
+        """(Req.init_next_round_input) tokens to run next = prompt + outputs so far; the part that
+        already has KV slots comes in as prefix_indices."""
+        self.fill_ids = self.origin_input_ids + self.output_ids
+        self.prefix_indices = [] if prefix_indices is None else prefix_indices
+        self.extend_input_len = len(self.fill_ids) - len(self.prefix_indices)
 
     @property
     def seqlen(self) -> int:
@@ -130,7 +139,11 @@ class ScheduleBatch:
             req.req_pool_idx = req_pool_indices[i]
             assert seq_len - pre_len == req.extend_input_len
             if pre_len > 0:
-                self.req_to_token_pool.write((req.req_pool_idx, slice(0, pre_len)), req.prefix_indices)
+                pre = req.prefix_indices
+                if not torch.is_tensor(pre):
+                    pre = torch.tensor(pre, dtype=torch.int32)
+                self.req_to_token_pool.write((req.req_pool_idx, slice(0, pre_len)),
+                                             pre.to(device=dev, dtype=torch.int32))
             req.cached_tokens += pre_len - req.already_computed
             req.already_computed = seq_len
 
@@ -181,6 +194,50 @@ class ScheduleBatch:
             sampling_info=self.sampling_info,
             positions=self.positions if self.forward_mode.is_decode() else None,
         )
+
+    def is_empty(self) -> bool:
+        return len(self.reqs) == 0
+
+    def filter_batch(self, keep_indices: Optional[List[int]] = None, chunked_req_to_exclude=None):
+        """Drop finished (and still-chunked) requests from a decode batch (schedule_batch.py:1575-1622)."""
+        if keep_indices is None:
+            keep_indices = [i for i, r in enumerate(self.reqs) if not r.finished and r is not chunked_req_to_exclude]
+        if len(keep_indices) == len(self.reqs):
+            return
+        if not keep_indices:
+            self.reqs = []
+            self.seq_lens_cpu_list = []
+            self.seq_lens_sum = 0
+            self.req_pool_indices = self.seq_lens = self.output_ids = self.positions = None
+            return
+        keep = torch.tensor(keep_indices, dtype=torch.int64).to(self.device, non_blocking=True)
+        self.reqs = [self.reqs[i] for i in keep_indices]
+        self.req_pool_indices = self.req_pool_indices[keep]
+        self.seq_lens = self.seq_lens[keep]
+        self.seq_lens_cpu_list = [self.seq_lens_cpu_list[i] for i in keep_indices]
+        self.seq_lens_sum = sum(self.seq_lens_cpu_list)
+        if self.output_ids is not None:
+            self.output_ids = self.output_ids[keep]
+        self.positions = None
+        self.out_cache_loc = None
+        self.sampling_info.filter_batch(keep_indices, keep)
+
+    def merge_batch(self, other: "ScheduleBatch"):
+        """Append a just-prefilled batch to the running decode batch (schedule_batch.py:1624-1668)."""
+        if self.is_empty():
+            self.__dict__.update(other.__dict__)
+            return
+        self.sampling_info.merge_batch(other.sampling_info)
+        self.req_pool_indices = torch.cat([self.req_pool_indices, other.req_pool_indices])
+        self.seq_lens = torch.cat([self.seq_lens, other.seq_lens])
+        self.seq_lens_cpu_list = self.seq_lens_cpu_list + other.seq_lens_cpu_list
+        self.seq_lens_sum += other.seq_lens_sum
+        self.out_cache_loc = None
+        self.positions = None
+        if self.output_ids is not None and other.output_ids is not None:
+            self.output_ids = torch.cat([self.output_ids.to(torch.int64), other.output_ids.to(torch.int64)])
+        self.reqs = self.reqs + other.reqs
+        self.return_logprob = self.return_logprob or other.return_logprob
 
     def release(self):
         """Return every slot of the batch (what the scheduler's cache_finished_req does)."""

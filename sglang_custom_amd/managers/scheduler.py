@@ -1,0 +1,195 @@
+"""Continuous-batching loop that drives the hot path: the part of the reference's Scheduler that
+decides what runs next and folds results back into the batches
+(python/sglang/srt/managers/scheduler.py: get_next_batch_to_run :1608-1680, get_new_batch_prefill
+:1682-1830, update_running_batch :1832-1866, run_batch :1868-1930;
+schedule_policy.py PrefillAdder: add_one_req / add_chunked_req budgets;
+scheduler_output_processor_mixin.py: process_batch_result_prefill / _decode).
+
+Kept: FCFS admission under three budgets (free KV slots incl. the tokens running requests may
+still generate, max_prefill_tokens per prefill batch, chunked_prefill_size per chunk), chunked
+prefill of long prompts (the unfinished request keeps its KV slots and re-enters the next prefill
+batch with them as its prefix), prefill-first policy, merge of prefilled requests into the running
+decode batch, per-step retirement of finished requests with slot release.
+Left out on purpose: the radix prefix cache, retraction under memory pressure (admission is
+conservative instead), mixed prefill+decode batches, priorities, streaming, the IPC around it."""
+from typing import Dict, List, Optional
+
+import torch
+
+from ..model_executor.forward_batch_info import ForwardBatch
+from .schedule_batch import Req, ScheduleBatch
+
+
+class Scheduler:
+    def __init__(self, model_runner, eos_token_id: Optional[int] = None):
+        self.mr = model_runner
+        sa = model_runner.server_args
+        self.eos_token_id = eos_token_id
+        self.max_running_requests = model_runner.req_to_token_pool.size
+        cps = sa.chunked_prefill_size
+        self.chunked_prefill_size = cps if cps is not None and cps > 0 else None
+        self.max_prefill_tokens = sa.max_prefill_tokens
+        self.waiting_queue: List[Req] = []
+        self.running_batch: ScheduleBatch = self._new_batch([])
+        self.chunked_req: Optional[Req] = None
+        self.finished: Dict[object, Req] = {}
+        self.num_prefill_batches = 0
+        self.num_decode_steps = 0
+
+    # ---- queue ----
+    def add_request(self, req: Req) -> None:
+        total = len(req.origin_input_ids) + req.sampling_params.max_new_tokens
+        if total > self.mr.req_to_token_pool.max_context_len:
+            raise ValueError(f"request {req.rid}: {total} tokens exceed the context length")
+        self.waiting_queue.append(req)
+
+    def _new_batch(self, reqs) -> ScheduleBatch:
+        mr = self.mr
+        return ScheduleBatch.init_new(reqs=reqs, req_to_token_pool=mr.req_to_token_pool,
+                                      token_to_kv_pool_allocator=mr.token_to_kv_pool_allocator,
+                                      tree_cache=None, model_config=mr.model_config)
+
+    # ---- admission (PrefillAdder) ----
+    def _reserved_decode_tokens(self) -> int:
+        """Slots the running requests may still need (rem_total_tokens of PrefillAdder)."""
+        return sum(r.sampling_params.max_new_tokens - len(r.output_ids) for r in self.running_batch.reqs)
+
+    def get_new_batch_prefill(self) -> Optional[ScheduleBatch]:
+        if not self.waiting_queue and self.chunked_req is None:
+            return None
+        alloc = self.mr.token_to_kv_pool_allocator
+        rem_total = alloc.available_size() - self._reserved_decode_tokens()
+        rem_input = self.max_prefill_tokens
+        rem_chunk = self.chunked_prefill_size
+        free_reqs = self.mr.req_to_token_pool.available_size()
+        can_run: List[Req] = []
+
+        def take(req: Req, prefix) -> bool:
+            """Admit req (whole, or its next chunk); returns False when the batch is full."""
+            nonlocal rem_total, rem_input, rem_chunk
+            req.init_next_round_input(prefix)
+            need_all = req.extend_input_len + req.sampling_params.max_new_tokens - len(req.output_ids)
+            if need_all > rem_total:
+                return False
+            n = req.extend_input_len
+            if rem_chunk is not None and n > rem_chunk:
+                if rem_chunk <= 0:
+                    return False
+                # truncate to the chunk budget (add_chunked_req / add_one_req trunc_len)
+                n = rem_chunk
+                req.fill_ids = req.fill_ids[: len(req.prefix_indices) + n]
+                req.extend_input_len = n
+                req.is_chunked += 1
+                self.chunked_req = req
+            elif n > rem_input and can_run:
+                return False
+            can_run.append(req)
+            rem_total -= need_all
+            rem_input -= n
+            if rem_chunk is not None:
+                rem_chunk -= n
+            return True
+
+        if self.chunked_req is not None:
+            # the unfinished prompt goes first, carrying the slots it already owns as its prefix
+            req = self.chunked_req
+            self.chunked_req = None
+            done = req.already_computed
+            prefix = self.mr.req_to_token_pool.req_to_token[req.req_pool_idx, :done].clone()
+            self.mr.req_to_token_pool.free(req.req_pool_idx)   # prepare_for_extend allocates a row again
+            req.req_pool_idx = None
+            free_reqs += 1
+            rem_total += 0   # its slots are already allocated and stay allocated
+            if not take(req, prefix):
+                raise RuntimeError("no room to continue a chunked prefill")
+        while self.waiting_queue and self.chunked_req is None:
+            if len(can_run) >= free_reqs or len(can_run) + len(self.running_batch.reqs) >= self.max_running_requests:
+                break
+            if rem_input <= 0 or (rem_chunk is not None and rem_chunk <= 0):
+                break
+            if not take(self.waiting_queue[0], None):
+                break
+            self.waiting_queue.pop(0)
+        if not can_run:
+            return None
+        batch = self._new_batch(can_run)
+        batch.prepare_for_extend()
+        return batch
+
+    # ---- one iteration of the event loop ----
+    def get_next_batch_to_run(self) -> Optional[ScheduleBatch]:
+        new_batch = self.get_new_batch_prefill()
+        if new_batch is not None:
+            return new_batch
+        if self.running_batch.is_empty():
+            return None
+        self.running_batch.prepare_for_decode()
+        return self.running_batch
+
+    @torch.no_grad()
+    def run_batch(self, batch: ScheduleBatch) -> torch.Tensor:
+        fb = ForwardBatch.init_new(batch.get_model_worker_batch(), self.mr)
+        logits_output, _ = self.mr.forward(fb)
+        return self.mr.sample(logits_output, fb)
+
+    def _check_finished(self, req: Req) -> None:
+        if len(req.output_ids) >= req.sampling_params.max_new_tokens:
+            req.finished = True
+        elif (self.eos_token_id is not None and not req.sampling_params.ignore_eos
+              and req.output_ids and req.output_ids[-1] == self.eos_token_id):
+            req.finished = True
+
+    def _release(self, req: Req, seq_len: int) -> None:
+        pool = self.mr.req_to_token_pool
+        slots = pool.req_to_token[req.req_pool_idx, :seq_len].to(torch.int64)
+        self.mr.token_to_kv_pool_allocator.free(slots)
+        pool.free(req.req_pool_idx)
+        req.req_pool_idx = None
+        self.finished[req.rid] = req
+
+    def process_batch_result(self, batch: ScheduleBatch, next_token_ids: torch.Tensor) -> None:
+        ids = next_token_ids.tolist()
+        if batch.forward_mode.is_extend():
+            self.num_prefill_batches += 1
+            keep = []
+            for i, (req, tok) in enumerate(zip(batch.reqs, ids)):
+                if req.is_chunked > 0 and req is self.chunked_req:
+                    continue   # mid-prompt: the sampled token is meaningless (scheduler_output_processor_mixin)
+                req.is_chunked = 0
+                req.output_ids.append(tok)
+                self._check_finished(req)
+                if req.finished:
+                    self._release(req, batch.seq_lens_cpu_list[i])
+                else:
+                    keep.append(i)
+            batch.output_ids = next_token_ids.to(torch.int64)
+            batch.filter_batch(keep_indices=keep)
+            if not batch.is_empty():
+                self.running_batch.merge_batch(batch)
+        else:
+            self.num_decode_steps += 1
+            keep = []
+            for i, (req, tok) in enumerate(zip(batch.reqs, ids)):
+                req.output_ids.append(tok)
+                self._check_finished(req)
+                if req.finished:
+                    self._release(req, batch.seq_lens_cpu_list[i])
+                else:
+                    keep.append(i)
+            batch.output_ids = next_token_ids.to(torch.int64)
+            batch.filter_batch(keep_indices=keep)
+
+    def step(self) -> bool:
+        batch = self.get_next_batch_to_run()
+        if batch is None:
+            return False
+        self.process_batch_result(batch, self.run_batch(batch))
+        return True
+
+    def run_until_done(self, max_iters: int = 1 << 30) -> Dict[object, Req]:
+        it = 0
+        while (self.waiting_queue or self.chunked_req is not None or not self.running_batch.is_empty()) and it < max_iters:
+            if not self.step():
+                raise RuntimeError("scheduler stalled: a waiting request does not fit the KV pool")
+            it += 1
+        return self.finished

@@ -35,3 +35,19 @@ class SamplingBatchInfo:
     @classmethod
     def from_schedule_batch(cls, batch, vocab_size: int) -> "SamplingBatchInfo":
         return cls.from_reqs(batch.reqs, vocab_size, batch.device)
+
+    def filter_batch(self, keep_indices: List[int], keep_indices_device: torch.Tensor) -> None:
+        """Keep the rows of the surviving requests (sampling_batch_info.py filter_batch)."""
+        self.temperatures = self.temperatures[keep_indices_device]
+        self.top_ps = self.top_ps[keep_indices_device]
+        self.top_ks = self.top_ks[keep_indices_device]
+        self.min_ps = self.min_ps[keep_indices_device]
+
+    def merge_batch(self, other: "SamplingBatchInfo") -> None:
+        """Append another batch's rows (sampling_batch_info.py merge_batch)."""
+        self.temperatures = torch.cat([self.temperatures, other.temperatures])
+        self.top_ps = torch.cat([self.top_ps, other.top_ps])
+        self.top_ks = torch.cat([self.top_ks, other.top_ks])
+        self.min_ps = torch.cat([self.min_ps, other.min_ps])
+        self.is_all_greedy = self.is_all_greedy and other.is_all_greedy
+        self.need_min_p_sampling = self.need_min_p_sampling or other.need_min_p_sampling

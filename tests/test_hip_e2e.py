@@ -156,3 +156,44 @@ def test_sampler_nongreedy_runs_in_kept_set():
     for _ in range(10):
         ids = sampler(LogitsProcessorOutput(next_token_logits=logits.clone().cuda()), info).cpu()
         assert (dist.gather(1, ids.long()[:, None]) > 0).all()
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_continuous_batching_on_gpu_matches_isolated_generation(graphs):
+    """Scheduler-driven run (staggered arrivals, 16-token prefill chunks, a KV pool that cannot hold
+    every request at once, decode batches that shrink and grow under HIP-graph padding): each
+    request's fp32 greedy tokens equal the oracle's for that prompt alone."""
+    from oracle.llama_ref import OracleLlama
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.managers.scheduler import Scheduler
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.sampling.sampling_params import SamplingParams
+    from sglang_custom_amd.server_args import ServerArgs
+
+    cfg = hf_config_dict("tiny-llama-d64", "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    sa = ServerArgs(dtype="float32", max_total_tokens=160, max_running_requests=4, disable_cuda_graph=not graphs,
+                    cuda_graph_bs=[1, 2, 4], chunked_prefill_size=16, max_prefill_tokens=64)
+    mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights={k: v.cuda() for k, v in w.items()})
+    rng = np.random.RandomState(3)
+    spec = [(5, 6), (40, 3), (17, 9), (33, 1), (70, 4), (9, 12), (24, 5)]
+    reqs = [Req(i, rng.randint(0, cfg["vocab_size"], n).tolist(), SamplingParams(max_new_tokens=m, temperature=0))
+            for i, (n, m) in enumerate(spec)]
+    sch = Scheduler(mr)
+    for r in reqs[:3]:
+        sch.add_request(r)
+    arrivals = {2: reqs[3], 4: reqs[4], 5: reqs[5], 9: reqs[6]}
+    it = 0
+    while sch.waiting_queue or sch.chunked_req is not None or not sch.running_batch.is_empty() or arrivals:
+        if it in arrivals:
+            sch.add_request(arrivals.pop(it))
+        assert sch.step() or arrivals
+        it += 1
+        assert it < 500
+    assert len(sch.finished) == len(reqs)
+    assert mr.token_to_kv_pool_allocator.available_size() == mr.max_total_num_tokens
+    oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
+    for r, (n, m) in zip(reqs, spec):
+        ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
+        assert r.output_ids == ref_toks[0].tolist(), (r.rid, graphs)
