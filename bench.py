@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--quantization", default=None, choices=[None, "w8a8_fp8"])
     ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--simulate-tp", type=int, default=0,
+                    help="measurement aid (not the contract metric): run ONE rank's shard of a TP=N "
+                         "configuration on one GPU with the collectives stubbed out")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -201,6 +204,9 @@ def main():
 
     torch.cuda.set_device(local_rank)
     tp = world if (args.parallelism == "tp" and world > 1) else 1
+    sim = args.simulate_tp if (args.simulate_tp > 1 and world == 1) else 0
+    if sim:
+        tp = sim
     if world > 1 and tp == 1:
         dist.init_process_group("nccl", world_size=world, rank=rank,
                                 device_id=torch.device(f"cuda:{local_rank}"))
@@ -210,7 +216,8 @@ def main():
     sa = ServerArgs(dtype=args.dtype, max_total_tokens=bs * (in_len + out_len + 8) + 64,
                     max_running_requests=max(bs, 8) + 8, context_length=in_len + out_len + 16,
                     disable_cuda_graph=args.no_graph, cuda_graph_bs=[bs], tp_size=tp,
-                    quantization=args.quantization, random_seed=rank if tp == 1 else 0)
+                    quantization=args.quantization, random_seed=rank if tp == 1 else 0,
+                    simulate_tp_shard=bool(sim))
     mc = ModelConfig(cfg, dtype=args.dtype, context_length=in_len + out_len + 16)
     graph_ok = True
     try:
@@ -271,7 +278,8 @@ def main():
     step_gbs = bytes_step / (ms_per_step * 1e-3) / 1e9
 
     out = {
-        "metric": "decode output tok/s (Llama-3-8B bf16 TP=1, bs=64, 1024-in) + p50 TTFT",
+        "metric": ("per-GPU kernel time of one simulated TP shard (diagnostic)" if sim else
+                   "decode output tok/s (Llama-3-8B bf16 TP=1, bs=64, 1024-in) + p50 TTFT"),
         "value": round(value, 1), "unit": "tok/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None,
@@ -281,7 +289,8 @@ def main():
         "config": {"workload": f"{args.model} {args.dtype} decode, static batch {bs}, {in_len}-token prompts, "
                                f"greedy, context {in_len + args.warmup}..{in_len + args.warmup + args.steps}",
                    "global_batch": bs * replicas, "seq_len": in_len,
-                   "parallelism": f"tp{tp}" if tp > 1 else (f"dp{world}" if world > 1 else "tp1"),
+                   "parallelism": (f"ONE shard of tp{tp}, collectives stubbed (not a job-level number)" if sim else
+                                   f"tp{tp}" if tp > 1 else (f"dp{world}" if world > 1 else "tp1")),
                    "hip_graph": bool(graph_ok)},
         "ttft_p50_ms": round(ttft * 1e3, 2),
         "prefill_tok_s": round(bs * in_len / ttft, 1),

@@ -30,6 +30,18 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: st
     _TP_GROUP = dist.group.WORLD
 
 
+_SIMULATED = False
+
+
+def init_simulated_shard(world_size: int, rank: int = 0) -> None:
+    """Measurement aid: build ONE rank's tensor-parallel shard on one GPU with no process group.
+    The collectives become local stand-ins of the same output shape (all-reduce: identity,
+    all-gather: the local shard repeated), so per-GPU kernel time of a TP configuration can be
+    measured without the other ranks.  Results are NOT the model's outputs."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _SIMULATED
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _SIMULATED = None, rank, world_size, True
+
+
 def destroy_model_parallel() -> None:
     global _TP_GROUP, _TP_RANK, _TP_SIZE
     _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
@@ -49,7 +61,7 @@ def get_tp_group() -> Optional[dist.ProcessGroup]:
 
 def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group (communication_op.py:11-13)."""
-    if _TP_SIZE == 1:
+    if _TP_SIZE == 1 or _SIMULATED:
         return x
     dist.all_reduce(x, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return x
@@ -61,6 +73,8 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
         return x
     if dim < 0:
         dim += x.dim()
+    if _SIMULATED:
+        return torch.cat([x] * _TP_SIZE, dim=dim)
     x = x.contiguous()
     # rank-major concatenation along dim 0: the one output layout every backend accepts
     out = torch.empty((_TP_SIZE * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)

@@ -63,6 +63,9 @@ class ModelRunner:
         if self.tp_size == 1:
             parallel_state.init_distributed_environment(1, 0)
             return
+        if getattr(self.server_args, "simulate_tp_shard", False):
+            parallel_state.init_simulated_shard(self.tp_size, self.tp_rank)
+            return
         backend = self.server_args.dist_backend or (
             "nccl" if str(self.device).startswith("cuda") else "gloo")
         parallel_state.init_distributed_environment(self.tp_size, self.tp_rank, backend,

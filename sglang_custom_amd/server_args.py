@@ -21,6 +21,7 @@ class ServerArgs:
     cuda_graph_max_bs: int = 64
     cuda_graph_bs: Optional[list] = None
     random_seed: int = 0
+    simulate_tp_shard: bool = False             # measurement aid: one TP rank, collectives stubbed
     chunked_prefill_size: Optional[int] = None   # None / -1: prompts are never split
     max_prefill_tokens: int = 16384
     dist_backend: Optional[str] = None          # default: nccl (RCCL) on GPU, gloo on CPU
