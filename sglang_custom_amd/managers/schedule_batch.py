@@ -37,6 +37,7 @@ class Req:
         self.cached_tokens = 0
         self.already_computed = 0
         self.finished = False
+        self.last_node = None   # radix-tree node its cached prefix ends in (locked while the request runs)
         self.is_chunked = 0   # > 0 while a prompt is being prefilled in chunks (schedule_batch.py Req.is_chunked)
 
     def init_next_round_input(self, prefix_indices=None):

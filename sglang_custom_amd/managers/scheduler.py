@@ -10,19 +10,26 @@ still generate, max_prefill_tokens per prefill batch, chunked_prefill_size per c
 prefill of long prompts (the unfinished request keeps its KV slots and re-enters the next prefill
 batch with them as its prefix), prefill-first policy, merge of prefilled requests into the running
 decode batch, per-step retirement of finished requests with slot release.
-Left out on purpose: the radix prefix cache, retraction under memory pressure (admission is
-conservative instead), mixed prefill+decode batches, priorities, streaming, the IPC around it."""
+Optional radix prefix cache (mem_cache/radix_cache.py): new requests start from the longest cached
+prefix (its slots become prefix_indices of the extend), finished and chunk-boundary requests hand
+their KV to the tree, and tree leaves are evicted LRU-first when the allocator runs short.
+Left out on purpose: retraction under memory pressure (admission is conservative instead), mixed
+prefill+decode batches, priorities, streaming, the IPC around it."""
 from typing import Dict, List, Optional
 
 import torch
 
+from ..mem_cache.radix_cache import RadixCache
 from ..model_executor.forward_batch_info import ForwardBatch
 from .schedule_batch import Req, ScheduleBatch
 
 
 class Scheduler:
-    def __init__(self, model_runner, eos_token_id: Optional[int] = None):
+    def __init__(self, model_runner, eos_token_id: Optional[int] = None, enable_radix_cache: bool = False):
         self.mr = model_runner
+        self.tree_cache = RadixCache(model_runner.req_to_token_pool, model_runner.token_to_kv_pool_allocator,
+                                     disable=not enable_radix_cache)
+        self.cached_prefix_tokens = 0
         sa = model_runner.server_args
         self.eos_token_id = eos_token_id
         self.max_running_requests = model_runner.req_to_token_pool.size
@@ -35,6 +42,7 @@ class Scheduler:
         self.finished: Dict[object, Req] = {}
         self.num_prefill_batches = 0
         self.num_decode_steps = 0
+        self.evicted_tokens = 0
 
     # ---- queue ----
     def add_request(self, req: Req) -> None:
@@ -58,7 +66,7 @@ class Scheduler:
         if not self.waiting_queue and self.chunked_req is None:
             return None
         alloc = self.mr.token_to_kv_pool_allocator
-        rem_total = alloc.available_size() - self._reserved_decode_tokens()
+        rem_total = alloc.available_size() + self.tree_cache.evictable_size() - self._reserved_decode_tokens()
         rem_input = self.max_prefill_tokens
         rem_chunk = self.chunked_prefill_size
         free_reqs = self.mr.req_to_token_pool.available_size()
@@ -67,22 +75,45 @@ class Scheduler:
         def take(req: Req, prefix) -> bool:
             """Admit req (whole, or its next chunk); returns False when the batch is full."""
             nonlocal rem_total, rem_input, rem_chunk
+            matched_node = None
+            if prefix is None and req.last_node is None:
+                # longest cached prefix, always leaving one token to compute (schedule_batch.py
+                # Req.init_next_round_input / adjust_max_prefix_ids)
+                key = req.origin_input_ids + req.output_ids
+                prefix, matched_node = self.tree_cache.match_prefix(key[:-1])
             req.init_next_round_input(prefix)
+            locked = 0
+            if matched_node is not None:
+                before = self.tree_cache.evictable_size()
+                self.tree_cache.inc_lock_ref(matched_node)   # its slots leave the evictable pool
+                locked = before - self.tree_cache.evictable_size()
+                rem_total -= locked
+
+            def refuse() -> bool:
+                nonlocal rem_total
+                if matched_node is not None:
+                    self.tree_cache.dec_lock_ref(matched_node)
+                    rem_total += locked
+                req.init_next_round_input(None)
+                return False
+
             need_all = req.extend_input_len + req.sampling_params.max_new_tokens - len(req.output_ids)
             if need_all > rem_total:
-                return False
+                return refuse()
             n = req.extend_input_len
-            if rem_chunk is not None and n > rem_chunk:
-                if rem_chunk <= 0:
-                    return False
+            truncate = rem_chunk is not None and n > rem_chunk
+            if (truncate and rem_chunk <= 0) or (not truncate and n > rem_input and can_run):
+                return refuse()
+            if matched_node is not None:
+                req.last_node = matched_node
+                self.cached_prefix_tokens += len(prefix)
+            if truncate:
                 # truncate to the chunk budget (add_chunked_req / add_one_req trunc_len)
                 n = rem_chunk
                 req.fill_ids = req.fill_ids[: len(req.prefix_indices) + n]
                 req.extend_input_len = n
                 req.is_chunked += 1
                 self.chunked_req = req
-            elif n > rem_input and can_run:
-                return False
             can_run.append(req)
             rem_total -= need_all
             rem_input -= n
@@ -112,9 +143,16 @@ class Scheduler:
             self.waiting_queue.pop(0)
         if not can_run:
             return None
+        self._make_room(sum(r.extend_input_len for r in can_run))
         batch = self._new_batch(can_run)
         batch.prepare_for_extend()
         return batch
+
+    def _make_room(self, need: int) -> None:
+        """Evict least-recently-used cached prefixes when the allocator alone cannot serve `need`."""
+        short = need - self.mr.token_to_kv_pool_allocator.available_size()
+        if short > 0:
+            self.evicted_tokens += self.tree_cache.evict(short)
 
     # ---- one iteration of the event loop ----
     def get_next_batch_to_run(self) -> Optional[ScheduleBatch]:
@@ -123,6 +161,7 @@ class Scheduler:
             return new_batch
         if self.running_batch.is_empty():
             return None
+        self._make_room(len(self.running_batch.reqs))
         self.running_batch.prepare_for_decode()
         return self.running_batch
 
@@ -140,11 +179,16 @@ class Scheduler:
             req.finished = True
 
     def _release(self, req: Req, seq_len: int) -> None:
-        pool = self.mr.req_to_token_pool
-        slots = pool.req_to_token[req.req_pool_idx, :seq_len].to(torch.int64)
-        self.mr.token_to_kv_pool_allocator.free(slots)
-        pool.free(req.req_pool_idx)
+        if not self.tree_cache.disable:
+            assert seq_len == len(req.origin_input_ids) + len(req.output_ids) - 1
+            self.tree_cache.cache_finished_req(req)
+        else:
+            pool = self.mr.req_to_token_pool
+            slots = pool.req_to_token[req.req_pool_idx, :seq_len].to(torch.int64)
+            self.mr.token_to_kv_pool_allocator.free(slots)
+            pool.free(req.req_pool_idx)
         req.req_pool_idx = None
+        req.last_node = None
         self.finished[req.rid] = req
 
     def process_batch_result(self, batch: ScheduleBatch, next_token_ids: torch.Tensor) -> None:
@@ -154,7 +198,10 @@ class Scheduler:
             keep = []
             for i, (req, tok) in enumerate(zip(batch.reqs, ids)):
                 if req.is_chunked > 0 and req is self.chunked_req:
-                    continue   # mid-prompt: the sampled token is meaningless (scheduler_output_processor_mixin)
+                    # mid-prompt: the sampled token is meaningless (scheduler_output_processor_mixin);
+                    # what is computed so far goes to the tree
+                    self.tree_cache.cache_unfinished_req(req)
+                    continue
                 req.is_chunked = 0
                 req.output_ids.append(tok)
                 self._check_finished(req)

@@ -197,3 +197,51 @@ def test_continuous_batching_on_gpu_matches_isolated_generation(graphs):
     for r, (n, m) in zip(reqs, spec):
         ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
         assert r.output_ids == ref_toks[0].tolist(), (r.rid, graphs)
+
+
+@pytest.mark.gpu
+def test_radix_prefix_cache_on_gpu_matches_isolated_generation():
+    """Shared-prefix requests through the scheduler with the prefix tree on: later requests run
+    extend-with-prefix over slots an earlier request wrote, eviction runs under a 120-slot pool,
+    and each request's fp32 greedy tokens equal the oracle's for that prompt alone."""
+    from oracle.llama_ref import OracleLlama
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.managers.scheduler import Scheduler
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.sampling.sampling_params import SamplingParams
+    from sglang_custom_amd.server_args import ServerArgs
+
+    cfg = hf_config_dict("tiny-llama-d64", "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    sa = ServerArgs(dtype="float32", max_total_tokens=120, max_running_requests=4, cuda_graph_bs=[1, 2, 4],
+                    chunked_prefill_size=32, max_prefill_tokens=64)
+    mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights={k: v.cuda() for k, v in w.items()})
+    rng = np.random.RandomState(5)
+    V = cfg["vocab_size"]
+    sys_prompt = rng.randint(0, V, 40).tolist()
+    other = rng.randint(0, V, 45).tolist()
+    prompts = [sys_prompt + rng.randint(0, V, 7).tolist(), sys_prompt + rng.randint(0, V, 12).tolist(), other,
+               sys_prompt[:25] + rng.randint(0, V, 9).tolist(), sys_prompt + rng.randint(0, V, 3).tolist(),
+               other + rng.randint(0, V, 5).tolist()]
+    new_tokens = [5, 4, 6, 3, 8, 4]
+    reqs = [Req(i, p, SamplingParams(max_new_tokens=m, temperature=0)) for i, (p, m) in enumerate(zip(prompts, new_tokens))]
+    sch = Scheduler(mr, enable_radix_cache=True)
+    sch.add_request(reqs[0])
+    arrivals = {3: reqs[1], 4: reqs[2], 9: reqs[3], 14: reqs[4], 22: reqs[5]}
+    it = 0
+    while sch.waiting_queue or sch.chunked_req is not None or not sch.running_batch.is_empty() or arrivals:
+        if it in arrivals:
+            sch.add_request(arrivals.pop(it))
+        assert sch.step() or arrivals
+        it += 1
+        assert it < 500
+    assert len(sch.finished) == len(reqs)
+    assert sch.cached_prefix_tokens >= 40 + 25 and sch.evicted_tokens > 0
+    tree, alloc = sch.tree_cache, mr.token_to_kv_pool_allocator
+    assert alloc.available_size() + tree.total_size() == mr.max_total_num_tokens
+    assert tree.protected_size() == 0
+    oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
+    for r, m in zip(reqs, new_tokens):
+        ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
+        assert r.output_ids == ref_toks[0].tolist(), r.rid

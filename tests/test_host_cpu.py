@@ -171,3 +171,96 @@ def test_continuous_batching_scheduler_matches_isolated_generation():
                     disable_cuda_graph=True, chunked_prefill_size=16, max_prefill_tokens=64)
     mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights=w)
     _scheduler_case(mr, cfg, w, torch.float32, 1e-4)
+
+
+def test_radix_cache_tree_semantics():
+    """match / insert / split / lock / LRU eviction of the prefix tree, on a fake allocator."""
+    from sglang_custom_amd.mem_cache.radix_cache import RadixCache
+
+    class Alloc:
+        device = "cpu"
+
+        def __init__(self):
+            self.freed = []
+
+        def free(self, idx):
+            self.freed.extend(idx.tolist())
+
+    alloc = Alloc()
+    tree = RadixCache(req_to_token_pool=None, token_to_kv_pool_allocator=alloc)
+    a = [1, 2, 3, 4, 5, 6]
+    assert tree.insert(a, torch.arange(10, 16)) == 0
+    v, node = tree.match_prefix([1, 2, 3, 9])
+    assert v.tolist() == [10, 11, 12] and node.key == [1, 2, 3]          # node split at the match
+    assert tree.insert([1, 2, 3, 7, 8], torch.tensor([90, 91, 92, 17, 18])) == 3   # 3 duplicates reported
+    assert tree.total_size() == 8 and tree.evictable_size() == 8
+    v, leaf = tree.match_prefix([1, 2, 3, 7, 8])
+    assert v.tolist() == [10, 11, 12, 17, 18]
+    tree.inc_lock_ref(leaf)
+    assert tree.evictable_size() == 3 and tree.protected_size() == 5
+    assert tree.evict(100) == 3 and sorted(alloc.freed) == [13, 14, 15]   # only the unlocked branch goes
+    tree.dec_lock_ref(leaf)
+    assert tree.evictable_size() == 5
+    assert tree.evict(1) == 2 and sorted(alloc.freed)[-2:] == [17, 18]    # leaf first, parent stays
+    assert tree.evict(100) == 3 and tree.total_size() == 0
+    assert tree.match_prefix([1, 2])[0].numel() == 0
+
+
+def test_scheduler_with_radix_prefix_cache_matches_isolated_generation():
+    """Requests that share prompt prefixes, arriving after earlier ones finished or mid-run: the
+    cached slots are reused (extend with prefix), outputs equal the oracle's for each prompt
+    alone, every slot is either free or owned by the tree at the end, and a pool that is too
+    small for everything forces LRU eviction."""
+    import cpu_ops
+    from oracle.llama_ref import OracleLlama
+    from sglang_custom_amd import ops_backend
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.managers.scheduler import Scheduler
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+    from sglang_custom_amd.sampling.sampling_params import SamplingParams
+    from sglang_custom_amd.server_args import ServerArgs
+
+    ops_backend.set_ops_backend(cpu_ops)
+    cfg = hf_config_dict("tiny-llama-d64", "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    sa = ServerArgs(dtype="float32", device="cpu", max_total_tokens=120, max_running_requests=4,
+                    disable_cuda_graph=True, chunked_prefill_size=32, max_prefill_tokens=64)
+    mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights=w)
+    rng = np.random.RandomState(5)
+    sys_prompt = rng.randint(0, cfg["vocab_size"], 40).tolist()
+    other = rng.randint(0, cfg["vocab_size"], 45).tolist()
+    prompts = [sys_prompt + rng.randint(0, cfg["vocab_size"], 7).tolist(),
+               sys_prompt + rng.randint(0, cfg["vocab_size"], 12).tolist(),
+               other,
+               sys_prompt[:25] + rng.randint(0, cfg["vocab_size"], 9).tolist(),
+               sys_prompt + rng.randint(0, cfg["vocab_size"], 3).tolist(),
+               other + rng.randint(0, cfg["vocab_size"], 5).tolist()]
+    new_tokens = [5, 4, 6, 3, 8, 4]
+    reqs = [Req(i, p, SamplingParams(max_new_tokens=m, temperature=0)) for i, (p, m) in enumerate(zip(prompts, new_tokens))]
+    sch = Scheduler(mr, enable_radix_cache=True)
+    sch.add_request(reqs[0])
+    arrivals = {3: reqs[1], 4: reqs[2], 9: reqs[3], 14: reqs[4], 22: reqs[5]}
+    it = 0
+    while sch.waiting_queue or sch.chunked_req is not None or not sch.running_batch.is_empty() or arrivals:
+        if it in arrivals:
+            sch.add_request(arrivals.pop(it))
+        assert sch.step() or arrivals
+        it += 1
+        assert it < 500
+    assert len(sch.finished) == len(reqs)
+    assert sch.cached_prefix_tokens >= 40 + 25          # at least the shared system prompt was reused
+    assert sch.evicted_tokens > 0                       # 120 slots do not hold every prompt: LRU eviction ran
+    tree, alloc = sch.tree_cache, mr.token_to_kv_pool_allocator
+    assert alloc.available_size() + tree.total_size() == mr.max_total_num_tokens
+    assert tree.protected_size() == 0 and tree.evictable_size() == tree.total_size()
+    assert mr.req_to_token_pool.available_size() == mr.req_to_token_pool.size
+    oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
+    for r, m in zip(reqs, new_tokens):
+        ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
+        assert r.output_ids == ref_toks[0].tolist(), (r.rid, r.output_ids, ref_toks[0].tolist())
+    # everything the tree holds can be evicted back to the allocator
+    held = tree.total_size()
+    assert tree.evict(10 ** 9) == held
+    assert alloc.available_size() == mr.max_total_num_tokens and tree.total_size() == 0
