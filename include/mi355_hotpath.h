@@ -55,6 +55,17 @@ int mi355_rmsnorm(void* out, const void* x, const void* weight, int64_t rows, in
 int mi355_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t rows,
                             int64_t hidden, float eps, int dtype, void* stream);
 
+/* L2 warm-up hint.  Row-norm and RoPE launches leave HBM idle; the next such launch made by the
+ * calling thread (mi355_rmsnorm, mi355_fused_add_rmsnorm, mi355_rope_inplace) carries extra
+ * workgroups that read the first budget_bytes of the packed weight image w_packed into L2, laid
+ * out the way the skinny GEMM y[m, n] = x[m, k] W^T (mi355_linear_packed, *_silu_mul,
+ * mi355_fp8_scaled_mm_packed; w_elem_bytes 2 or 1) will ask for them, so that GEMM starts on L2
+ * hits.  Loads only: results never change.  w_packed == NULL cancels a pending hint; a shape the
+ * ring GEMM does not serve is ignored.  No counterpart in the reference (weights there are read
+ * cold by every GEMM). */
+int mi355_prefetch_next(const void* w_packed, int64_t m, int64_t n, int64_t k, int w_elem_bytes,
+                        int64_t budget_bytes);
+
 /* ---- K10 SiLU-and-mul -------------------------------------------------------------------
  * out[r, j] = T( f32(T(silu(x[r, j]))) * x[r, d + j] ), x is [rows, 2d] contiguous.
  * replaces: SiluAndMul.forward_native/forward_cuda (python/sglang/srt/layers/activation.py:55-65),
@@ -234,6 +245,8 @@ void mi355_debug_set(int key, int value);
 /* Read-bandwidth probe (development only): streams `bytes` from src with `grid` workgroups. */
 int mi355_debug_read_bw(const void* src, int64_t bytes, int grid, int unroll, void* sink,
                         void* stream);
+/* Development aid: out[wg] = XCD the workgroup ran on, for a 1-D grid of `grid` workgroups. */
+int mi355_debug_xcc_map(void* out, int grid, void* stream);
 
 /* ---- K14 fp8 W8A8 ------------------------------------------------------------------------------
  * Per-token dynamic quantisation to OCP e4m3fn (max 448): s[r] = max(absmax(x[r,:]), 1e-10)/448,

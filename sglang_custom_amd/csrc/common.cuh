@@ -103,6 +103,48 @@ __host__ __device__ static inline bool aligned16(const void* p) { return (reinte
       return MI355_ERR_UNSUPPORTED;                                          \
   }
 
+// ---- L2 warm-up of the next GEMM's packed weights --------------------------------------------
+// A kernel that leaves HBM idle (row norms, RoPE: tens of KB of traffic) can carry extra
+// workgroups that pull the head of the NEXT skinny GEMM's weight stream into L2.  L2 contents
+// survive the kernel boundary, and workgroup p of the warm-up lands on the same XCD as workgroup
+// p of the GEMM (both are dispatched round-robin from workgroup 0), so each XCD's L2 holds exactly
+// the bytes its GEMM workgroups ask for first.  Geometry is the GEMM planner's own.
+struct WeightPrefetch {
+  const char* base;       // packed weight image ([64-row group][k step][4 tiles][64 lanes][16 B])
+  int nblocks, splits;    // the GEMM's grid
+  int tiles_per_wg;       // 16-row tiles per workgroup
+  int ntiles;             // tiles in the image
+  int ksteps_total;       // K / (elements per fragment row)
+  int ksteps_per_split;
+  int pf_steps;           // k steps warmed per workgroup (0 = nothing to do)
+};
+bool plan_weight_prefetch(const void* w_packed, int64_t m, int64_t n, int64_t k16, int64_t budget_bytes,
+                          WeightPrefetch* out);
+
+// Called by all 256 threads of warm-up workgroup p.  Loads only; the xor keeps them alive.
+__device__ __forceinline__ void prefetch_weights(const WeightPrefetch& d, int p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bx = p % d.nblocks, by = p / d.nblocks;
+  const int t0 = bx * d.tiles_per_wg, s0 = by * d.ksteps_per_split;
+  const int pieces = d.tiles_per_wg * d.pf_steps;     // 1-KiB pieces: (k step, tile)
+  unsigned acc = 0;
+  constexpr int U = 8;
+  for (int i0 = wave; i0 < pieces; i0 += 4 * U) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + 4 * u, pieces - 1);
+      const int tile = min(t0 + i % d.tiles_per_wg, d.ntiles - 1);
+      const int step = min(s0 + i / d.tiles_per_wg, d.ksteps_total - 1);
+      const char* src = d.base + (((int64_t)(tile >> 2) * d.ksteps_total + step) * 4 + (tile & 3)) * 1024 + lane * 16;
+      v[u] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+  }
+  asm volatile("" ::"v"(acc));
+}
+
 // silu(a) * b with the rounding points of F.silu(a) * b on dtype T (layers/activation.py:55-58).
 template <typename T> __device__ __forceinline__ T silu_mul_one(T a, T b) {
   const float x = to_f32(a);

@@ -25,7 +25,18 @@ __global__ __launch_bounds__(256) void read_bw_kernel(const uint4* __restrict__ 
   if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive
 }
 
+// Which XCD each workgroup runs on (hardware register XCC_ID, low 4 bits).
+__global__ void xcc_map_kernel(int* __restrict__ out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15);
+}
+
 }  // namespace mi355
+
+extern "C" int mi355_debug_xcc_map(void* out, int grid, void* stream) {
+  hipLaunchKernelGGL(mi355::xcc_map_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (int*)out);
+  MI355_CHECK_LAUNCH("debug_xcc_map");
+  return MI355_OK;
+}
 
 extern "C" int mi355_debug_read_bw(const void* src, int64_t bytes, int grid, int unroll, void* sink,
                                    void* stream) {

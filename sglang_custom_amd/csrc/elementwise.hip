@@ -15,6 +15,17 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+// Pending L2 warm-up (mi355_prefetch_next): taken by the next launch that can carry it.
+static thread_local WeightPrefetch g_pf;
+static thread_local bool g_pf_pending = false;
+static int take_prefetch(WeightPrefetch* d) {
+  d->pf_steps = 0;
+  if (!g_pf_pending) return 0;
+  g_pf_pending = false;
+  *d = g_pf;
+  return d->nblocks * d->splits;
+}
+
 // ------------------------------------------------------------------------------------------
 // RMSNorm.  One workgroup per row.  The row is held in registers between the sum-of-squares
 // pass and the scale pass when it fits (CHUNKS vectors per thread), so HBM sees each element
@@ -25,10 +36,14 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
                                                           T* __restrict__ residual,
                                                           const T* __restrict__ w, int64_t hidden,
                                                           int64_t x_stride, int64_t out_stride,
-                                                          float eps) {
+                                                          float eps, WeightPrefetch pf, int pf_wgs) {
   constexpr int VE = V16<T>::n;
   __shared__ float red[16];
-  const int64_t row = blockIdx.x;
+  if ((int)blockIdx.x < pf_wgs) {   // warm-up riders come first so they keep the GEMM's XCD mapping
+    prefetch_weights(pf, blockIdx.x);
+    return;
+  }
+  const int64_t row = blockIdx.x - pf_wgs;
   T* xr = x + row * x_stride;
   T* rr = ADD ? residual + row * hidden : nullptr;
   T* orow = out + row * out_stride;
@@ -131,9 +146,12 @@ static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, i
   dim3 grid((unsigned)rows), block(256);
   if (vec_ok && nvec <= 256 * 8) {
     const int chunks = (int)((nvec + 255) / 256);
+    WeightPrefetch pf;
+    const int pf_wgs = take_prefetch(&pf);
+    grid.x += pf_wgs;
 #define LAUNCH(C)                                                                              \
   hipLaunchKernelGGL((rmsnorm_vec_kernel<T, ADD, C>), grid, block, 0, st, out, x, residual, w, \
-                     hidden, x_stride, out_stride, eps)
+                     hidden, x_stride, out_stride, eps, pf, pf_wgs)
     if (chunks <= 1) LAUNCH(1);
     else if (chunks <= 2) LAUNCH(2);
     else if (chunks <= 4) LAUNCH(4);
@@ -377,6 +395,17 @@ extern "C" {
 
 int mi355_abi_version(void) { return MI355_ABI_VERSION; }
 const char* mi355_last_error(void) { return mi355::get_error(); }
+
+int mi355_prefetch_next(const void* w_packed, int64_t m, int64_t n, int64_t k, int w_elem_bytes,
+                        int64_t budget_bytes) {
+  g_pf_pending = false;
+  if (!w_packed) return MI355_OK;
+  MI355_REQUIRE(w_elem_bytes == 2 || w_elem_bytes == 1, MI355_ERR_UNSUPPORTED,
+                "prefetch_next: packed weights are 16-bit or fp8 (w_elem_bytes 2 or 1)");
+  const int64_t k16 = w_elem_bytes == 1 ? k / 2 : k;
+  g_pf_pending = plan_weight_prefetch(w_packed, m, n, k16, budget_bytes, &g_pf);
+  return MI355_OK;
+}
 
 int mi355_rmsnorm(void* out, const void* x, const void* weight, int64_t rows, int64_t hidden,
                   int64_t x_row_stride, int64_t out_row_stride, float eps, int dtype,

@@ -595,6 +595,30 @@ static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k, bool ring) {
   return p;
 }
 
+// Warm-up geometry for the packed GEMM y[m, n] over k16 16-bit-equivalent K elements (an fp8
+// weight counts K / 2): the first `budget_bytes` of the weight stream, spread evenly over the
+// workgroups the GEMM will launch.  False when that GEMM does not run on the ring kernel.
+bool plan_weight_prefetch(const void* w_packed, int64_t m, int64_t n, int64_t k16, int64_t budget_bytes,
+                          WeightPrefetch* out) {
+  if (!w_packed || m < 1 || m > 64 || n < 1 || k16 < SK_BK || k16 % SK_BK != 0 || g_gemm_variant != 0 ||
+      n >= 64 * 1024 || budget_bytes <= 0)
+    return false;
+  const SkinnyPlan p = plan_skinny(m, n, k16, true);
+  // A split-K plan is bound by its latency chain (few chunks per workgroup, then the combine), not
+  // by the stream: warming it was measured to cost more in the carrier kernel than it returns.
+  if (p.nt != 1 || p.splits > 1 || p.nblocks > 4096) return false;
+  out->base = static_cast<const char*>(w_packed);
+  out->nblocks = (int)p.nblocks;
+  out->splits = p.splits;
+  out->tiles_per_wg = p.waves;
+  out->ntiles = (int)((n + 63) / 64 * 4);
+  out->ksteps_total = (int)(k16 / 32);
+  out->ksteps_per_split = p.k_per_split / 32;
+  const int64_t per_wg = budget_bytes / (p.nblocks * p.splits);
+  out->pf_steps = (int)std::min<int64_t>(out->ksteps_per_split, per_wg / (1024 * p.waves));
+  return out->pf_steps > 0;
+}
+
 static bool skinny_ok(int64_t m, int64_t n, int64_t k, int64_t x_stride, const void* x,
                       const void* w, int dtype) {
   return (dtype == MI355_BF16 || dtype == MI355_F16) && m >= 1 && m <= 64 && k % 8 == 0 &&

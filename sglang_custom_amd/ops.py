@@ -390,6 +390,14 @@ def linear_packed(x: torch.Tensor, weight_packed: torch.Tensor, n: int, bias: Op
     return y
 
 
+def prefetch_next(weight_packed: torch.Tensor, m: int, n: int, k: int, budget_bytes: int = 24 << 20) -> None:
+    """Hint: the next rmsnorm / fused_add_rmsnorm launch of this thread also pulls the head of this
+    packed weight into L2, in the order the M-row skinny GEMM over it will ask for it (24 MiB of the
+    32 MiB of L2 by default).  Results never change; shapes the hint does not serve are ignored."""
+    check(_lib_().mi355_prefetch_next(weight_packed.data_ptr(), m, n, k, weight_packed.element_size(),
+                                      budget_bytes), "prefetch_next")
+
+
 def pack_weight_gate_up(weight: torch.Tensor) -> torch.Tensor:
     """[2d, K] = [gate rows | up rows] -> packed copy for linear_packed_silu_mul: every 16-row MFMA
     tile holds 8 gate rows followed by the 8 up rows of the same output features."""

@@ -572,3 +572,30 @@ def test_errors_are_reported_not_thrown_by_the_library(ops):
                                    None, None, 1, 0.125)
     with pytest.raises(RuntimeError):
         ops.silu_and_mul(torch.randn(2, 8))  # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_prefetch_hint_rides_rmsnorm_without_changing_results(ops):
+    """mi355_prefetch_next: the next row-norm launch carries L2 warm-up workgroups for a packed
+    weight.  Outputs of the norm and of the GEMM behind it are bit-identical with and without the
+    hint, for served shapes, ignored shapes (split-K plans, K not a multiple of 256) and ragged N."""
+    torch.manual_seed(0)
+    for (m, n, k) in [(64, 28672, 4096), (7, 28672, 4096), (64, 4096, 4096), (16, 1200, 512), (3, 9000, 2048)]:
+        w = torch.randn(n, k, device="cuda", dtype=torch.bfloat16) * 0.05
+        wp = ops.pack_weight(w)
+        x = torch.randn(m, 4096, device="cuda", dtype=torch.bfloat16)
+        res = torch.randn_like(x)
+        g = torch.randn(4096, device="cuda", dtype=torch.bfloat16)
+        xin = torch.randn(m, k, device="cuda", dtype=torch.bfloat16)
+        x0, r0 = x.clone(), res.clone()
+        ops.fused_add_rmsnorm(x0, r0, g, 1e-5)
+        y0 = ops.linear_packed(xin, wp, n)
+        n0 = ops.rmsnorm(x, g, 1e-5)
+        x1, r1 = x.clone(), res.clone()
+        ops.prefetch_next(wp, m, n, k)
+        ops.fused_add_rmsnorm(x1, r1, g, 1e-5)
+        y1 = ops.linear_packed(xin, wp, n)
+        ops.prefetch_next(wp, m, n, k, budget_bytes=1 << 30)      # more than the weight holds: clamped
+        n1 = ops.rmsnorm(x, g, 1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(y0, y1) and torch.equal(n0, n1)
