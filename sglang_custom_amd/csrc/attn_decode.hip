@@ -519,6 +519,198 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const T* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// head_dim 128, 16-bit: Q.K^T AND P.V on the matrix cores.
+//
+// Scores as above: lane (g = l & 15, c = l >> 4) gets head g's scores of keys 4c..4c+3 of the
+// wave's 16-key tile.  That is exactly the B operand of v_mfma_f32_16x16x16 for O^T = V^T P^T
+// (B[k = key 4c + r][j = g]), so the probabilities go from the softmax straight into the next
+// MFMA with no cross-lane movement -- rounded to T first, as the reference's decode kernel does
+// (p.to(v.dtype) before the dot, triton_ops/decode_attention.py:135-140).  The A operand V^T
+// (lane (d, c): keys 4c..4c+3 of feature d) comes from the wave's own row-major LDS copy of the
+// V tile through transposed reads.  The softmax maximum is shared by the 16 keys of a tile (two
+// cross-lane max steps), which leaves ~80 vector instructions per 16 keys instead of ~250.
+// The accumulator holds O^T[d = 16 dt + 4c + r][g]; columns g >= G are padding.
+// ------------------------------------------------------------------------------------------
+constexpr int DV_ROW = 128 + 16;   // V tile row in LDS (elements): 288 B -> conflict-free transposed reads
+
+template <typename T, int G, bool CAP>
+__global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __restrict__ q,
+                                                                  const T* __restrict__ kbuf,
+                                                                  const T* __restrict__ vbuf,
+                                                                  T* __restrict__ o, DecodeParams p) {
+  constexpr int D = 128, VE = 8;
+  using frag = typename Mfma<T>::frag;
+  using frag4 = typename Mfma16<T>::frag;
+  __shared__ float sm_acc[4][G][D];
+  __shared__ float sm_m[4][G];
+  __shared__ float sm_l[4][G];
+  __shared__ __attribute__((aligned(16))) T sm_v[4][16 * DV_ROW];
+
+  const int gtotal = p.hq / p.hkv;
+  const int groups_per_kv = gtotal / G;
+  const int xrot = (blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x;
+  const int kvh = xrot / groups_per_kv;
+  const int head0 = kvh * gtotal + (xrot % groups_per_kv) * G;
+  const int split = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, c4 = lane >> 4;
+
+  int64_t page_off, len;
+  seq_range(p, b, page_off, len);
+  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t k0 = (int64_t)split * chunk;
+  const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
+  const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  frag qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (r16 < G) {
+      qf[s] = *reinterpret_cast<const frag*>(q + (int64_t)b * p.q_stride + (int64_t)(head0 + r16) * D + 32 * s + 8 * c4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
+    }
+  }
+
+  float m = -INFINITY;   // running maximum of head g = r16 (same in the four lanes c of a head)
+  float l = 0.f;         // this lane's share of the denominator (its keys 4c..4c+3 of every tile)
+  f32x4 acc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int32_t* pt = p.page_table + page_off;
+  const int64_t row_stride = (int64_t)p.hkv * D;
+  const T* kbase = kbuf + (int64_t)kvh * D + 8 * c4;     // + slot * row_stride + 32 s
+  const T* vbase = vbuf + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
+  const int64_t wave_first = k0 + (int64_t)wave * 16;
+  const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 63) / 64) : 0;
+  const int64_t last_key = len - 1;
+  T* v_wr = &sm_v[wave][(4 * c4) * DV_ROW + 8 * r16];                           // + u rows
+  const T* v_rd = &sm_v[wave][(4 * c4 + (r16 >> 2)) * DV_ROW + 4 * (r16 & 3)];  // + 16 dt
+
+  auto load_slots = [&](int it, int32_t& sk, int32_t (&sv)[4]) {
+    const int64_t tb = wave_first + (int64_t)it * 64;
+    int64_t key = tb + r16;
+    sk = pt[key < last_key ? key : last_key];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      key = tb + 4 * c4 + u;
+      sv[u] = pt[key < last_key ? key : last_key];
+    }
+  };
+
+  auto load_kv = [&](const int32_t& sk, const int32_t (&sv)[4], frag (&kf)[4], Vec<T, VE> (&vv)[4]) {
+    const T* krow = kbase + (int64_t)sk * row_stride;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)sv[u] * row_stride);
+  };
+  // One 16-key tile.  A tile past the end of the range is harmless: every key is masked, so the
+  // probabilities are zero and the rescale factor is one.
+  auto compute = [&](const frag (&kf)[4], const Vec<T, VE> (&vv)[4], int it) {
+    f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc = Mfma<T>::run(kf[s], qf[s], sc);
+
+    const int64_t kb0 = wave_first + (int64_t)it * 64 + 4 * c4;
+    float x[4], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = sc[r] * qmul;
+      if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
+      x[r] = kb0 + r < k1 ? v : -INFINITY;
+      mx = fmaxf(mx, x[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, m);
+    const float ms = safe_m(mx);
+    const float alpha = exp2f(m - ms);
+    float pr[4], psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = exp2f(x[r] - ms);
+      psum += pr[r];
+    }
+    l = l * alpha + psum;
+    m = mx;
+    T pt4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pt4[r] = from_f32<T>(pr[r]);
+    const frag4 pb = __builtin_bit_cast(frag4, pt4);
+
+#pragma unroll
+    for (int u = 0; u < 4; ++u) stvec<T, VE>(v_wr + u * DV_ROW, vv[u]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const auto va = TrRead<T>::run(v_rd + 16 * dt);
+      acc[dt] *= alpha;
+      acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, va), pb, acc[dt]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  if (n_iter > 0) {
+    // Two K/V register buffers: the loads of tile it+1 are in flight while tile it is computed, so a
+    // wave keeps 8-16 KiB outstanding at all times.  Addresses past the range are clamped (valid).
+    int32_t skA, svA[4], skB, svB[4];
+    frag kfA[4], kfB[4];
+    Vec<T, VE> vvA[4], vvB[4];
+    load_slots(0, skA, svA);
+    load_slots(1, skB, svB);
+    load_kv(skA, svA, kfA, vvA);
+    for (int it = 0; it < n_iter; it += 2) {
+      load_kv(skB, svB, kfB, vvB);
+      load_slots(it + 2, skA, svA);
+      compute(kfA, vvA, it);
+      load_kv(skA, svA, kfA, vvA);
+      load_slots(it + 3, skB, svB);
+      compute(kfB, vvB, it + 1);
+    }
+  }
+
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (r16 < G) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm_acc[wave][r16][16 * dt + 4 * c4 + r] = acc[dt][r];
+    if (c4 == 0) {
+      sm_m[wave][r16] = m;
+      sm_l[wave][r16] = l;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * D; idx += 256) {
+    const int g = idx / D, d = idx - g * D;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mx = fmaxf(mx, sm_m[w][g]);
+    const float ms = safe_m(mx);
+    float lt = 0.f, at = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = exp2f(sm_m[w][g] - ms);
+      lt += sm_l[w][g] * f;
+      at += sm_acc[w][g][d] * f;
+    }
+    const float val = lt > 0.f ? at / lt : 0.f;
+    const int head = head0 + g;
+    if (p.num_splits == 1) {
+      o[((int64_t)b * p.hq + head) * D + d] = from_f32<T>(val);
+    } else {
+      const int64_t ph = ((int64_t)b * p.hq + head) * p.num_splits + split;
+      p.part_o[ph * D + d] = val;
+      if (d == 0) p.part_lse[ph] = lt > 0.f ? mx * kLn2 + logf(lt) : -INFINITY;
+    }
+  }
+}
+
 // Any head_dim / v_head_dim (<= 1024): one wave per (head, split, sequence); lanes stride the
 // feature axis.  Slow path for shapes outside the vectorised kernel (e.g. D = 80, 96, 576/512).
 template <typename T>
@@ -600,6 +792,8 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const float* __restri
   }
 }
 
+int g_decode_variant = 0;   // 0 = P.V on MFMA, 1 = P.V on the vector ALU (mi355_debug_set key 6)
+
 template <typename T, int D, int U, bool CAP>
 static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const DecodeParams& p,
                              int64_t bs, hipStream_t st) {
@@ -608,6 +802,15 @@ static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const D
   const dim3 grid((unsigned)(p.hkv * (gtotal / G)), (unsigned)p.num_splits, (unsigned)bs);
   const dim3 block(256);
   if constexpr (D == 128 && !std::is_same<T, float>::value) {
+    if (g_decode_variant == 0) {
+      switch (G) {
+        case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+        case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+        case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+        default: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
+      }
+      return;
+    }
     switch (G) {
       case 8: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 8, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
       case 4: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 4, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;

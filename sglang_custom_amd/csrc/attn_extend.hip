@@ -315,18 +315,6 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const T* __restrict
 constexpr int XK_ROW = 128 + 8;    // K tile row (elements): 272 B -> conflict-free ds_read_b128
 constexpr int XV_ROW = 128 + 16;   // V tile row: 288 B -> conflict-free transposed reads
 
-// ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x 16 columns of 16-bit elements, delivered
-// column-major -- lane i of the group receives column i of the four rows.  Lane 4 q + pp supplies
-// the address of row q, columns 4 pp .. 4 pp + 3 (8-byte aligned).  EXEC must be all ones.
-template <typename T> struct TrRead {
-  typedef short s4 __attribute__((ext_vector_type(4)));
-  typedef T v4 __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ v4 run(const T* lds) {
-    const s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(lds));
-    return __builtin_bit_cast(v4, r);
-  }
-};
-
 template <typename T>
 __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restrict__ q_ext,
                                                                const T* __restrict__ k_ext,

@@ -165,6 +165,22 @@ template <> struct Mfma<bf16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
+// v_mfma_f32_16x16x16 on 16-bit operands: lane l holds A[i = l & 15][k = 4 * (l >> 4) + 0..3] and
+// B[k = 4 * (l >> 4) + 0..3][j = l & 15]; the result layout is that of the k = 32 instruction.
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+  typedef short frag __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<f16_t> {
+  typedef _Float16 frag __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+  }
+};
+
 // fp8 (OCP e4m3fn): a 16-byte fragment feeds TWO k = 32 steps -- within a 64-wide K block lane
 // group c owns bytes [16c, 16c + 16) and step h uses its bytes [8h, 8h + 8); the other operand
 // uses the same map, so products pair up.
@@ -185,6 +201,18 @@ template <> struct Mfma<f16_t> {
   using frag = f16x8;
   static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x 16 columns of 16-bit elements, delivered
+// column-major -- lane i of the group receives column i of the four rows.  Lane 4 q + pp supplies
+// the address of row q, columns 4 pp .. 4 pp + 3 (8-byte aligned).  EXEC must be all ones.
+template <typename T> struct TrRead {
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef T v4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ v4 run(const T* lds) {
+    const s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(lds));
+    return __builtin_bit_cast(v4, r);
   }
 };
 

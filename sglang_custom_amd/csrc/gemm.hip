@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 //     workgroup that consumes it).
 // grid: (ceil(N / (64*NT)), splits).  block: 256.
 // ------------------------------------------------------------------------------------------
+extern int g_decode_variant;
 int g_gemm_variant = 0;   // tuning switches, see mi355_debug_set
 int g_force_splits = 0;
 
@@ -749,6 +750,7 @@ void mi355_debug_set(int key, int value) {
   if (key == 0) g_gemm_variant = value;   // 0 = ring kernel (default), 1 = two-launch kernel
   if (key == 2) g_force_splits = value;   // > 0 overrides the split-K plan
   if (key == 4) g_force_waves = value;    // 4 | 6 | 7 | 8 overrides the tiles-per-workgroup plan
+  if (key == 6) g_decode_variant = value; // decode attention P.V: 0 = on MFMA (default), 1 = on the vector ALU
 }
 
 int64_t mi355_linear_workspace_bytes(int64_t m, int64_t n, int64_t k) {
