@@ -229,6 +229,22 @@ int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void
                         int64_t n, int64_t k, int64_t x_stride, void* workspace,
                         int64_t workspace_bytes, int dtype, int out_dtype, void* stream);
 
+/* Deferred split-K reduction.  mi355_linear_packed_partials runs the packed skinny GEMM of
+ * mi355_linear_packed but leaves each K split's fp32 partial in part[split][m][n] (row-major,
+ * mi355_linear_packed_splits(m, n, k) splits; 0 = shape not served: needs K % 256 == 0, N < 65536)
+ * for the kernel that consumes y to sum: mi355_fused_add_rmsnorm_partials(x, residual, weight,
+ * part, nsplit, ...) computes y = T(sum over splits, in split order) and then exactly what
+ * mi355_fused_add_rmsnorm does with x = y (x receives the normalised rows).  Bit-identical to the
+ * GEMM followed by the norm; saves the GEMM's arrival ticket and second pass.  No counterpart in
+ * the reference (its row-parallel GEMMs and norms are separate library calls, layers/linear.py:1277-1303,
+ * layers/layernorm.py:76-78). */
+int mi355_linear_packed_splits(int64_t m, int64_t n, int64_t k);
+int mi355_linear_packed_partials(float* part, const void* x, const void* w_packed, int64_t m, int64_t n,
+                                 int64_t k, int64_t x_stride, int dtype, void* stream);
+int mi355_fused_add_rmsnorm_partials(void* x, void* residual, const void* weight, const float* part,
+                                     int nsplit, int64_t rows, int64_t hidden, float eps, int dtype,
+                                     void* stream);
+
 /* gate_up projection with SiLU-and-mul fused into the epilogue: y[m, j] = T(silu(g_j)) * u_j with
  * g = x W_gate^T, u = x W_up^T each rounded to T first (the rounding points of the unfused ops).
  * w_packed = mi355_pack_weight of the [2d, K] matrix whose 16-row tile t holds gate rows

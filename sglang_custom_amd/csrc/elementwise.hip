@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
                                                           T* __restrict__ residual,
                                                           const T* __restrict__ w, int64_t hidden,
                                                           int64_t x_stride, int64_t out_stride,
-                                                          float eps, WeightPrefetch pf, int pf_wgs) {
+                                                          float eps, WeightPrefetch pf, int pf_wgs,
+                                                          const float* __restrict__ part, int nsplit) {
   constexpr int VE = V16<T>::n;
   __shared__ float red[16];
   if ((int)blockIdx.x < pf_wgs) {   // warm-up riders come first so they keep the GEMM's XCD mapping
@@ -50,11 +51,39 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
   const int nvec = (int)(hidden / VE);
   float vals[CHUNKS][VE];
   float ss = 0.f;
+  // the norm weight is fetched up front so that its latency overlaps the row loads and the reduction
+  Vec<T, VE> wv[CHUNKS];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int vi = threadIdx.x + c * 256;
+    wv[c] = ldvec<T, VE>(w + (int64_t)(vi < nvec ? vi : 0) * VE);
+  }
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
     const int vi = threadIdx.x + c * 256;
     if (vi < nvec) {
-      Vec<T, VE> a = ldvec<T, VE>(xr + (int64_t)vi * VE);
+      Vec<T, VE> a;
+      if (part) {
+        // x is still the split-K partials of the GEMM that produced it ([split][rows][hidden] fp32):
+        // sum in split order and round once, exactly as that GEMM's own combine would have.
+        const int64_t split_stride = (int64_t)(gridDim.x - pf_wgs) * hidden;
+        const float* pr = part + row * hidden + (int64_t)vi * VE;
+        float sum[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) sum[j] = 0.f;
+#pragma unroll 4
+        for (int sp = 0; sp < nsplit; ++sp) {
+#pragma unroll
+          for (int j4 = 0; j4 < VE; j4 += 4) {
+            const float4 f = *reinterpret_cast<const float4*>(pr + sp * split_stride + j4);
+            sum[j4] += f.x; sum[j4 + 1] += f.y; sum[j4 + 2] += f.z; sum[j4 + 3] += f.w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < VE; ++j) a.v[j] = from_f32<T>(sum[j] + 0.f);
+      } else {
+        a = ldvec<T, VE>(xr + (int64_t)vi * VE);
+      }
       if (ADD) {
         Vec<T, VE> b = ldvec<T, VE>(rr + (int64_t)vi * VE);
         Vec<T, VE> s;
@@ -79,10 +108,9 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
   for (int c = 0; c < CHUNKS; ++c) {
     const int vi = threadIdx.x + c * 256;
     if (vi < nvec) {
-      Vec<T, VE> wv = ldvec<T, VE>(w + (int64_t)vi * VE);
       Vec<T, VE> o;
 #pragma unroll
-      for (int j = 0; j < VE; ++j) o.v[j] = from_f32<T>((vals[c][j] * inv) * to_f32(wv.v[j]));
+      for (int j = 0; j < VE; ++j) o.v[j] = from_f32<T>((vals[c][j] * inv) * to_f32(wv[c].v[j]));
       stvec<T, VE>(orow + (int64_t)vi * VE, o);
     }
   }
@@ -137,13 +165,15 @@ __global__ __launch_bounds__(256) void fused_add_rmsnorm_generic_kernel(T* __res
 
 template <typename T, bool ADD>
 static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, int64_t hidden,
-                          int64_t x_stride, int64_t out_stride, float eps, hipStream_t st) {
+                          int64_t x_stride, int64_t out_stride, float eps, hipStream_t st,
+                          const float* part = nullptr, int nsplit = 0) {
   constexpr int VE = V16<T>::n;
   const bool vec_ok = hidden % VE == 0 && x_stride % VE == 0 && out_stride % VE == 0 &&
                       aligned16(out) && aligned16(x) && aligned16(w) &&
                       (!ADD || aligned16(residual));
   const int64_t nvec = hidden / VE;
   dim3 grid((unsigned)rows), block(256);
+  if (part && !(vec_ok && nvec <= 256 * 8 && VE % 4 == 0)) return MI355_ERR_UNSUPPORTED;
   if (vec_ok && nvec <= 256 * 8) {
     const int chunks = (int)((nvec + 255) / 256);
     WeightPrefetch pf;
@@ -151,7 +181,7 @@ static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, i
     grid.x += pf_wgs;
 #define LAUNCH(C)                                                                              \
   hipLaunchKernelGGL((rmsnorm_vec_kernel<T, ADD, C>), grid, block, 0, st, out, x, residual, w, \
-                     hidden, x_stride, out_stride, eps, pf, pf_wgs)
+                     hidden, x_stride, out_stride, eps, pf, pf_wgs, part, nsplit)
     if (chunks <= 1) LAUNCH(1);
     else if (chunks <= 2) LAUNCH(2);
     else if (chunks <= 4) LAUNCH(4);
@@ -404,6 +434,27 @@ int mi355_prefetch_next(const void* w_packed, int64_t m, int64_t n, int64_t k, i
                 "prefetch_next: packed weights are 16-bit or fp8 (w_elem_bytes 2 or 1)");
   const int64_t k16 = w_elem_bytes == 1 ? k / 2 : k;
   g_pf_pending = plan_weight_prefetch(w_packed, m, n, k16, budget_bytes, &g_pf);
+  return MI355_OK;
+}
+
+int mi355_fused_add_rmsnorm_partials(void* x, void* residual, const void* weight, const float* part,
+                                     int nsplit, int64_t rows, int64_t hidden, float eps, int dtype,
+                                     void* stream) {
+  MI355_REQUIRE(x && residual && weight && part, MI355_ERR_INVALID, "fused_add_rmsnorm_partials: null pointer");
+  MI355_REQUIRE(rows >= 0 && hidden > 0 && nsplit >= 1 && nsplit <= 64, MI355_ERR_INVALID,
+                "fused_add_rmsnorm_partials: bad shape rows=%lld hidden=%lld nsplit=%d", (long long)rows,
+                (long long)hidden, nsplit);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "fused_add_rmsnorm_partials: only 16-bit dtypes");
+  MI355_REQUIRE(aligned16(part), MI355_ERR_INVALID, "fused_add_rmsnorm_partials: misaligned partials");
+  if (rows == 0) return MI355_OK;
+  int rc = MI355_OK;
+  MI355_DISPATCH_DTYPE(dtype, "fused_add_rmsnorm_partials",
+                       rc = launch_rmsnorm<T, true>((T*)x, (T*)x, (T*)residual, (const T*)weight, rows, hidden,
+                                                    hidden, hidden, eps, (hipStream_t)stream, part, nsplit));
+  MI355_REQUIRE(rc == MI355_OK, MI355_ERR_UNSUPPORTED,
+                "fused_add_rmsnorm_partials: needs hidden %% 8 == 0, hidden <= 16384 and 16-B aligned pointers");
+  MI355_CHECK_LAUNCH("fused_add_rmsnorm_partials");
   return MI355_OK;
 }
 

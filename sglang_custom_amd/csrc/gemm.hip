@@ -365,6 +365,29 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   };
 
   const int splits = gridDim.y;
+  if constexpr (!ACT && !FP8) {
+    if (y == nullptr) {
+      // Deferred reduction: this split's fp32 partial goes out row-major, [split][M][N], and the
+      // CONSUMER kernel sums the splits (in split order, then rounds once -- the same arithmetic as
+      // the combine below).  No ticket, no second pass here; the kernel boundary publishes the data.
+      float* part = slab + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = mt * 16 + r16, n0 = (tile0 + WAVES * nt) * 16 + q * 4;
+          if (m >= M) continue;
+          if (n0 + 3 < N && (N & 3) == 0) {
+            *reinterpret_cast<f32x4*>(part + (int64_t)m * N + n0) = acc[nt][mt];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n0 + r < N) part[(int64_t)m * N + n0 + r] = acc[nt][mt][r];
+          }
+        }
+      return;
+    }
+  }
   if (splits == 1) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -644,9 +667,14 @@ static void launch_ring(const T* x, const T* w, const void* bias, OUT* y, float*
 template <typename T, int MT, int NT, typename OUT, bool PACKED, bool ACT = false>
 static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, char* ws, int M,
                               int N, int K, int64_t x_stride, const SkinnyPlan& p,
-                              hipStream_t st) {
+                              hipStream_t st, float* part = nullptr) {
   unsigned* counters = p.splits > 1 ? reinterpret_cast<unsigned*>(ws) : nullptr;
   float* slab = p.splits > 1 ? reinterpret_cast<float*>(ws + p.counter_bytes) : nullptr;
+  if (part) {   // deferred reduction (ring kernel only; the caller checked): y == nullptr selects it
+    counters = nullptr;
+    slab = part;
+    y = nullptr;
+  }
   if (use_ring(K) || ACT) {
     if constexpr (PACKED && NT == 1) {
       if (p.waves == 8) return launch_ring<T, MT, NT, OUT, PACKED, 8, ACT>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
@@ -673,10 +701,10 @@ static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, cha
 
 template <typename T, typename OUT, bool PACKED = false, bool ACT = false>
 static void launch_skinny(const T* x, const T* w, const T* bias, OUT* y, void* ws, int M, int N,
-                          int K, int64_t x_stride, hipStream_t st) {
+                          int K, int64_t x_stride, hipStream_t st, float* part = nullptr) {
   const SkinnyPlan p = plan_skinny(M, N, K, use_ring(K) && PACKED);
   const int mt = (M + 15) / 16;
-#define SK(MT_, NT_) launch_skinny_cfg<T, MT_, NT_, OUT, PACKED, ACT>(x, w, bias, y, (char*)ws, M, N, K, x_stride, p, st)
+#define SK(MT_, NT_) launch_skinny_cfg<T, MT_, NT_, OUT, PACKED, ACT>(x, w, bias, y, (char*)ws, M, N, K, x_stride, p, st, part)
   if constexpr (ACT) {
     if (mt <= 1) SK(1, 1); else if (mt <= 2) SK(2, 1); else SK(4, 1);
   } else if (p.nt == 2) {
@@ -810,6 +838,33 @@ int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void
     else launch_skinny<f16_t, f16_t, true>((const f16_t*)x, (const f16_t*)w_packed, (const f16_t*)bias, (f16_t*)y, workspace, (int)m, (int)n, (int)k, x_stride, st);
   }
   MI355_CHECK_LAUNCH("linear_packed");
+  return MI355_OK;
+}
+
+int mi355_linear_packed_splits(int64_t m, int64_t n, int64_t k) {
+  if (m < 1 || m > 64 || n < 1 || n >= 64 * 1024 || k < SK_BK || k % SK_BK != 0 || g_gemm_variant != 0) return 0;
+  return plan_skinny(m, n, k, true).splits;
+}
+
+int mi355_linear_packed_partials(float* part, const void* x, const void* w_packed, int64_t m, int64_t n,
+                                 int64_t k, int64_t x_stride, int dtype, void* stream) {
+  MI355_REQUIRE(part && x && w_packed, MI355_ERR_INVALID, "linear_packed_partials: null pointer");
+  MI355_REQUIRE(m >= 0 && m <= 64 && n > 0 && k > 0 && x_stride >= k && x_stride % 8 == 0, MI355_ERR_INVALID,
+                "linear_packed_partials: needs 0 <= M <= 64 (m=%lld n=%lld k=%lld)", (long long)m, (long long)n,
+                (long long)k);
+  MI355_REQUIRE(mi355_linear_packed_splits(m > 0 ? m : 1, n, k) > 0, MI355_ERR_UNSUPPORTED,
+                "linear_packed_partials: needs K %% 256 == 0 and N < 65536 (k=%lld n=%lld)", (long long)k, (long long)n);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "linear_packed_partials: only 16-bit dtypes");
+  MI355_REQUIRE(aligned16(x) && aligned16(w_packed) && aligned16(part), MI355_ERR_INVALID,
+                "linear_packed_partials: misaligned pointer");
+  if (m == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI355_BF16)
+    launch_skinny<bf16_t, bf16_t, true>((const bf16_t*)x, (const bf16_t*)w_packed, nullptr, nullptr, nullptr, (int)m, (int)n, (int)k, x_stride, st, part);
+  else
+    launch_skinny<f16_t, f16_t, true>((const f16_t*)x, (const f16_t*)w_packed, nullptr, nullptr, nullptr, (int)m, (int)n, (int)k, x_stride, st, part);
+  MI355_CHECK_LAUNCH("linear_packed_partials");
   return MI355_OK;
 }
 

@@ -9,6 +9,7 @@ from torch import nn
 
 from ..custom_op import CustomOp
 from ..ops_backend import get_ops
+from .quantization.unquant import SplitKPartials
 
 
 class RMSNorm(CustomOp):
@@ -20,9 +21,13 @@ class RMSNorm(CustomOp):
     def forward_hip(
         self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
     ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        ops = get_ops()
+        if isinstance(x, SplitKPartials):
+            # the producing GEMM left its split-K partials for this kernel to sum
+            assert residual is not None
+            return ops.fused_add_rmsnorm_partials(x.part, residual, self.weight.data, self.variance_epsilon), residual
         if not x.is_contiguous():
             x = x.contiguous()
-        ops = get_ops()
         if residual is not None:
             ops.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
             return x, residual

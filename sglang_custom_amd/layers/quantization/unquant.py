@@ -59,6 +59,28 @@ def gate_up_silu_mul(layer, act_fn, x: torch.Tensor) -> torch.Tensor:
     return act_fn(gate_up)
 
 
+class SplitKPartials:
+    """Output of a row-parallel decode GEMM whose split-K partials ([splits, M, N] fp32) are still
+    to be summed -- by the fused add + RMSNorm that consumes it (RMSNorm.forward accepts it as x)."""
+
+    def __init__(self, part: torch.Tensor):
+        self.part = part
+        self.shape = part.shape[1:]
+
+
+def decode_linear_deferred(layer, x: torch.Tensor):
+    """layer(x) for the TP=1 decode path, leaving the split-K reduction to the following norm; None
+    when the layer, the shape or the ops backend does not support it."""
+    fn = getattr(get_ops(), "linear_packed_partials", None)
+    wp = getattr(layer, "weight_packed", None)
+    if (fn is None or wp is None or getattr(layer, "tp_size", 1) != 1 or x.dim() != 2
+            or not 1 <= x.shape[0] <= SKINNY_MAX_M or x.stride(0) % 8 != 0
+            or not isinstance(layer.quant_method, UnquantizedLinearMethod)):
+        return None
+    part = fn(x, wp, layer.weight.shape[0])
+    return None if part is None else SplitKPartials(part)
+
+
 class UnquantizedLinearMethod:
     def process_weights_after_loading(self, layer) -> None:
         pack_for_decode(layer)

@@ -20,6 +20,7 @@ from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowPa
 from ..layers.logits_processor import LogitsProcessor
 from ..layers.quantization.unquant import (
     UnquantizedLinearMethod,
+    decode_linear_deferred,
     gate_up_silu_mul,
     pack_for_decode,
     pack_gate_up_for_decode,
@@ -44,6 +45,9 @@ class LlamaMLP(nn.Module):
         else:
             gate_up, _ = self.gate_up_proj(x)
             x = self.act_fn(gate_up)
+        deferred = decode_linear_deferred(self.down_proj, x)   # summed by the next layer's norm
+        if deferred is not None:
+            return deferred
         x, _ = self.down_proj(x)
         return x
 
@@ -80,6 +84,9 @@ class LlamaAttention(nn.Module):
         kb, vb = pool.get_kv_buffer(self.attn.layer_id)
         self.rotary_emb.forward_with_kv_write(positions, q, k, v, kb, vb, forward_batch.out_cache_loc)
         attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        deferred = decode_linear_deferred(self.o_proj, attn_output)   # summed by post_attention_layernorm
+        if deferred is not None:
+            return deferred
         output, _ = self.o_proj(attn_output)
         return output
 

@@ -390,6 +390,38 @@ def linear_packed(x: torch.Tensor, weight_packed: torch.Tensor, n: int, bias: Op
     return y
 
 
+def linear_packed_partials(x: torch.Tensor, weight_packed: torch.Tensor, n: int) -> Optional[torch.Tensor]:
+    """x @ W^T left as fp32 split-K partials [splits, M, N] for fused_add_rmsnorm_partials to sum
+    (None when the shape is not served: the caller then runs linear_packed)."""
+    _gpu(x, weight_packed)
+    assert x.dim() == 2 and x.stride(1) == 1
+    m, k = x.shape
+    splits = _lib_().mi355_linear_packed_splits(max(m, 1), n, k)
+    if splits <= 0 or m > 64 or x.dtype not in (torch.bfloat16, torch.float16):
+        return None
+    part = torch.empty((splits, m, n), dtype=torch.float32, device=x.device)
+    if m:
+        check(_lib_().mi355_linear_packed_partials(part.data_ptr(), x.data_ptr(), weight_packed.data_ptr(), m, n, k,
+                                                   x.stride(0), _dt(x), _stream(x)), "linear_packed_partials")
+    return part
+
+
+def fused_add_rmsnorm_partials(part: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                               eps: float) -> torch.Tensor:
+    """y = sum of the split-K partials (rounded once to residual.dtype), then fused_add_rmsnorm(y,
+    residual): returns the normalised rows, residual updated in place."""
+    _gpu(part, residual, weight)
+    assert part.dim() == 3 and part.is_contiguous() and part.dtype == torch.float32
+    assert residual.is_contiguous() and residual.shape == part.shape[1:] and residual.dtype == weight.dtype
+    x = torch.empty_like(residual)
+    if residual.numel():
+        check(_lib_().mi355_fused_add_rmsnorm_partials(x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                                       part.data_ptr(), part.shape[0], part.shape[1], part.shape[2],
+                                                       float(eps), _dt(residual), _stream(residual)),
+              "fused_add_rmsnorm_partials")
+    return x
+
+
 def prefetch_next(weight_packed: torch.Tensor, m: int, n: int, k: int, budget_bytes: int = 24 << 20) -> None:
     """Hint: the next rmsnorm / fused_add_rmsnorm launch of this thread also pulls the head of this
     packed weight into L2, in the order the M-row skinny GEMM over it will ask for it (24 MiB of the

@@ -599,3 +599,29 @@ def test_prefetch_hint_rides_rmsnorm_without_changing_results(ops):
         n1 = ops.rmsnorm(x, g, 1e-5)
         torch.cuda.synchronize()
         assert torch.equal(x0, x1) and torch.equal(r0, r1) and torch.equal(y0, y1) and torch.equal(n0, n1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_deferred_splitk_reduction_is_bit_identical(ops, dtype):
+    """linear_packed_partials + fused_add_rmsnorm_partials == linear_packed + fused_add_rmsnorm, bit for
+    bit (same split order, one rounding), over split and unsplit plans, ragged M and N % 64 != 0."""
+    torch.manual_seed(1)
+    for (m, n, k) in [(64, 4096, 4096), (64, 4096, 14336), (5, 4096, 4096), (33, 2048, 8192), (16, 1208, 512), (1, 4096, 256)]:
+        w = torch.randn(n, k, device="cuda", dtype=dtype) * 0.05
+        wp = ops.pack_weight(w)
+        x = torch.randn(m, k, device="cuda", dtype=dtype)
+        res = torch.randn(m, n, device="cuda", dtype=dtype)
+        g = torch.randn(n, device="cuda", dtype=dtype)
+        y = ops.linear_packed(x, wp, n)
+        r0 = res.clone()
+        ops.fused_add_rmsnorm(y, r0, g, 1e-5)
+        part = ops.linear_packed_partials(x, wp, n)
+        assert part is not None and part.shape[1:] == (m, n)
+        r1 = res.clone()
+        y1 = ops.fused_add_rmsnorm_partials(part, r1, g, 1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1), (m, n, k, part.shape[0])
+        assert torch.equal(y, y1), (m, n, k, part.shape[0])
+    assert ops.linear_packed_partials(torch.randn(4, 96, device="cuda", dtype=dtype),
+                                      ops.pack_weight(torch.randn(64, 96, device="cuda", dtype=dtype)), 64) is None
