@@ -184,6 +184,26 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
                            int64_t num_slots, float sm_scale, float logit_cap,
                            int sliding_window_size, int dtype, void* stream);
 
+/* Decode attention fused with everything between the qkv GEMM and the attention kernel.
+ * qkv_part: the fp32 split-K partials [nsplit][bs][(hq + 2 hkv) * 128] of the qkv projection
+ * (mi355_linear_packed_partials).  The kernel sums them (split order, one rounding to the tensor
+ * dtype = the GEMM's own result), applies neox RoPE over the whole head to q and the new k with
+ * cos_sin_cache[positions[b]] (rounding points of mi355_rope_inplace), writes the new k / v rows to
+ * slot out_cache_loc[b] (which the page table must name for position seq_len - 1, except for padding
+ * rows, whose writes go to the sink slot they name), and runs mi355_decode_attention.  Output and
+ * cache contents are bit-identical to mi355_linear_packed -> mi355_rope_inplace (fused KV write) ->
+ * mi355_decode_attention.  Needs head_dim 128, a 16-bit dtype, hq / hkv in {1, 2, 4, 8}, no logit cap.
+ * replaces: LlamaAttention.forward's rotary_emb + attn sequence (models/llama.py:180-191) on the
+ *           decode path; the reference has no fused counterpart. */
+int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const int64_t* positions,
+                                     const int64_t* out_cache_loc, const void* cos_sin_cache, int cache_dtype, void* k_buffer,
+                                     void* v_buffer, void* o, const int32_t* page_table, int mode,
+                                     const int64_t* req_pool_indices, const int64_t* seq_lens,
+                                     const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
+                                     float* attn_lse, int num_splits, int64_t bs, int hq, int hkv,
+                                     int head_dim, int64_t num_slots, float sm_scale, int dtype,
+                                     void* stream);
+
 /* MLA (compressed-KV) decode: every query head attends over ONE latent row per token,
  * kv_buffer [num_slots, 1, kv_lora_rank + rope_dim]; the key is the whole row, the value its first
  * kv_lora_rank features (read from the same buffer, never materialised).  q [B, hq, rank + rope],

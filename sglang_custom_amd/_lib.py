@@ -47,6 +47,7 @@ _SIGNATURES = {
     "mi355_debug_read_bw": (I, [P, L, I, I, P, P]),
     "mi355_debug_xcc_map": (I, [P, I, P]),
     "mi355_prefetch_next": (I, [P, L, L, L, I, L]),
+    "mi355_decode_attention_fused_qkv": (I, [P, I, P, P, P, I, P, P, P, P, I, P, P, P, L, P, P, I, L, I, I, I, L, F, I, P]),
     "mi355_linear_packed_splits": (I, [L, L, L]),
     "mi355_linear_packed_partials": (I, [P, P, P, L, L, L, L, I, P]),
     "mi355_fused_add_rmsnorm_partials": (I, [P, P, P, P, I, L, L, F, I, P]),

@@ -32,6 +32,18 @@ struct DecodeParams {
   int64_t k_slot_stride, v_slot_stride;  // elements between consecutive slots (generic kernel)
 };
 
+// Inputs of the fused decode step: the qkv projection is still fp32 split-K partials, RoPE has
+// not been applied and the new token's K/V rows are not in the cache yet.
+struct FusedQkv {
+  const float* part;          // [nsplit][B][row] partials of the qkv GEMM, row = (hq + 2 hkv) * 128
+  int nsplit;
+  int64_t split_stride, row;  // elements
+  const int64_t* positions;   // [B]
+  const int64_t* out_loc;     // [B] cache slot of the new token (padded rows of a captured batch name the sink slot)
+  const void* cos_sin;        // [max_pos][128]: cos (64) | sin (64), fp32 or the tensor dtype
+  int cache_f32;
+};
+
 __device__ __forceinline__ void seq_range(const DecodeParams& p, int b, int64_t& page_off,
                                           int64_t& len) {
   if (p.mode == 0) {
@@ -534,11 +546,17 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const T* __restri
 // ------------------------------------------------------------------------------------------
 constexpr int DV_ROW = 128 + 16;   // V tile row in LDS (elements): 288 B -> conflict-free transposed reads
 
-template <typename T, int G, bool CAP>
+//
+// FUSED: q, k_new and v_new are summed from the qkv GEMM's split-K partials (split order, one
+// rounding -- that GEMM's own combine), q and k_new get neox RoPE with the rounding points of the
+// RoPE kernel, the wave that owns the newest key writes k_new / v_new into the cache and uses
+// them from registers for that key's tile.  One workgroup per (sequence, kv head, split) is
+// required (G = all query heads of the kv head), so nobody else reads or writes that slot.
+template <typename T, int G, bool CAP, bool FUSED = false>
 __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __restrict__ q,
-                                                                  const T* __restrict__ kbuf,
-                                                                  const T* __restrict__ vbuf,
-                                                                  T* __restrict__ o, DecodeParams p) {
+                                                                  const T* kbuf, const T* vbuf,
+                                                                  T* __restrict__ o, DecodeParams p,
+                                                                  FusedQkv fz = FusedQkv()) {
   constexpr int D = 128, VE = 8;
   using frag = typename Mfma<T>::frag;
   using frag4 = typename Mfma16<T>::frag;
@@ -563,14 +581,66 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
 
+  // FUSED: the workgroup first reduces its (G + 2) x 128 slice of the qkv row (q heads, k, v) from
+  // the split-K partials into LDS -- one float4 per thread and split -- together with the rounded
+  // cos | sin row of the sequence's position; the MFMA fragments are then read from LDS and rotated
+  // in registers (neox pairs feature i with i + 64: fragment s with s + 2).
+  __shared__ __attribute__((aligned(16))) T sm_qkv[FUSED ? (G + 2) * D : 8];
+  __shared__ __attribute__((aligned(16))) float sm_cs[FUSED ? D : 4];
+  float rc[2][8], rs[2][8];   // cos / sin of this lane's first-half features (FUSED only)
+  auto rotate = [&](frag (&y)[4]) {
+    // every product and sum rounds on its own, as in the RoPE kernel: with native f16 arithmetic the
+    // compiler would otherwise contract the rounded products into fused multiply-adds
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x1 = to_f32((T)y[s][j]), x2 = to_f32((T)y[s + 2][j]);
+        const float c = rc[s][j], sn = rs[s][j];
+        y[s][j] = from_f32<T>(round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * sn)));
+        y[s + 2][j] = from_f32<T>(round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * sn)));
+      }
+  };
+  auto reduce_qkv_to_lds = [&]() {
+    const int64_t pos = fz.positions[b];
+    for (int v = threadIdx.x; v < (G + 2) * 32; v += 256) {
+      const int seg = v >> 5, f4 = v & 31;
+      const int64_t head = seg < G ? head0 + seg : seg == G ? p.hq + kvh : p.hq + p.hkv + kvh;
+      const float* src = fz.part + (int64_t)b * fz.row + head * D + 4 * f4;
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int sp = 0; sp < fz.nsplit; ++sp) {
+        const float4 f = *reinterpret_cast<const float4*>(src + sp * fz.split_stride);
+        sum[0] += f.x; sum[1] += f.y; sum[2] += f.z; sum[3] += f.w;
+      }
+      Vec<T, 4> out;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out.v[j] = from_f32<T>(sum[j] + 0.f);
+      stvec<T, 4>(&sm_qkv[seg * D + 4 * f4], out);
+    }
+    if (threadIdx.x < D) {
+      const int64_t i = pos * D + threadIdx.x;
+      const float cv = fz.cache_f32 ? static_cast<const float*>(fz.cos_sin)[i] : to_f32(static_cast<const T*>(fz.cos_sin)[i]);
+      sm_cs[threadIdx.x] = round_to<T>(cv);
+    }
+  };
+  auto frags_from_lds = [&](int seg, frag (&y)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) y[s] = *reinterpret_cast<const frag*>(&sm_qkv[seg * D + 32 * s + 8 * c4]);
+    rotate(y);
+  };
+
   frag qf[4];
+  if constexpr (!FUSED) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (r16 < G) {
-      qf[s] = *reinterpret_cast<const frag*>(q + (int64_t)b * p.q_stride + (int64_t)(head0 + r16) * D + 32 * s + 8 * c4);
-    } else {
+    for (int s = 0; s < 4; ++s) {
+      if (r16 < G) {
+        qf[s] = *reinterpret_cast<const frag*>(q + (int64_t)b * p.q_stride + (int64_t)(head0 + r16) * D + 32 * s + 8 * c4);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
+        for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
+      }
     }
   }
 
@@ -589,6 +659,21 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   const int64_t last_key = len - 1;
   T* v_wr = &sm_v[wave][(4 * c4) * DV_ROW + 8 * r16];                           // + u rows
   const T* v_rd = &sm_v[wave][(4 * c4 + (r16 >> 2)) * DV_ROW + 4 * (r16 & 3)];  // + 16 dt
+
+  // FUSED: the newest key (position len - 1) belongs to the last split; its 16-key tile is tile
+  // `tl` of the split, walked by wave tl & 3 in iteration tl >> 2, row `rl` of the tile.
+  frag knew[4];
+  Vec<T, VE> vnew;
+  bool owner = false;
+  int it_new = -1, rl = 0;
+  if constexpr (FUSED) {
+    if (k1 == len && len > k0) {
+      const int tl = (int)((len - 1 - k0) >> 4);
+      rl = (int)((len - 1 - k0) & 15);
+      it_new = tl >> 2;
+      owner = (tl & 3) == wave;
+    }
+  }
 
   auto load_slots = [&](int it, int32_t& sk, int32_t (&sv)[4]) {
     const int64_t tb = wave_first + (int64_t)it * 64;
@@ -610,7 +695,17 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   };
   // One 16-key tile.  A tile past the end of the range is harmless: every key is masked, so the
   // probabilities are zero and the rescale factor is one.
-  auto compute = [&](const frag (&kf)[4], const Vec<T, VE> (&vv)[4], int it) {
+  auto compute = [&](frag (&kf)[4], Vec<T, VE> (&vv)[4], int it) {
+    if constexpr (FUSED) {
+      if (owner && it == it_new) {   // this tile's row rl was loaded before the cache held it
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (r16 == rl) kf[s] = knew[s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * c4 + u == rl) vv[u] = vnew;
+      }
+    }
     f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) sc = Mfma<T>::run(kf[s], qf[s], sc);
@@ -654,15 +749,46 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
     __builtin_amdgcn_wave_barrier();
   };
 
+  // Two K/V register buffers: the loads of tile it+1 are in flight while tile it is computed, so a
+  // wave keeps 8-16 KiB outstanding at all times.  Addresses past the range are clamped (valid).
+  int32_t skA, svA[4], skB, svB[4];
+  frag kfA[4], kfB[4];
+  Vec<T, VE> vvA[4], vvB[4];
   if (n_iter > 0) {
-    // Two K/V register buffers: the loads of tile it+1 are in flight while tile it is computed, so a
-    // wave keeps 8-16 KiB outstanding at all times.  Addresses past the range are clamped (valid).
-    int32_t skA, svA[4], skB, svB[4];
-    frag kfA[4], kfB[4];
-    Vec<T, VE> vvA[4], vvB[4];
     load_slots(0, skA, svA);
     load_slots(1, skB, svB);
-    load_kv(skA, svA, kfA, vvA);
+  }
+  if constexpr (FUSED) reduce_qkv_to_lds();   // its loads share the page-table round trip
+  if (n_iter > 0) load_kv(skA, svA, kfA, vvA);   // first K/V tile in flight across the barrier below
+  if constexpr (FUSED) {
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      *reinterpret_cast<float4*>(&rc[s][0]) = *reinterpret_cast<const float4*>(&sm_cs[32 * s + 8 * c4]);
+      *reinterpret_cast<float4*>(&rc[s][4]) = *reinterpret_cast<const float4*>(&sm_cs[32 * s + 8 * c4 + 4]);
+      *reinterpret_cast<float4*>(&rs[s][0]) = *reinterpret_cast<const float4*>(&sm_cs[64 + 32 * s + 8 * c4]);
+      *reinterpret_cast<float4*>(&rs[s][4]) = *reinterpret_cast<const float4*>(&sm_cs[64 + 32 * s + 8 * c4 + 4]);
+    }
+    frags_from_lds(r16 < G ? r16 : 0, qf);
+    if (r16 >= G) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
+    }
+    if (owner) {
+      frags_from_lds(G, knew);
+      vnew = ldvec<T, VE>(&sm_qkv[(G + 1) * D + 8 * r16]);
+      const int64_t slot = fz.out_loc[b];
+      if (r16 == 0) {
+        T* kd = const_cast<T*>(kbuf) + slot * row_stride + (int64_t)kvh * D + 8 * c4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<frag*>(kd + 32 * s) = knew[s];
+      }
+      if (c4 == 0) stvec<T, VE>(const_cast<T*>(vbuf) + slot * row_stride + (int64_t)kvh * D + 8 * r16, vnew);
+    }
+  }
+  if (n_iter > 0) {
     for (int it = 0; it < n_iter; it += 2) {
       load_kv(skB, svB, kfB, vvB);
       load_slots(it + 2, skA, svA);
@@ -862,6 +988,26 @@ static int launch_decode(const void* q_, const void* kb_, const void* vb_, void*
   return MI355_OK;
 }
 
+template <typename T>
+static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParams& p, const FusedQkv& fz,
+                               int64_t bs, hipStream_t st) {
+  const int G = p.hq / p.hkv;
+  const dim3 grid((unsigned)p.hkv, (unsigned)p.num_splits, (unsigned)bs), block(256);
+  switch (G) {
+    case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    case 1: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    default:
+      set_error("decode_attention_fused_qkv: %d query heads per kv head (needs 1, 2, 4 or 8)", G);
+      return MI355_ERR_UNSUPPORTED;
+  }
+  if (p.num_splits > 1)
+    hipLaunchKernelGGL((decode_merge_kernel<T>), dim3((unsigned)(bs * p.hq)), dim3(128), 0, st,
+                       p.part_o, p.part_lse, o, p.num_splits, 128);
+  return MI355_OK;
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -932,6 +1078,69 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
                                              (hipStream_t)stream));
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("decode_attention");
+  return MI355_OK;
+}
+
+int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const int64_t* positions,
+                                     const int64_t* out_cache_loc, const void* cos_sin_cache, int cache_dtype, void* k_buffer,
+                                     void* v_buffer, void* o, const int32_t* page_table, int mode,
+                                     const int64_t* req_pool_indices, const int64_t* seq_lens,
+                                     const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
+                                     float* attn_lse, int num_splits, int64_t bs, int hq, int hkv,
+                                     int head_dim, int64_t num_slots, float sm_scale, int dtype,
+                                     void* stream) {
+  MI355_REQUIRE(qkv_part && positions && out_cache_loc && cos_sin_cache && k_buffer && v_buffer && o && page_table,
+                MI355_ERR_INVALID, "decode_attention_fused_qkv: null pointer");
+  MI355_REQUIRE(mode == 0 || mode == 1, MI355_ERR_INVALID, "decode_attention_fused_qkv: mode must be 0|1");
+  if (mode == 0)
+    MI355_REQUIRE(req_pool_indices && seq_lens && table_stride > 0, MI355_ERR_INVALID,
+                  "decode_attention_fused_qkv: mode 0 needs req_pool_indices, seq_lens, table_stride");
+  else
+    MI355_REQUIRE(kv_indptr, MI355_ERR_INVALID, "decode_attention_fused_qkv: mode 1 needs kv_indptr");
+  MI355_REQUIRE(bs >= 0 && bs <= 65535 && hq > 0 && hkv > 0 && hq % hkv == 0 && num_slots > 0 && nsplit >= 1 &&
+                    nsplit <= 64,
+                MI355_ERR_INVALID, "decode_attention_fused_qkv: bad shape hq=%d hkv=%d nsplit=%d", hq, hkv, nsplit);
+  MI355_REQUIRE(head_dim == 128 && (dtype == MI355_BF16 || dtype == MI355_F16), MI355_ERR_UNSUPPORTED,
+                "decode_attention_fused_qkv: needs head_dim 128 and a 16-bit dtype");
+  MI355_REQUIRE(cache_dtype == MI355_F32 || cache_dtype == dtype, MI355_ERR_UNSUPPORTED,
+                "decode_attention_fused_qkv: cos_sin_cache must be fp32 or the tensor dtype");
+  MI355_REQUIRE(num_splits >= 1 && num_splits <= 65535 && (num_splits == 1 || (attn_logits && attn_lse)),
+                MI355_ERR_INVALID, "decode_attention_fused_qkv: bad num_splits / missing scratch");
+  MI355_REQUIRE(aligned16(qkv_part) && aligned16(k_buffer) && aligned16(v_buffer), MI355_ERR_INVALID,
+                "decode_attention_fused_qkv: misaligned pointer");
+  if (bs == 0) return MI355_OK;
+  DecodeParams p;
+  p.page_table = page_table;
+  p.req_pool_indices = req_pool_indices;
+  p.seq_lens = seq_lens;
+  p.kv_indptr = kv_indptr;
+  p.table_stride = table_stride;
+  p.q_stride = (int64_t)hq * head_dim;
+  p.part_o = attn_logits;
+  p.part_lse = attn_lse;
+  p.mode = mode;
+  p.num_splits = num_splits;
+  p.hq = hq;
+  p.hkv = hkv;
+  p.sm_scale = sm_scale;
+  p.logit_cap = 0.f;
+  p.k_slot_stride = (int64_t)hkv * head_dim;
+  p.v_slot_stride = (int64_t)hkv * head_dim;
+  FusedQkv fz;
+  fz.part = qkv_part;
+  fz.nsplit = nsplit;
+  fz.row = (int64_t)(hq + 2 * hkv) * head_dim;
+  fz.split_stride = bs * fz.row;
+  fz.positions = positions;
+  fz.out_loc = out_cache_loc;
+  fz.cos_sin = cos_sin_cache;
+  fz.cache_f32 = cache_dtype == MI355_F32;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dtype == MI355_BF16) rc = launch_decode_fused<bf16_t>((const bf16_t*)k_buffer, (const bf16_t*)v_buffer, (bf16_t*)o, p, fz, bs, st);
+  else rc = launch_decode_fused<f16_t>((const f16_t*)k_buffer, (const f16_t*)v_buffer, (f16_t*)o, p, fz, bs, st);
+  if (rc != MI355_OK) return rc;
+  MI355_CHECK_LAUNCH("decode_attention_fused_qkv");
   return MI355_OK;
 }
 

@@ -127,6 +127,32 @@ class Mi355AttnBackend(AttentionBackend):
             layer.scaling, layer.logit_cap)
         return o
 
+    def forward_decode_fused_qkv(self, qkv_part, positions, cos_sin_cache, layer, forward_batch):
+        """Decode step from the qkv GEMM's split-K partials: reduction, RoPE, KV-cache write and
+        attention in one launch (ops.decode_attention_fused_qkv).  Same result as rotary_emb +
+        forward_decode(save_kv_cache=True) on the reduced projection."""
+        o = torch.empty((qkv_part.shape[1], layer.tp_q_head_num * layer.v_head_dim),
+                        dtype=forward_batch.token_to_kv_pool.dtype, device=qkv_part.device)
+        pool = forward_batch.token_to_kv_pool
+        md = self.forward_metadata
+        get_ops().decode_attention_fused_qkv(
+            qkv_part, positions, forward_batch.out_cache_loc, cos_sin_cache,
+            pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
+            forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, layer.scaling)
+        return o
+
+    @staticmethod
+    def supports_fused_qkv(layer, rotary_emb, dtype) -> bool:
+        g = layer.tp_q_head_num // max(layer.tp_k_head_num, 1)
+        return (hasattr(get_ops(), "decode_attention_fused_qkv") and layer.qk_head_dim == 128
+                and layer.v_head_dim == 128 and dtype in (torch.bfloat16, torch.float16)
+                and layer.tp_q_head_num % layer.tp_k_head_num == 0 and g in (1, 2, 4, 8)
+                and not layer.logit_cap and layer.sliding_window_size in (None, -1)
+                and rotary_emb.is_neox_style and rotary_emb.rotary_dim == 128
+                and rotary_emb.cos_sin_cache.dtype in (torch.float32, dtype))
+
     def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
         ops = get_ops()
         o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))

@@ -68,12 +68,13 @@ class SplitKPartials:
         self.shape = part.shape[1:]
 
 
-def decode_linear_deferred(layer, x: torch.Tensor):
-    """layer(x) for the TP=1 decode path, leaving the split-K reduction to the following norm; None
-    when the layer, the shape or the ops backend does not support it."""
+def decode_linear_deferred(layer, x: torch.Tensor, needs_all_reduce: bool = True):
+    """layer(x) on the decode path, leaving the split-K reduction to the kernel that consumes it; None
+    when the layer, the shape or the ops backend does not support it.  A row-parallel layer
+    (needs_all_reduce) qualifies only at TP=1: its output would have to cross ranks first."""
     fn = getattr(get_ops(), "linear_packed_partials", None)
     wp = getattr(layer, "weight_packed", None)
-    if (fn is None or wp is None or getattr(layer, "tp_size", 1) != 1 or x.dim() != 2
+    if (fn is None or wp is None or (needs_all_reduce and getattr(layer, "tp_size", 1) != 1) or x.dim() != 2
             or not 1 <= x.shape[0] <= SKINNY_MAX_M or x.stride(0) % 8 != 0
             or not isinstance(layer.quant_method, UnquantizedLinearMethod)):
         return None

@@ -77,7 +77,28 @@ class LlamaAttention(nn.Module):
         self.attn = RadixAttention(self.num_heads, self.head_dim, self.scaling,
                                    num_kv_heads=self.num_kv_heads, layer_id=layer_id)
 
+    def _fused_decode(self, positions, hidden_states, forward_batch):
+        """Decode fast path: the qkv GEMM leaves its split-K partials and ONE attention launch does
+        the reduction, RoPE, the KV-cache write and the attention.  None when it does not apply."""
+        backend = forward_batch.attn_backend
+        pool = forward_batch.token_to_kv_pool
+        if (not forward_batch.forward_mode.is_decode() or not hasattr(backend, "forward_decode_fused_qkv")
+                or getattr(pool, "dtype", None) != hidden_states.dtype
+                or not backend.supports_fused_qkv(self.attn, self.rotary_emb, hidden_states.dtype)):
+            return None
+        part = decode_linear_deferred(self.qkv_proj, hidden_states, needs_all_reduce=False)
+        if part is None:
+            return None
+        return backend.forward_decode_fused_qkv(part.part, positions, self.rotary_emb.cos_sin_cache, self.attn,
+                                                forward_batch)
+
     def forward(self, positions, hidden_states, forward_batch):
+        attn_output = self._fused_decode(positions, hidden_states, forward_batch)
+        if attn_output is not None:
+            deferred = decode_linear_deferred(self.o_proj, attn_output)
+            if deferred is not None:
+                return deferred
+            return self.o_proj(attn_output)[0]
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         pool = forward_batch.token_to_kv_pool

@@ -265,6 +265,32 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
         "decode_attention")
 
 
+def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache, k_buffer, v_buffer, o, req_to_token,
+                               req_pool_indices, seq_lens, attn_logits, attn_lse, num_kv_splits: int,
+                               sm_scale: float) -> None:
+    """Decode attention straight from the qkv GEMM's split-K partials [splits, B, (Hq + 2 Hkv) * D]:
+    sums them, applies neox RoPE to q and the new k, writes the new k / v rows into cache slot
+    out_cache_loc[b] (= req_to_token[req_pool_indices[b], seq_lens[b] - 1] for real rows) and attends.  o: [B, Hq, D]."""
+    _gpu(qkv_part, positions, cos_sin_cache, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    B, Hq, D = o.shape
+    Hkv = k_buffer.shape[1]
+    assert qkv_part.dim() == 3 and qkv_part.is_contiguous() and qkv_part.dtype == torch.float32
+    assert qkv_part.shape[1] == B and qkv_part.shape[2] == (Hq + 2 * Hkv) * D
+    assert k_buffer.is_contiguous() and v_buffer.is_contiguous() and o.is_contiguous()
+    assert k_buffer.shape[1:] == (Hkv, D) and v_buffer.shape == k_buffer.shape and k_buffer.dtype == o.dtype == v_buffer.dtype
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == B
+    assert out_cache_loc.dtype == torch.int64 and out_cache_loc.is_contiguous() and out_cache_loc.numel() == B
+    assert cos_sin_cache.is_contiguous() and cos_sin_cache.shape[1] == D
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    check(_lib_().mi355_decode_attention_fused_qkv(
+        qkv_part.data_ptr(), qkv_part.shape[0], positions.data_ptr(), out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
+        _dt(cos_sin_cache), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
+        req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0), _p(attn_logits),
+        _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _dt(o), _stream(o)),
+        "decode_attention_fused_qkv")
+
+
 def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
                          attn_lse, num_kv_splits: int, kv_lora_rank: int, sm_scale: float,
                          logit_cap: float = 0.0) -> None:

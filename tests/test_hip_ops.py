@@ -625,3 +625,57 @@ def test_deferred_splitk_reduction_is_bit_identical(ops, dtype):
         assert torch.equal(y, y1), (m, n, k, part.shape[0])
     assert ops.linear_packed_partials(torch.randn(4, 96, device="cuda", dtype=dtype),
                                       ops.pack_weight(torch.randn(64, 96, device="cuda", dtype=dtype)), 64) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,cache_dtype", [(torch.bfloat16, torch.float32), (torch.float16, torch.float16)])
+def test_fused_qkv_decode_attention_is_bit_identical(ops, dtype, cache_dtype):
+    """qkv partials -> (reduce + RoPE + KV write + attention in one launch) against the unfused
+    sequence linear_packed -> rope_inplace(with KV write) -> decode_attention_paged: outputs and both
+    caches bit-identical; ragged lengths (new key in every row / wave position of a tile), GQA 1/2/4/8,
+    split-KV on and off; padded rows (seq_len 1, sink slot) leave the real slots untouched."""
+    torch.manual_seed(2)
+    D, hidden = 128, 1024
+    for hq, hkv, bs, maxlen, splits in [(32, 8, 9, 300, 1), (8, 8, 5, 70, 1), (16, 2, 6, 530, 3), (8, 4, 4, 129, 2), (8, 1, 19, 90, 1)]:
+        n = (hq + 2 * hkv) * D
+        w = torch.randn(n, hidden, device="cuda", dtype=dtype) * 0.04
+        wp = ops.pack_weight(w)
+        x = torch.randn(bs, hidden, device="cuda", dtype=dtype)
+        lens = torch.randint(1, maxlen, (bs,), device="cuda", dtype=torch.int64)
+        lens[0] = maxlen                     # a full-length row
+        lens[-1] = 1                         # and a padded-looking one
+        for i in range(1, min(bs - 1, 6)):   # newest key on different tile rows / waves
+            lens[i] = min(17 * i + 1, maxlen)   # newest key = row i of tile i (wave i & 3)
+        slots = int(lens.sum().item()) + 8
+        perm = (torch.randperm(slots - 1, device="cuda") + 1).to(torch.int32)
+        r2t = torch.zeros(bs + 3, maxlen + 8, dtype=torch.int32, device="cuda")
+        rpi = torch.randperm(bs + 3, device="cuda")[:bs].to(torch.int64)
+        off = 0
+        for b in range(bs):
+            L = int(lens[b])
+            r2t[rpi[b], :L] = perm[off:off + L]
+            off += L
+        loc = torch.stack([r2t[rpi[b], int(lens[b]) - 1] for b in range(bs)]).to(torch.int64)
+        loc[-1] = 0                          # padded row: writes go to the sink slot, reads are replaced in registers
+        positions = lens - 1
+        cache = torch.cat([torch.randn(maxlen + 8, D // 2, device="cuda").cos(), torch.randn(maxlen + 8, D // 2, device="cuda").sin()], dim=1).to(cache_dtype).contiguous()
+        kb0 = torch.randn(slots, hkv, D, device="cuda", dtype=dtype)
+        vb0 = torch.randn(slots, hkv, D, device="cuda", dtype=dtype)
+        logits = torch.empty(bs, hq, 8, D, dtype=torch.float32, device="cuda")
+        lse = torch.empty(bs, hq, 8, dtype=torch.float32, device="cuda")
+        # unfused
+        kb, vb = kb0.clone(), vb0.clone()
+        qkv = ops.linear_packed(x, wp, n)
+        q, k, v = qkv.split([hq * D, hkv * D, hkv * D], dim=-1)
+        ops.rope_inplace(positions, q, k, D, cache, True, v=v, k_buffer=kb, v_buffer=vb, loc=loc)
+        o_ref = torch.empty(bs, hq, D, device="cuda", dtype=dtype)
+        ops.decode_attention_paged(q.reshape(bs, hq * D).contiguous().view(bs, hq, D), kb, vb, o_ref, r2t, rpi, lens, logits, lse, splits, D ** -0.5)
+        # fused
+        kb2, vb2 = kb0.clone(), vb0.clone()
+        part = ops.linear_packed_partials(x, wp, n)
+        o = torch.empty_like(o_ref)
+        ops.decode_attention_fused_qkv(part, positions, loc, cache, kb2, vb2, o, r2t, rpi, lens, logits, lse, splits, D ** -0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(kb, kb2) and torch.equal(vb, vb2), (hq, hkv)
+        # the padded row attends over its own new key only in the fused kernel; the unfused one reads the cache
+        assert torch.equal(o[:-1], o_ref[:-1]), (hq, hkv, (o[:-1].float() - o_ref[:-1].float()).abs().max().item())
