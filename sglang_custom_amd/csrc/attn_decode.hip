@@ -759,7 +759,12 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
     load_slots(1, skB, svB);
   }
   if constexpr (FUSED) reduce_qkv_to_lds();   // its loads share the page-table round trip
-  if (n_iter > 0) load_kv(skA, svA, kfA, vvA);   // first K/V tile in flight across the barrier below
+  if (n_iter > 0) {   // the first two K/V tiles are in flight across the barrier below
+    load_kv(skA, svA, kfA, vvA);
+    load_kv(skB, svB, kfB, vvB);
+    load_slots(2, skA, svA);
+    load_slots(3, skB, svB);
+  }
   if constexpr (FUSED) {
     __syncthreads();
 #pragma unroll
@@ -790,12 +795,12 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   }
   if (n_iter > 0) {
     for (int it = 0; it < n_iter; it += 2) {
-      load_kv(skB, svB, kfB, vvB);
-      load_slots(it + 2, skA, svA);
       compute(kfA, vvA, it);
-      load_kv(skA, svA, kfA, vvA);
-      load_slots(it + 3, skB, svB);
+      load_kv(skA, svA, kfA, vvA);      // tile it + 2
+      load_slots(it + 4, skA, svA);
       compute(kfB, vvB, it + 1);
+      load_kv(skB, svB, kfB, vvB);      // tile it + 3
+      load_slots(it + 5, skB, svB);
     }
   }
 
