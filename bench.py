@@ -75,7 +75,7 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
     """Average duration of the decode projection kernel (gemm_ring_kernel) over one step's worth
     of launches -- every layer's real weights in order, M = bs, through the same call the model
     makes -- bracketed by HIP events on the stream the kernels are launched on."""
-    from sglang_custom_amd.layers.quantization.unquant import decode_linear, gate_up_silu_mul
+    from sglang_custom_amd.layers.quantization.unquant import decode_linear, decode_linear_deferred, gate_up_silu_mul
 
     dev = mr.device
     layers = mr.model.model.layers
@@ -84,12 +84,18 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
     x_mlp = torch.randn(bs, layers[0].mlp.down_proj.weight.shape[1], device=dev).to(mr.dtype)
     head = mr.model.lm_head
 
+    def proj(layer, x, needs_all_reduce=True):
+        # the call the decode path makes: split-K partials left to the consuming kernel when the
+        # layer qualifies, the in-kernel combine otherwise
+        if decode_linear_deferred(layer, x, needs_all_reduce=needs_all_reduce) is None:
+            decode_linear(layer, x, None)
+
     def one_pass():
         for layer in layers:
-            decode_linear(layer.self_attn.qkv_proj, x_h, None)
-            decode_linear(layer.self_attn.o_proj, x_attn, None)
+            proj(layer.self_attn.qkv_proj, x_h, needs_all_reduce=False)
+            proj(layer.self_attn.o_proj, x_attn)
             gate_up_silu_mul(layer.mlp.gate_up_proj, layer.mlp.act_fn, x_h)
-            decode_linear(layer.mlp.down_proj, x_mlp, None)
+            proj(layer.mlp.down_proj, x_mlp)
         decode_linear(head, x_h, None, out_dtype=torch.float32)
 
     stream = torch.cuda.current_stream()

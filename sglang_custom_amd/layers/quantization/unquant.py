@@ -12,6 +12,9 @@ import torch.nn.functional as F
 from ...ops_backend import get_ops
 
 SKINNY_MAX_M = 64
+# Deferred split-K reduction / fused decode step (bit-identical to the unfused kernels; the switch
+# exists so that tests and profiles can run both).
+DECODE_FUSION = True
 
 
 def pack_for_decode(layer) -> None:
@@ -74,7 +77,7 @@ def decode_linear_deferred(layer, x: torch.Tensor, needs_all_reduce: bool = True
     (needs_all_reduce) qualifies only at TP=1: its output would have to cross ranks first."""
     fn = getattr(get_ops(), "linear_packed_partials", None)
     wp = getattr(layer, "weight_packed", None)
-    if (fn is None or wp is None or (needs_all_reduce and getattr(layer, "tp_size", 1) != 1) or x.dim() != 2
+    if (not DECODE_FUSION or fn is None or wp is None or (needs_all_reduce and getattr(layer, "tp_size", 1) != 1) or x.dim() != 2
             or not 1 <= x.shape[0] <= SKINNY_MAX_M or x.stride(0) % 8 != 0
             or not isinstance(layer.quant_method, UnquantizedLinearMethod)):
         return None

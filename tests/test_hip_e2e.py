@@ -245,3 +245,28 @@ def test_radix_prefix_cache_on_gpu_matches_isolated_generation():
     for r, m in zip(reqs, new_tokens):
         ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
         assert r.output_ids == ref_toks[0].tolist(), r.rid
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_decode_fusion_is_bit_identical_end_to_end(graphs):
+    """bf16 decode with the fused step (qkv partials -> one attention launch; o/down partials summed by
+    the norms) against the same model with every fusion switched off: logits equal bit for bit at
+    every step, KV cache contents equal."""
+    from sglang_custom_amd.layers.quantization import unquant
+
+    name, preset, dtn, lens, steps = [c for c in cases.E2E_CASES if c[2] == "bf16"][0]
+    outs = []
+    for fusion in (True, False):
+        unquant.DECODE_FUSION = fusion
+        try:
+            mr, cfg, _ = make_runner(preset, dtn, graphs)
+            prompts = cases.e2e_prompts(cfg["vocab_size"], lens)
+            toks, logits, locs, _ = run_steps(mr, prompts, steps + 3)
+            kb, vb = mr.token_to_kv_pool.get_kv_buffer(0)
+            outs.append((toks, logits, kb.clone(), vb.clone()))
+        finally:
+            unquant.DECODE_FUSION = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
