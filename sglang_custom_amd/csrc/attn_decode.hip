@@ -901,6 +901,210 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MLA decode (DeepSeek absorbed form): every query head attends over ONE shared latent row per
+// token, [kv_lora_rank 512 | rope 64] = 576 features; the value is its first 512 features.
+// Sixteen heads are exactly one MFMA tile: a workgroup takes 16 heads of one sequence (and one KV
+// split), so each 1152-byte row is read from HBM once per 16 heads and used for both products.
+//   scores: lane (key r = l & 15, c = l >> 4) loads the row straight into 18 A-fragments; the heads'
+//           queries sit in B (18 fragments, held for the whole kernel); 18 v_mfma_f32_16x16x32.
+//   values: the same fragments (features < 512) are written to the wave's row-major LDS tile; V^T
+//           comes back through transposed reads, the probabilities are already the B operand of
+//           v_mfma_f32_16x16x16 (as in the kernel above); 32 feature tiles -> O^T[512][16 heads].
+// Register budget ~400 per lane (2 x 18 row fragments, 18 query fragments, 128 accumulators): one
+// workgroup per CU, which still keeps 4 waves x 36 KiB of row loads in flight.
+// grid (ceil(hq / 16), num_splits, B), block 256.
+// ------------------------------------------------------------------------------------------
+constexpr int MLA_RANK = 512, MLA_ROPE = 64, MLA_D = MLA_RANK + MLA_ROPE;
+constexpr int MLA_ROW = MLA_RANK + 16;   // LDS row (elements): 1056 B, same bank residue as DV_ROW
+
+constexpr int MLA_QROW = MLA_D + 8;                   // query tile row in LDS: 1168 B, conflict-free b128 reads
+constexpr int MLA_V_BYTES = 4 * 16 * MLA_ROW * 2;     // four waves' value tiles (16-bit elements)
+constexpr int MLA_LDS_BYTES = MLA_V_BYTES + 16 * MLA_QROW * 2;
+static_assert(MLA_V_BYTES >= 16 * MLA_RANK * 4, "the merge buffer reuses the value tiles");
+
+template <typename T, bool CAP>
+__global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __restrict__ q,
+                                                                   const T* __restrict__ kvbuf,
+                                                                   T* __restrict__ o, DecodeParams p) {
+  constexpr int NS = MLA_D / 32;      // 18 score k-steps
+  constexpr int NDT = MLA_RANK / 16;  // 32 value feature tiles
+  using frag = typename Mfma<T>::frag;
+  using frag4 = typename Mfma16<T>::frag;
+  // the value tiles during the key loop; afterwards the cross-wave accumulator [16 heads][512]
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // MLA_LDS_BYTES (> 64 KiB: dynamic)
+  __shared__ float sm_m[4][16];
+  __shared__ float sm_l[4][16];
+
+  const int head0 = blockIdx.x * 16, split = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, c4 = lane >> 4;
+  const bool head_ok = head0 + r16 < p.hq;
+
+  int64_t page_off, len;
+  seq_range(p, b, page_off, len);
+  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t k0 = (int64_t)split * chunk;
+  const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
+  const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  // The 16 heads' queries live in LDS (rows padded to 1168 B) and are re-read per tile: 18 more
+  // fragments in registers would not fit beside two row buffers and the accumulators.
+  T* sm_q = reinterpret_cast<T*>(sm_raw + MLA_V_BYTES);
+  for (int i = threadIdx.x; i < 16 * (MLA_D / 8); i += 256) {
+    const int h = i / (MLA_D / 8), c = i % (MLA_D / 8);
+    Vec<T, 8> v;
+    if (head0 + h < p.hq) {
+      v = ldvec<T, 8>(q + (int64_t)b * p.q_stride + (int64_t)(head0 + h) * MLA_D + 8 * c);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v.v[j] = from_f32<T>(0.f);
+    }
+    stvec<T, 8>(sm_q + h * MLA_QROW + 8 * c, v);
+  }
+  __syncthreads();
+  const T* q_rd = sm_q + r16 * MLA_QROW + 8 * c4;   // + 32 s
+
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int32_t* pt = p.page_table + page_off;
+  const T* kbase = kvbuf + 8 * c4;                        // + slot * k_slot_stride + 32 s
+  const int64_t wave_first = k0 + (int64_t)wave * 16;
+  const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 63) / 64) : 0;
+  const int64_t last_key = len - 1;
+  T* my_v = reinterpret_cast<T*>(sm_raw) + wave * (16 * MLA_ROW);
+  T* v_wr = my_v + r16 * MLA_ROW + 8 * c4;                                  // + 32 s
+  const T* v_rd = my_v + (4 * c4 + (r16 >> 2)) * MLA_ROW + 4 * (r16 & 3);   // + 16 dt
+
+  auto load_slot = [&](int it) -> int32_t {
+    const int64_t key = wave_first + (int64_t)it * 64 + r16;
+    return pt[key < last_key ? key : last_key];
+  };
+  auto load_row = [&](int32_t slot, frag (&kf)[NS]) {
+    const T* krow = kbase + (int64_t)slot * p.k_slot_stride;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+  };
+  auto compute = [&](const frag (&kf)[NS], int it) {
+    f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sc = Mfma<T>::run(kf[s], *reinterpret_cast<const frag*>(q_rd + 32 * s), sc);
+    const int64_t kb0 = wave_first + (int64_t)it * 64 + 4 * c4;
+    float x[4], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = sc[r] * qmul;
+      if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
+      x[r] = kb0 + r < k1 ? v : -INFINITY;
+      mx = fmaxf(mx, x[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // Lazy rescale: the reference point m moves only when a tile's maximum exceeds it by more than
+    // 2^8 (probabilities then stay below 256 -- exact in fp32, same relative rounding in 16 bits),
+    // so the 128 accumulator registers are rescaled a handful of times per sequence, not per tile.
+    const bool need = mx > m + 8.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+      const float mnew = need ? mx : m;
+      const float alpha = exp2f(m - safe_m(mnew));
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) acc[dt] *= alpha;
+      m = mnew;
+    }
+    const float ms = safe_m(m);
+    float pr[4], psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = exp2f(x[r] - ms);
+      psum += pr[r];
+    }
+    l += psum;
+    T pt4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pt4[r] = from_f32<T>(pr[r]);
+    const frag4 pb = __builtin_bit_cast(frag4, pt4);
+#pragma unroll
+    for (int s = 0; s < MLA_RANK / 32; ++s) *reinterpret_cast<frag*>(v_wr + 32 * s) = kf[s];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const auto va = TrRead<T>::run(v_rd + 16 * dt);
+      acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, va), pb, acc[dt]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  if (n_iter > 0) {
+    frag kfA[NS], kfB[NS];
+    int32_t sA = load_slot(0), sB = load_slot(1);
+    load_row(sA, kfA);
+    load_row(sB, kfB);
+    sA = load_slot(2);
+    sB = load_slot(3);
+    for (int it = 0; it < n_iter; it += 2) {
+      compute(kfA, it);
+      load_row(sA, kfA);
+      sA = load_slot(it + 4);
+      compute(kfB, it + 1);
+      load_row(sB, kfB);
+      sB = load_slot(it + 5);
+    }
+  }
+
+  // merge the four waves: common maximum per head, then the waves add their rescaled accumulators
+  // into one fp32 tile in turn (fixed order: deterministic)
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (c4 == 0) {
+    sm_m[wave][r16] = m;
+    sm_l[wave][r16] = l;
+  }
+  __syncthreads();   // every wave is done with its value tile: sm_raw becomes the merge buffer
+  float mg = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) mg = fmaxf(mg, sm_m[w][r16]);
+  const float msg = safe_m(mg);
+  const float mine = exp2f(m - msg);
+  float lt = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) lt += sm_l[w][r16] * exp2f(sm_m[w][r16] - msg);
+  float* macc = reinterpret_cast<float*>(sm_raw);   // [16 heads][512]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        float* dst = macc + r16 * MLA_RANK + 16 * dt + 4 * c4;
+        f32x4 v = acc[dt] * mine;
+        if (w > 0) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+    __syncthreads();
+  }
+  const float inv = lt > 0.f ? 1.f / lt : 0.f;
+  if (head_ok) {
+    const int head = head0 + r16;
+    // lane (head r16, c4) writes features [128 c4 + 32 wave, + 32) of its head
+    const float* src = macc + r16 * MLA_RANK + 128 * c4 + 32 * wave;
+    if (p.num_splits == 1) {
+      T* dst = o + ((int64_t)b * p.hq + head) * MLA_RANK + 128 * c4 + 32 * wave;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) dst[i] = from_f32<T>(lt > 0.f ? src[i] / lt : 0.f);
+    } else {
+      const int64_t ph = ((int64_t)b * p.hq + head) * p.num_splits + split;
+      float* dst = p.part_o + ph * MLA_RANK + 128 * c4 + 32 * wave;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) dst[i] = lt > 0.f ? src[i] / lt : 0.f;
+      if (c4 == 0 && wave == 0) p.part_lse[ph] = lt > 0.f ? mg * kLn2 + logf(lt) : -INFINITY;
+    }
+  }
+  (void)inv;
+}
+
 // Stage 2: o[b,h,:] = sum_s w_s * part_o[b,h,s,:], w_s = exp(lse_s - lse_total).
 // grid (B*Hq), block 128.
 template <typename T>
@@ -1189,6 +1393,24 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   p.k_slot_stride = D;   // one latent row per slot; the value is its first kv_lora_rank features
   p.v_slot_stride = D;
   hipStream_t st = (hipStream_t)stream;
+  if (kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
+      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && g_decode_variant == 0) {
+    const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)num_splits, (unsigned)bs);
+#define MLA_LAUNCH(T_, CAP_)                                                                                   \
+  do {                                                                                                         \
+    auto kern = decode_attn_mla_mfma_kernel<T_, CAP_>;                                                         \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MLA_LDS_BYTES);   \
+    hipLaunchKernelGGL(kern, grid, dim3(256), MLA_LDS_BYTES, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p); \
+    if (num_splits > 1)                                                                                        \
+      hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
+                         p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
+  } while (0)
+    if (dtype == MI355_BF16) { if (logit_cap > 0.f) MLA_LAUNCH(bf16_t, true); else MLA_LAUNCH(bf16_t, false); }
+    else { if (logit_cap > 0.f) MLA_LAUNCH(f16_t, true); else MLA_LAUNCH(f16_t, false); }
+#undef MLA_LAUNCH
+    MI355_CHECK_LAUNCH("decode_attention_mla");
+    return MI355_OK;
+  }
   MI355_DISPATCH_DTYPE(dtype, "decode_attention_mla", {
     hipLaunchKernelGGL((decode_attn_generic_kernel<T>), dim3((unsigned)hq, (unsigned)num_splits, (unsigned)bs),
                        dim3(64), 0, st, (const T*)q, (const T*)kv_buffer, (const T*)kv_buffer, (T*)o, p, D,

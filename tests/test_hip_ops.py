@@ -679,3 +679,36 @@ def test_fused_qkv_decode_attention_is_bit_identical(ops, dtype, cache_dtype):
         assert torch.equal(kb, kb2) and torch.equal(vb, vb2), (hq, hkv)
         # the padded row attends over its own new key only in the fused kernel; the unfused one reads the cache
         assert torch.equal(o[:-1], o_ref[:-1]), (hq, hkv, (o[:-1].float() - o_ref[:-1].float()).abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+def test_mla_decode_mfma_kernel_shapes(ops, dtn):
+    """The 16-heads-per-tile MLA kernel: head counts that do not fill a tile, several tiles, ragged
+    lengths around the 16-key / 64-key steps, split-KV with empty splits; against float64."""
+    rank, rope = 512, 64
+    D = rank + rope
+    dt = DT[dtn]
+    for H, lens, splits in [(16, [1, 15, 16, 17, 63, 64, 65, 300], 1), (20, [129, 700], 4), (128, [1000, 3], 2), (5, [40], 8)]:
+        total = sum(lens)
+        rows = cases.randn((total + 1, 1, D), 21, dt)
+        kvb = rows.to(DEV).contiguous()
+        r2t = torch.zeros((len(lens), max(lens)), dtype=torch.int32)
+        perm = torch.randperm(total, generator=torch.Generator().manual_seed(3)) + 1
+        p = 0
+        for b, n in enumerate(lens):
+            r2t[b, :n] = perm[p: p + n].int()
+            p += n
+        rpi = torch.arange(len(lens), dtype=torch.int64)
+        q = cases.randn((len(lens), H, D), 22, dt)
+        o = torch.empty((len(lens), H, rank), dtype=dt, device=DEV)
+        lg = torch.empty(len(lens) * H * splits * rank, dtype=torch.float32, device=DEV)
+        ls = torch.empty(len(lens) * H * splits, dtype=torch.float32, device=DEV)
+        ops.decode_attention_mla(q.to(DEV), kvb, o, r2t.to(DEV), rpi.to(DEV),
+                                 torch.tensor(lens, dtype=torch.int64).to(DEV), lg, ls, splits, rank, D ** -0.5)
+        p = 0
+        for b, n in enumerate(lens):
+            kv = rows[perm[p: p + n], 0]
+            ref = ops_ref.attention_fp64(q[b][:, None], kv[None], kv[None, :, :rank], D ** -0.5, None)[:, 0]
+            assert maxdiff(o[b], ref) <= ATTN_TOL["bf16" if dtn == "bf16" else "f16"], (dtn, H, b, splits)
+            p += n

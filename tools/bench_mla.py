@@ -1,0 +1,44 @@
+"""MLA decode attention micro-benchmark (DeepSeek-V3 TP=8 shard: 16 heads, latent 512 + 64 rope)."""
+import ctypes, sys, torch
+sys.path.insert(0, '.')
+from sglang_custom_amd import ops, _lib
+lib = _lib.load()
+bs, H, ctx = 64, 16, 4096
+if len(sys.argv) > 3: bs, H, ctx = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rank, rope = 512, 64
+D = rank + rope
+NL = 3
+slots = bs * ctx + 16
+torch.manual_seed(0)
+kv = [torch.randn(slots, 1, D, device='cuda').bfloat16() for _ in range(NL)]
+q = torch.randn(bs, H, D, device='cuda').bfloat16()
+o = torch.empty(bs, H, rank, device='cuda', dtype=torch.bfloat16)
+r2t = (1 + torch.arange(bs * ctx, device='cuda', dtype=torch.int32)).view(bs, ctx).contiguous()
+rpi = torch.arange(bs, dtype=torch.int64, device='cuda')
+sl = torch.full((bs,), ctx, dtype=torch.int64, device='cuda')
+MAXS = 16
+lg = torch.empty(bs * H * MAXS * rank, dtype=torch.float32, device='cuda'); ls = torch.empty(bs * H * MAXS, dtype=torch.float32, device='cuda')
+def timeit(fn, reps=8):
+    fn(0); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(reps): fn(i)
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
+nb = min(bs, 4)
+K = kv[0][r2t[:nb].long(), 0].float()
+s = torch.einsum('bhd,bkd->bhk', q[:nb].float(), K) * D ** -0.5
+ref = torch.einsum('bhk,bkd->bhd', s.softmax(-1), K[..., :rank])
+nbytes = bs * ctx * D * 2
+for dbg in (1, 0):
+    lib.mi355_debug_set(6, dbg)   # 1 = generic wave-per-head kernel, 0 = MFMA kernel
+    for ns in (1, 2, 4, 8):
+        if dbg == 1 and ns not in (1, 4): continue
+        ops.decode_attention_mla(q, kv[0], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5)
+        err = (o[:nb].float() - ref).abs().max().item()
+        t = timeit(lambda i: ops.decode_attention_mla(q, kv[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5))
+        print(f"variant={dbg} splits={ns}: {t:7.1f} us  {nbytes / t / 1e6:5.2f} TB/s  err={err:.4f}", flush=True)
