@@ -186,8 +186,9 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
 
 /* Decode attention fused with everything between the qkv GEMM and the attention kernel.
  * qkv_part: the fp32 split-K partials [nsplit][bs][(hq + 2 hkv) * 128] of the qkv projection
- * (mi355_linear_packed_partials).  The kernel sums them (split order, one rounding to the tensor
- * dtype = the GEMM's own result), applies neox RoPE over the whole head to q and the new k with
+ * (mi355_linear_packed_partials, or mi355_fp8_packed_partials together with that GEMM's per-token
+ * and per-channel scales; both NULL otherwise).  The kernel sums them (split order, scales applied
+ * as (sum * x_scale[b]) * w_scale[n], one rounding to the tensor dtype = the GEMM's own result), applies neox RoPE over the whole head to q and the new k with
  * cos_sin_cache[positions[b]] (rounding points of mi355_rope_inplace), writes the new k / v rows to
  * slot out_cache_loc[b] (which the page table must name for position seq_len - 1, except for padding
  * rows, whose writes go to the sink slot they name), and runs mi355_decode_attention.  Output and
@@ -195,7 +196,8 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
  * mi355_decode_attention.  Needs head_dim 128, a 16-bit dtype, hq / hkv in {1, 2, 4, 8}, no logit cap.
  * replaces: LlamaAttention.forward's rotary_emb + attn sequence (models/llama.py:180-191) on the
  *           decode path; the reference has no fused counterpart. */
-int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const int64_t* positions,
+int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const float* part_x_scale,
+                                     const float* part_w_scale, const int64_t* positions,
                                      const int64_t* out_cache_loc, const void* cos_sin_cache, int cache_dtype, void* k_buffer,
                                      void* v_buffer, void* o, const int32_t* page_table, int mode,
                                      const int64_t* req_pool_indices, const int64_t* seq_lens,
@@ -258,6 +260,24 @@ int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void
  * GEMM followed by the norm; saves the GEMM's arrival ticket and second pass.  No counterpart in
  * the reference (its row-parallel GEMMs and norms are separate library calls, layers/linear.py:1277-1303,
  * layers/layernorm.py:76-78). */
+/* The same deferred reduction for the fp8 W8A8 GEMM (mi355_fp8_scaled_mm_packed): raw fp32
+ * accumulator partials [splits][m][n]; the consumer applies (sum * x_scale[m]) * w_scale[n] and
+ * rounds once.  mi355_rmsnorm_ex is the general row norm behind it: x or split-K partials (with
+ * optional fp8 scales) in, optional fused add of `residual` (updated in place), normalised rows to
+ * `out`, and optionally their per-token fp8 quantisation (q_out [rows, hidden] e4m3fn + q_scale
+ * [rows]; identical to mi355_per_token_quant_fp8 applied to `out`) for the fp8 GEMM that follows.
+ * mi355_silu_and_mul_quant_fp8 = mi355_silu_and_mul followed by mi355_per_token_quant_fp8 in one
+ * launch (the 16-bit activation is never written).
+ * replaces: apply_fp8_linear's quantise-then-GEMM pairs (layers/quantization/fp8_utils.py:676-749)
+ *           around RMSNorm / SiluAndMul on the decode path; no fused counterpart in the reference. */
+int mi355_fp8_packed_splits(int64_t m, int64_t n, int64_t k);
+int mi355_fp8_packed_partials(float* part, const uint8_t* xq, const uint8_t* wq_packed, int64_t m, int64_t n,
+                              int64_t k, void* stream);
+int mi355_rmsnorm_ex(void* out, const void* x, void* residual, const void* weight, const float* part,
+                     int nsplit, const float* part_x_scale, const float* part_w_scale, uint8_t* q_out,
+                     float* q_scale, int64_t rows, int64_t hidden, float eps, int dtype, void* stream);
+int mi355_silu_and_mul_quant_fp8(uint8_t* q_out, float* q_scale, const void* x, int64_t rows, int64_t d,
+                                 int dtype, void* stream);
 int mi355_linear_packed_splits(int64_t m, int64_t n, int64_t k);
 int mi355_linear_packed_partials(float* part, const void* x, const void* w_packed, int64_t m, int64_t n,
                                  int64_t k, int64_t x_stride, int dtype, void* stream);

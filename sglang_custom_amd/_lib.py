@@ -47,7 +47,11 @@ _SIGNATURES = {
     "mi355_debug_read_bw": (I, [P, L, I, I, P, P]),
     "mi355_debug_xcc_map": (I, [P, I, P]),
     "mi355_prefetch_next": (I, [P, L, L, L, I, L]),
-    "mi355_decode_attention_fused_qkv": (I, [P, I, P, P, P, I, P, P, P, P, I, P, P, P, L, P, P, I, L, I, I, I, L, F, I, P]),
+    "mi355_decode_attention_fused_qkv": (I, [P, I, P, P, P, P, P, I, P, P, P, P, I, P, P, P, L, P, P, I, L, I, I, I, L, F, I, P]),
+    "mi355_fp8_packed_splits": (I, [L, L, L]),
+    "mi355_fp8_packed_partials": (I, [P, P, P, L, L, L, P]),
+    "mi355_rmsnorm_ex": (I, [P, P, P, P, P, I, P, P, P, P, L, L, F, I, P]),
+    "mi355_silu_and_mul_quant_fp8": (I, [P, P, P, L, L, I, P]),
     "mi355_linear_packed_splits": (I, [L, L, L]),
     "mi355_linear_packed_partials": (I, [P, P, P, L, L, L, L, I, P]),
     "mi355_fused_add_rmsnorm_partials": (I, [P, P, P, P, I, L, L, F, I, P]),

@@ -38,6 +38,8 @@ struct FusedQkv {
   const float* part;          // [nsplit][B][row] partials of the qkv GEMM, row = (hq + 2 hkv) * 128
   int nsplit;
   int64_t split_stride, row;  // elements
+  const float* xs;            // fp8 qkv GEMM: per-token activation scales [B] and per-channel weight
+  const float* ws;            //   scales [row]; both null for a 16-bit GEMM
   const int64_t* positions;   // [B]
   const int64_t* out_loc;     // [B] cache slot of the new token (padded rows of a captured batch name the sink slot)
   const void* cos_sin;        // [max_pos][128]: cos (64) | sin (64), fp32 or the tensor dtype
@@ -615,8 +617,17 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
         sum[0] += f.x; sum[1] += f.y; sum[2] += f.z; sum[3] += f.w;
       }
       Vec<T, 4> out;
+      if (fz.xs) {   // the fp8 GEMM's epilogue: (acc * x_scale[m]) * w_scale[n], cast once
+        const float xs = fz.xs[b];
+        const float4 w4 = *reinterpret_cast<const float4*>(fz.ws + head * D + 4 * f4);
+        out.v[0] = from_f32<T>((sum[0] * xs) * w4.x);
+        out.v[1] = from_f32<T>((sum[1] * xs) * w4.y);
+        out.v[2] = from_f32<T>((sum[2] * xs) * w4.z);
+        out.v[3] = from_f32<T>((sum[3] * xs) * w4.w);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) out.v[j] = from_f32<T>(sum[j] + 0.f);
+        for (int j = 0; j < 4; ++j) out.v[j] = from_f32<T>(sum[j] + 0.f);
+      }
       stvec<T, 4>(&sm_qkv[seg * D + 4 * f4], out);
     }
     if (threadIdx.x < D) {
@@ -1290,7 +1301,8 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   return MI355_OK;
 }
 
-int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const int64_t* positions,
+int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const float* part_x_scale,
+                                     const float* part_w_scale, const int64_t* positions,
                                      const int64_t* out_cache_loc, const void* cos_sin_cache, int cache_dtype, void* k_buffer,
                                      void* v_buffer, void* o, const int32_t* page_table, int mode,
                                      const int64_t* req_pool_indices, const int64_t* seq_lens,
@@ -1315,8 +1327,10 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const in
                 "decode_attention_fused_qkv: cos_sin_cache must be fp32 or the tensor dtype");
   MI355_REQUIRE(num_splits >= 1 && num_splits <= 65535 && (num_splits == 1 || (attn_logits && attn_lse)),
                 MI355_ERR_INVALID, "decode_attention_fused_qkv: bad num_splits / missing scratch");
-  MI355_REQUIRE(aligned16(qkv_part) && aligned16(k_buffer) && aligned16(v_buffer), MI355_ERR_INVALID,
-                "decode_attention_fused_qkv: misaligned pointer");
+  MI355_REQUIRE(aligned16(qkv_part) && aligned16(k_buffer) && aligned16(v_buffer) && aligned16(part_w_scale),
+                MI355_ERR_INVALID, "decode_attention_fused_qkv: misaligned pointer");
+  MI355_REQUIRE((part_x_scale == nullptr) == (part_w_scale == nullptr), MI355_ERR_INVALID,
+                "decode_attention_fused_qkv: the fp8 scales come in pairs");
   if (bs == 0) return MI355_OK;
   DecodeParams p;
   p.page_table = page_table;
@@ -1338,6 +1352,8 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const in
   FusedQkv fz;
   fz.part = qkv_part;
   fz.nsplit = nsplit;
+  fz.xs = part_x_scale;
+  fz.ws = part_w_scale;
   fz.row = (int64_t)(hq + 2 * hkv) * head_dim;
   fz.split_stride = bs * fz.row;
   fz.positions = positions;

@@ -103,6 +103,30 @@ __host__ __device__ static inline bool aligned16(const void* p) { return (reinte
       return MI355_ERR_UNSUPPORTED;                                          \
   }
 
+// Eight values -> eight OCP e4m3fn bytes: clamp(v * inv, +-448), round to nearest even (the
+// per-token quantiser's arithmetic, python/sglang/srt/layers/quantization/fp8_kernel.py:149-152).
+template <typename T> __device__ __forceinline__ uint2 quant8_fp8(const Vec<T, 8>& v, float inv) {
+  unsigned out[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = fminf(fmaxf(to_f32(v.v[4 * h + j]) * inv, -448.0f), 448.0f);
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+    out[h] = (unsigned)pk;
+  }
+  return uint2{out[0], out[1]};
+}
+// Row maximum over a 256-thread workgroup (4 waves); `red` is 4 floats of LDS.
+__device__ __forceinline__ float block_max256(float x, float* red) {
+  x = wave_max(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 // ---- L2 warm-up of the next GEMM's packed weights --------------------------------------------
 // A kernel that leaves HBM idle (row norms, RoPE: tens of KB of traffic) can carry extra
 // workgroups that pull the head of the NEXT skinny GEMM's weight stream into L2.  L2 contents

@@ -37,7 +37,11 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
                                                           const T* __restrict__ w, int64_t hidden,
                                                           int64_t x_stride, int64_t out_stride,
                                                           float eps, WeightPrefetch pf, int pf_wgs,
-                                                          const float* __restrict__ part, int nsplit) {
+                                                          const float* __restrict__ part, int nsplit,
+                                                          const float* __restrict__ part_xs,
+                                                          const float* __restrict__ part_ws,
+                                                          uint8_t* __restrict__ q_out,
+                                                          float* __restrict__ q_scale) {
   constexpr int VE = V16<T>::n;
   __shared__ float red[16];
   if ((int)blockIdx.x < pf_wgs) {   // warm-up riders come first so they keep the GEMM's XCD mapping
@@ -79,8 +83,14 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
             sum[j4] += f.x; sum[j4 + 1] += f.y; sum[j4 + 2] += f.z; sum[j4 + 3] += f.w;
           }
         }
+        if (part_xs) {   // partials of an fp8 GEMM: (acc * x_scale[m]) * w_scale[n], its own epilogue
+          const float xs = part_xs[row];
 #pragma unroll
-        for (int j = 0; j < VE; ++j) a.v[j] = from_f32<T>(sum[j] + 0.f);
+          for (int j = 0; j < VE; ++j) a.v[j] = from_f32<T>((sum[j] * xs) * part_ws[(int64_t)vi * VE + j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VE; ++j) a.v[j] = from_f32<T>(sum[j] + 0.f);
+        }
       } else {
         a = ldvec<T, VE>(xr + (int64_t)vi * VE);
       }
@@ -104,14 +114,33 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
   }
   ss = block_sum(ss, red);
   const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  Vec<T, VE> ov[CHUNKS];
+  float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
     const int vi = threadIdx.x + c * 256;
     if (vi < nvec) {
-      Vec<T, VE> o;
 #pragma unroll
-      for (int j = 0; j < VE; ++j) o.v[j] = from_f32<T>((vals[c][j] * inv) * to_f32(wv[c].v[j]));
-      stvec<T, VE>(orow + (int64_t)vi * VE, o);
+      for (int j = 0; j < VE; ++j) {
+        ov[c].v[j] = from_f32<T>((vals[c][j] * inv) * to_f32(wv[c].v[j]));
+        amax = fmaxf(amax, fabsf(to_f32(ov[c].v[j])));
+      }
+      stvec<T, VE>(orow + (int64_t)vi * VE, ov[c]);
+    }
+  }
+  if constexpr (VE == 8) {
+    if (q_out) {
+      // per-token fp8 quantisation of the normalised row, for the fp8 GEMM that consumes it
+      // (same arithmetic as per_token_quant_fp8 on the stored 16-bit row)
+      amax = block_max256(amax, red);
+      const float s = fmaxf(amax, 1e-10f) / 448.0f;
+      const float qinv = 1.0f / s;
+      if (threadIdx.x == 0) q_scale[row] = s;
+#pragma unroll
+      for (int c = 0; c < CHUNKS; ++c) {
+        const int vi = threadIdx.x + c * 256;
+        if (vi < nvec) *reinterpret_cast<uint2*>(q_out + row * hidden + (int64_t)vi * 8) = quant8_fp8<T>(ov[c], qinv);
+      }
     }
   }
 }
@@ -166,14 +195,16 @@ __global__ __launch_bounds__(256) void fused_add_rmsnorm_generic_kernel(T* __res
 template <typename T, bool ADD>
 static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, int64_t hidden,
                           int64_t x_stride, int64_t out_stride, float eps, hipStream_t st,
-                          const float* part = nullptr, int nsplit = 0) {
+                          const float* part = nullptr, int nsplit = 0, const float* part_xs = nullptr,
+                          const float* part_ws = nullptr, uint8_t* q_out = nullptr, float* q_scale = nullptr) {
   constexpr int VE = V16<T>::n;
   const bool vec_ok = hidden % VE == 0 && x_stride % VE == 0 && out_stride % VE == 0 &&
                       aligned16(out) && aligned16(x) && aligned16(w) &&
                       (!ADD || aligned16(residual));
   const int64_t nvec = hidden / VE;
   dim3 grid((unsigned)rows), block(256);
-  if (part && !(vec_ok && nvec <= 256 * 8 && VE % 4 == 0)) return MI355_ERR_UNSUPPORTED;
+  if ((part || q_out) && !(vec_ok && nvec <= 256 * 8 && VE % 4 == 0)) return MI355_ERR_UNSUPPORTED;
+  if (q_out && VE != 8) return MI355_ERR_UNSUPPORTED;
   if (vec_ok && nvec <= 256 * 8) {
     const int chunks = (int)((nvec + 255) / 256);
     WeightPrefetch pf;
@@ -181,7 +212,7 @@ static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, i
     grid.x += pf_wgs;
 #define LAUNCH(C)                                                                              \
   hipLaunchKernelGGL((rmsnorm_vec_kernel<T, ADD, C>), grid, block, 0, st, out, x, residual, w, \
-                     hidden, x_stride, out_stride, eps, pf, pf_wgs, part, nsplit)
+                     hidden, x_stride, out_stride, eps, pf, pf_wgs, part, nsplit, part_xs, part_ws, q_out, q_scale)
     if (chunks <= 1) LAUNCH(1);
     else if (chunks <= 2) LAUNCH(2);
     else if (chunks <= 4) LAUNCH(4);
@@ -215,6 +246,44 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(T* __restrict__ out,
 #pragma unroll
     for (int j = 0; j < VE; ++j) o.v[j] = silu_mul_one<T>(a.v[j], b.v[j]);
     stvec<T, VE>(out + r * d + c, o);
+  }
+}
+
+// SiLU-and-mul fused with the per-token fp8 quantisation of its output (the activation of an fp8
+// down projection): one workgroup per row, the row stays in registers between the activation, the
+// absmax and the conversion.  d % 8 == 0, d <= 16384.  Same values as silu_and_mul followed by
+// per_token_quant_fp8 on its 16-bit output.
+template <typename T>
+__global__ __launch_bounds__(256) void silu_mul_quant_fp8_kernel(uint8_t* __restrict__ q_out,
+                                                                 float* __restrict__ q_scale,
+                                                                 const T* __restrict__ x, int64_t d) {
+  constexpr int MAXV = 8;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const T* g = x + row * 2 * d;
+  const int nvec = (int)(d >> 3);
+  Vec<T, 8> o[MAXV];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    if (idx < nvec) {
+      const Vec<T, 8> a = ldvec<T, 8>(g + (int64_t)idx * 8), b = ldvec<T, 8>(g + d + (int64_t)idx * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[i].v[j] = silu_mul_one<T>(a.v[j], b.v[j]);
+        amax = fmaxf(amax, fabsf(to_f32(o[i].v[j])));
+      }
+    }
+  }
+  amax = block_max256(amax, red);
+  const float s = fmaxf(amax, 1e-10f) / 448.0f;
+  const float inv = 1.0f / s;
+  if (threadIdx.x == 0) q_scale[row] = s;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    if (idx < nvec) *reinterpret_cast<uint2*>(q_out + row * d + (int64_t)idx * 8) = quant8_fp8<T>(o[i], inv);
   }
 }
 
@@ -455,6 +524,58 @@ int mi355_fused_add_rmsnorm_partials(void* x, void* residual, const void* weight
   MI355_REQUIRE(rc == MI355_OK, MI355_ERR_UNSUPPORTED,
                 "fused_add_rmsnorm_partials: needs hidden %% 8 == 0, hidden <= 16384 and 16-B aligned pointers");
   MI355_CHECK_LAUNCH("fused_add_rmsnorm_partials");
+  return MI355_OK;
+}
+
+int mi355_rmsnorm_ex(void* out, const void* x, void* residual, const void* weight, const float* part,
+                     int nsplit, const float* part_x_scale, const float* part_w_scale, uint8_t* q_out,
+                     float* q_scale, int64_t rows, int64_t hidden, float eps, int dtype, void* stream) {
+  MI355_REQUIRE(out && weight && (x || part), MI355_ERR_INVALID, "rmsnorm_ex: null pointer");
+  MI355_REQUIRE(rows >= 0 && hidden > 0, MI355_ERR_INVALID, "rmsnorm_ex: bad shape");
+  MI355_REQUIRE(!part || (nsplit >= 1 && nsplit <= 64 && aligned16(part)), MI355_ERR_INVALID,
+                "rmsnorm_ex: bad partials (nsplit=%d)", nsplit);
+  MI355_REQUIRE((part_x_scale == nullptr) == (part_w_scale == nullptr) && (!part_x_scale || part), MI355_ERR_INVALID,
+                "rmsnorm_ex: scales come in pairs and only with partials");
+  MI355_REQUIRE((q_out == nullptr) == (q_scale == nullptr), MI355_ERR_INVALID, "rmsnorm_ex: q_out and q_scale come together");
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "rmsnorm_ex: only 16-bit dtypes");
+  MI355_REQUIRE(!q_out || (reinterpret_cast<uintptr_t>(q_out) & 7) == 0, MI355_ERR_INVALID, "rmsnorm_ex: misaligned q_out");
+  if (rows == 0) return MI355_OK;
+  int rc = MI355_OK;
+  const void* xin = x ? x : out;
+  if (residual) {
+    MI355_DISPATCH_DTYPE(dtype, "rmsnorm_ex",
+                         rc = launch_rmsnorm<T, true>((T*)out, (T*)xin, (T*)residual, (const T*)weight, rows, hidden, hidden,
+                                                      hidden, eps, (hipStream_t)stream, part, nsplit, part_x_scale,
+                                                      part_w_scale, q_out, q_scale));
+  } else {
+    MI355_DISPATCH_DTYPE(dtype, "rmsnorm_ex",
+                         rc = launch_rmsnorm<T, false>((T*)out, (T*)xin, nullptr, (const T*)weight, rows, hidden, hidden,
+                                                       hidden, eps, (hipStream_t)stream, part, nsplit, part_x_scale,
+                                                       part_w_scale, q_out, q_scale));
+  }
+  MI355_REQUIRE(rc == MI355_OK, MI355_ERR_UNSUPPORTED,
+                "rmsnorm_ex: needs hidden %% 8 == 0, hidden <= 16384 and 16-B aligned pointers");
+  MI355_CHECK_LAUNCH("rmsnorm_ex");
+  return MI355_OK;
+}
+
+int mi355_silu_and_mul_quant_fp8(uint8_t* q_out, float* q_scale, const void* x, int64_t rows, int64_t d,
+                                 int dtype, void* stream) {
+  MI355_REQUIRE(q_out && q_scale && x, MI355_ERR_INVALID, "silu_and_mul_quant_fp8: null pointer");
+  MI355_REQUIRE(rows >= 0 && d > 0 && d % 8 == 0 && d <= 16384, MI355_ERR_UNSUPPORTED,
+                "silu_and_mul_quant_fp8: needs d %% 8 == 0 and d <= 16384 (d=%lld)", (long long)d);
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
+                "silu_and_mul_quant_fp8: only 16-bit dtypes");
+  MI355_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(q_out) & 7) == 0, MI355_ERR_INVALID,
+                "silu_and_mul_quant_fp8: misaligned pointer");
+  if (rows == 0) return MI355_OK;
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                       q_out, q_scale, (const bf16_t*)x, d);
+  else
+    hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                       q_out, q_scale, (const f16_t*)x, d);
+  MI355_CHECK_LAUNCH("silu_and_mul_quant_fp8");
   return MI355_OK;
 }
 

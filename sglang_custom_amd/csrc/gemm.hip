@@ -365,11 +365,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   };
 
   const int splits = gridDim.y;
-  if constexpr (!ACT && !FP8) {
+  if constexpr (!ACT) {
     if (y == nullptr) {
       // Deferred reduction: this split's fp32 partial goes out row-major, [split][M][N], and the
-      // CONSUMER kernel sums the splits (in split order, then rounds once -- the same arithmetic as
-      // the combine below).  No ticket, no second pass here; the kernel boundary publishes the data.
+      // CONSUMER kernel sums the splits (in split order, applies the fp8 scales if any, then rounds
+      // once -- the same arithmetic as the combine below).  No ticket, no second pass here; the kernel boundary publishes the data.
       float* part = slab + (int64_t)blockIdx.y * M * N;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -750,9 +750,15 @@ static SkinnyPlan plan_fp8(int64_t m, int64_t n, int64_t k) {
 
 template <typename OUT, int MT>
 static void launch_fp8_mt(const fp8_t* x, const fp8_t* w, const void* bias, OUT* y, char* ws, int M, int N,
-                          int K, const SkinnyPlan& p, const float* xs, const float* wsc, hipStream_t st) {
+                          int K, const SkinnyPlan& p, const float* xs, const float* wsc, hipStream_t st,
+                          float* part = nullptr) {
   unsigned* counters = p.splits > 1 ? reinterpret_cast<unsigned*>(ws) : nullptr;
   float* slab = p.splits > 1 ? reinterpret_cast<float*>(ws + p.counter_bytes) : nullptr;
+  if (part) {   // deferred reduction: raw fp32 accumulator sums out, scales applied by the consumer
+    counters = nullptr;
+    slab = part;
+    y = nullptr;
+  }
 #define F8R(W_) launch_ring<fp8_t, MT, 1, OUT, true, W_>(x, w, bias, y, slab, counters, M, N, K, K, p, st, xs, wsc)
   if (p.waves == 8) F8R(8); else if (p.waves == 7) F8R(7); else if (p.waves == 6) F8R(6); else F8R(4);
 #undef F8R
@@ -760,12 +766,12 @@ static void launch_fp8_mt(const fp8_t* x, const fp8_t* w, const void* bias, OUT*
 
 template <typename OUT>
 static void launch_fp8(const fp8_t* x, const fp8_t* w, const void* bias, OUT* y, char* ws, int M, int N, int K,
-                       const float* xs, const float* wsc, hipStream_t st) {
+                       const float* xs, const float* wsc, hipStream_t st, float* part = nullptr) {
   const SkinnyPlan p = plan_fp8(M, N, K);
   const int mt = (M + 15) / 16;
-  if (mt <= 1) launch_fp8_mt<OUT, 1>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st);
-  else if (mt <= 2) launch_fp8_mt<OUT, 2>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st);
-  else launch_fp8_mt<OUT, 4>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st);
+  if (mt <= 1) launch_fp8_mt<OUT, 1>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st, part);
+  else if (mt <= 2) launch_fp8_mt<OUT, 2>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st, part);
+  else launch_fp8_mt<OUT, 4>(x, w, bias, y, ws, M, N, K, p, xs, wsc, st, part);
 }
 
 }  // namespace mi355
@@ -959,6 +965,27 @@ int mi355_fp8_scaled_mm_packed(void* y, const uint8_t* xq, const uint8_t* wq_pac
     default: set_error("fp8_scaled_mm_packed: unsupported out dtype %d", out_dtype); return MI355_ERR_UNSUPPORTED;
   }
   MI355_CHECK_LAUNCH("fp8_scaled_mm_packed");
+  return MI355_OK;
+}
+
+int mi355_fp8_packed_splits(int64_t m, int64_t n, int64_t k) {
+  if (m < 1 || m > 64 || n < 1 || n >= 64 * 1024 || k < 512 || k % 512 != 0 || g_gemm_variant != 0) return 0;
+  return plan_fp8(m, n, k).splits;
+}
+
+int mi355_fp8_packed_partials(float* part, const uint8_t* xq, const uint8_t* wq_packed, int64_t m, int64_t n,
+                              int64_t k, void* stream) {
+  MI355_REQUIRE(part && xq && wq_packed, MI355_ERR_INVALID, "fp8_packed_partials: null pointer");
+  MI355_REQUIRE(m >= 0 && m <= 64 && n > 0 && k > 0, MI355_ERR_INVALID,
+                "fp8_packed_partials: needs 0 <= M <= 64 (m=%lld n=%lld k=%lld)", (long long)m, (long long)n, (long long)k);
+  MI355_REQUIRE(mi355_fp8_packed_splits(m > 0 ? m : 1, n, k) > 0, MI355_ERR_UNSUPPORTED,
+                "fp8_packed_partials: needs K %% 512 == 0 and N < 65536 (k=%lld n=%lld)", (long long)k, (long long)n);
+  MI355_REQUIRE(aligned16(xq) && aligned16(wq_packed) && aligned16(part), MI355_ERR_INVALID,
+                "fp8_packed_partials: misaligned pointer");
+  if (m == 0) return MI355_OK;
+  launch_fp8<bf16_t>(xq, wq_packed, nullptr, nullptr, nullptr, (int)m, (int)n, (int)k, nullptr, nullptr,
+                     (hipStream_t)stream, part);
+  MI355_CHECK_LAUNCH("fp8_packed_partials");
   return MI355_OK;
 }
 

@@ -267,7 +267,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
 
 def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache, k_buffer, v_buffer, o, req_to_token,
                                req_pool_indices, seq_lens, attn_logits, attn_lse, num_kv_splits: int,
-                               sm_scale: float) -> None:
+                               sm_scale: float, part_x_scale=None, part_w_scale=None) -> None:
     """Decode attention straight from the qkv GEMM's split-K partials [splits, B, (Hq + 2 Hkv) * D]:
     sums them, applies neox RoPE to q and the new k, writes the new k / v rows into cache slot
     out_cache_loc[b] (= req_to_token[req_pool_indices[b], seq_lens[b] - 1] for real rows) and attends.  o: [B, Hq, D]."""
@@ -283,8 +283,12 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
     assert cos_sin_cache.is_contiguous() and cos_sin_cache.shape[1] == D
     assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
     assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    if part_x_scale is not None:   # partials of an fp8 GEMM: its per-token / per-channel scales
+        assert part_x_scale.dtype == part_w_scale.dtype == torch.float32 and part_x_scale.numel() == B
+        assert part_w_scale.numel() == qkv_part.shape[2] and part_x_scale.is_contiguous() and part_w_scale.is_contiguous()
     check(_lib_().mi355_decode_attention_fused_qkv(
-        qkv_part.data_ptr(), qkv_part.shape[0], positions.data_ptr(), out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
+        qkv_part.data_ptr(), qkv_part.shape[0], _p(part_x_scale), _p(part_w_scale), positions.data_ptr(),
+        out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
         _dt(cos_sin_cache), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0), _p(attn_logits),
         _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _dt(o), _stream(o)),
@@ -446,6 +450,65 @@ def fused_add_rmsnorm_partials(part: torch.Tensor, residual: torch.Tensor, weigh
                                                        float(eps), _dt(residual), _stream(residual)),
               "fused_add_rmsnorm_partials")
     return x
+
+
+def fp8_packed_partials(xq: torch.Tensor, wq_packed: torch.Tensor, n: int) -> Optional[torch.Tensor]:
+    """fp8 x fp8 GEMM of fp8_scaled_mm_packed left as raw fp32 split-K partials [splits, M, N]; the
+    consumer applies (sum * x_scale[m]) * w_scale[n].  None when the shape is not served."""
+    _gpu(xq, wq_packed)
+    assert xq.dim() == 2 and xq.is_contiguous() and xq.dtype == torch.float8_e4m3fn
+    m, k = xq.shape
+    splits = _lib_().mi355_fp8_packed_splits(max(m, 1), n, k)
+    if splits <= 0 or m > 64:
+        return None
+    part = torch.empty((splits, m, n), dtype=torch.float32, device=xq.device)
+    if m:
+        check(_lib_().mi355_fp8_packed_partials(part.data_ptr(), xq.data_ptr(), wq_packed.data_ptr(), m, n, k,
+                                                _stream(xq)), "fp8_packed_partials")
+    return part
+
+
+def rmsnorm_ex(weight: torch.Tensor, eps: float, x: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, part: Optional[torch.Tensor] = None,
+               part_x_scale: Optional[torch.Tensor] = None, part_w_scale: Optional[torch.Tensor] = None,
+               quant_fp8: bool = False):
+    """General decode row norm: input x or split-K partials [splits, M, hidden] (with the fp8 GEMM's
+    scales when they come from one), optional fused add of residual (updated in place), and optionally
+    the per-token fp8 quantisation of the result.  Returns (out, xq or None, x_scale or None)."""
+    src = part if part is not None else x
+    _gpu(src, weight, residual)
+    rows, hidden = (part.shape[1], part.shape[2]) if part is not None else x.shape
+    dt = weight.dtype
+    out = torch.empty((rows, hidden), dtype=dt, device=weight.device)
+    if part is not None:
+        assert part.is_contiguous() and part.dtype == torch.float32
+    else:
+        assert x.is_contiguous() and x.dtype == dt
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == (rows, hidden) and residual.dtype == dt
+    xq = xs = None
+    if quant_fp8:
+        xq = torch.empty((rows, hidden), dtype=torch.float8_e4m3fn, device=weight.device)
+        xs = torch.empty((rows, 1), dtype=torch.float32, device=weight.device)
+    if rows:
+        check(_lib_().mi355_rmsnorm_ex(out.data_ptr(), _p(x), _p(residual), weight.data_ptr(), _p(part),
+                                       part.shape[0] if part is not None else 0, _p(part_x_scale), _p(part_w_scale),
+                                       _p(xq), _p(xs), rows, hidden, float(eps), _dt(weight), _stream(weight)),
+              "rmsnorm_ex")
+    return out, xq, xs
+
+
+def silu_and_mul_quant_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """per_token_quant_fp8(silu_and_mul(x)) in one launch: x [M, 2d] 16-bit -> (e4m3fn [M, d], scale [M, 1])."""
+    _gpu(x)
+    assert x.dim() == 2 and x.is_contiguous() and x.shape[1] % 2 == 0
+    m, d = x.shape[0], x.shape[1] // 2
+    xq = torch.empty((m, d), dtype=torch.float8_e4m3fn, device=x.device)
+    xs = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    if m:
+        check(_lib_().mi355_silu_and_mul_quant_fp8(xq.data_ptr(), xs.data_ptr(), x.data_ptr(), m, d, _dt(x),
+                                                   _stream(x)), "silu_and_mul_quant_fp8")
+    return xq, xs
 
 
 def prefetch_next(weight_packed: torch.Tensor, m: int, n: int, k: int, budget_bytes: int = 24 << 20) -> None:

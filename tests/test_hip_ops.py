@@ -712,3 +712,54 @@ def test_mla_decode_mfma_kernel_shapes(ops, dtn):
             ref = ops_ref.attention_fp64(q[b][:, None], kv[None], kv[None, :, :rank], D ** -0.5, None)[:, 0]
             assert maxdiff(o[b], ref) <= ATTN_TOL["bf16" if dtn == "bf16" else "f16"], (dtn, H, b, splits)
             p += n
+
+
+@pytest.mark.gpu
+def test_fp8_fused_producers_and_deferred_reduction_are_bit_identical(ops):
+    """The fp8 decode fusions against the unfused launches they replace, bit for bit:
+    rmsnorm_ex(quant) == (fused_add_)rmsnorm -> per_token_quant_fp8; silu_and_mul_quant_fp8 ==
+    silu_and_mul -> per_token_quant_fp8; fp8_packed_partials + rmsnorm_ex(partials, scales) ==
+    fp8_scaled_mm_packed -> fused_add_rmsnorm."""
+    torch.manual_seed(4)
+    dt = torch.bfloat16
+    for m, hidden in [(64, 4096), (3, 1024), (17, 2048)]:
+        x = torch.randn(m, hidden, device="cuda", dtype=dt)
+        res = torch.randn(m, hidden, device="cuda", dtype=dt)
+        g = torch.randn(hidden, device="cuda", dtype=dt)
+        # plain norm + quant
+        y0 = ops.rmsnorm(x, g, 1e-5)
+        q0, s0 = ops.per_token_quant_fp8(y0)
+        y1, q1, s1 = ops.rmsnorm_ex(g, 1e-5, x=x, quant_fp8=True)
+        assert torch.equal(y0, y1) and torch.equal(q0.view(torch.uint8), q1.view(torch.uint8)) and torch.equal(s0, s1)
+        # fused add + norm + quant
+        xa, ra = x.clone(), res.clone()
+        ops.fused_add_rmsnorm(xa, ra, g, 1e-5)
+        qa, sa = ops.per_token_quant_fp8(xa)
+        rb = res.clone()
+        yb, qb, sb = ops.rmsnorm_ex(g, 1e-5, x=x, residual=rb, quant_fp8=True)
+        assert torch.equal(xa, yb) and torch.equal(ra, rb)
+        assert torch.equal(qa.view(torch.uint8), qb.view(torch.uint8)) and torch.equal(sa, sb)
+    for m, d in [(64, 14336), (5, 1536), (1, 8)]:
+        x = torch.randn(m, 2 * d, device="cuda", dtype=dt)
+        q0, s0 = ops.per_token_quant_fp8(ops.silu_and_mul(x))
+        q1, s1 = ops.silu_and_mul_quant_fp8(x)
+        assert torch.equal(q0.view(torch.uint8), q1.view(torch.uint8)) and torch.equal(s0, s1)
+    from sglang_custom_amd.layers.quantization.w8a8_fp8 import quantize_weight_per_channel
+    for m, n, k in [(64, 4096, 4096), (64, 4096, 14336), (9, 2048, 1024), (33, 1208, 512)]:
+        wq, wsc = quantize_weight_per_channel(torch.randn(n, k, device="cuda") * 0.05)
+        wp = ops.pack_weight_fp8(wq.contiguous())
+        xq, xs = ops.per_token_quant_fp8(torch.randn(m, k, device="cuda", dtype=dt))
+        res = torch.randn(m, n, device="cuda", dtype=dt)
+        g = torch.randn(n, device="cuda", dtype=dt)
+        y = ops.fp8_scaled_mm_packed(xq, wp, n, xs, wsc.contiguous(), dt)
+        r0 = res.clone()
+        ops.fused_add_rmsnorm(y, r0, g, 1e-5)
+        q0, s0 = ops.per_token_quant_fp8(y)
+        part = ops.fp8_packed_partials(xq, wp, n)
+        assert part is not None
+        r1 = res.clone()
+        y1, q1, s1 = ops.rmsnorm_ex(g, 1e-5, residual=r1, part=part, part_x_scale=xs, part_w_scale=wsc.contiguous(),
+                                    quant_fp8=True)
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1) and torch.equal(y, y1), (m, n, k, part.shape[0])
+        assert torch.equal(q0.view(torch.uint8), q1.view(torch.uint8)) and torch.equal(s0, s1)
