@@ -127,7 +127,8 @@ class Mi355AttnBackend(AttentionBackend):
             layer.scaling, layer.logit_cap)
         return o
 
-    def forward_decode_fused_qkv(self, qkv_part, positions, cos_sin_cache, layer, forward_batch):
+    def forward_decode_fused_qkv(self, qkv_part, positions, cos_sin_cache, layer, forward_batch,
+                                 part_x_scale=None, part_w_scale=None):
         """Decode step from the qkv GEMM's split-K partials: reduction, RoPE, KV-cache write and
         attention in one launch (ops.decode_attention_fused_qkv).  Same result as rotary_emb +
         forward_decode(save_kv_cache=True) on the reduced projection."""
@@ -140,7 +141,8 @@ class Mi355AttnBackend(AttentionBackend):
             pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
-            forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, layer.scaling)
+            forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, layer.scaling,
+            part_x_scale=part_x_scale, part_w_scale=part_w_scale)
         return o
 
     @staticmethod

@@ -9,7 +9,7 @@ from torch import nn
 
 from ..custom_op import CustomOp
 from ..ops_backend import get_ops
-from .quantization.unquant import SplitKPartials
+from .quantization.unquant import QuantizedAct, SplitKPartials
 
 
 class RMSNorm(CustomOp):
@@ -19,13 +19,25 @@ class RMSNorm(CustomOp):
         self.variance_epsilon = eps
 
     def forward_hip(
-        self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
+        self, x, residual: Optional[torch.Tensor] = None, quant_fp8: bool = False
     ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        """x: a tensor, or the SplitKPartials of the GEMM that produced it (summed here).
+        quant_fp8: also quantise the normalised rows per token for an fp8 GEMM -- the result is then
+        a QuantizedAct (decode-sized inputs only; callers check the ops backend supports it)."""
         ops = get_ops()
-        if isinstance(x, SplitKPartials):
-            # the producing GEMM left its split-K partials for this kernel to sum
-            assert residual is not None
-            return ops.fused_add_rmsnorm_partials(x.part, residual, self.weight.data, self.variance_epsilon), residual
+        if isinstance(x, SplitKPartials) or quant_fp8:
+            part = x if isinstance(x, SplitKPartials) else None
+            assert part is None or residual is not None
+            if part is not None and not quant_fp8 and part.x_scale is None:
+                return ops.fused_add_rmsnorm_partials(part.part, residual, self.weight.data, self.variance_epsilon), residual
+            dense = None if part is not None else (x if x.is_contiguous() else x.contiguous())
+            out, xq, xs = ops.rmsnorm_ex(self.weight.data, self.variance_epsilon, x=dense, residual=residual,
+                                         part=part.part if part is not None else None,
+                                         part_x_scale=part.x_scale if part is not None else None,
+                                         part_w_scale=part.w_scale if part is not None else None,
+                                         quant_fp8=quant_fp8)
+            y = QuantizedAct(xq, xs, out.dtype, out) if quant_fp8 else out
+            return (y, residual) if residual is not None else y
         if not x.is_contiguous():
             x = x.contiguous()
         if residual is not None:

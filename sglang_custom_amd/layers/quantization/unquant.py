@@ -63,25 +63,57 @@ def gate_up_silu_mul(layer, act_fn, x: torch.Tensor) -> torch.Tensor:
 
 
 class SplitKPartials:
-    """Output of a row-parallel decode GEMM whose split-K partials ([splits, M, N] fp32) are still
-    to be summed -- by the fused add + RMSNorm that consumes it (RMSNorm.forward accepts it as x)."""
+    """Output of a decode GEMM whose split-K partials ([splits, M, N] fp32) are still to be summed
+    -- by the kernel that consumes it (the fused add + RMSNorm, or the fused decode attention).
+    x_scale / w_scale: the fp8 GEMM's per-token and per-channel scales (None for a 16-bit GEMM)."""
 
-    def __init__(self, part: torch.Tensor):
+    def __init__(self, part: torch.Tensor, x_scale=None, w_scale=None):
         self.part = part
+        self.x_scale = x_scale
+        self.w_scale = w_scale
         self.shape = part.shape[1:]
 
 
-def decode_linear_deferred(layer, x: torch.Tensor, needs_all_reduce: bool = True):
+class QuantizedAct:
+    """A decode activation that already went through per-token fp8 quantisation inside the kernel
+    that produced it (row norm, SiLU-mul): xq [M, K] e4m3fn, x_scale [M, 1]; `dense` is the 16-bit
+    tensor when the producer also wrote it (None otherwise)."""
+
+    def __init__(self, xq: torch.Tensor, x_scale: torch.Tensor, dtype: torch.dtype,
+                 dense: Optional[torch.Tensor] = None):
+        self.xq = xq
+        self.x_scale = x_scale
+        self.dtype = dtype      # the activation dtype of the model (output dtype of the GEMM that follows)
+        self.dense = dense
+        self.shape = xq.shape
+
+
+def decode_linear_deferred(layer, x, needs_all_reduce: bool = True):
     """layer(x) on the decode path, leaving the split-K reduction to the kernel that consumes it; None
     when the layer, the shape or the ops backend does not support it.  A row-parallel layer
-    (needs_all_reduce) qualifies only at TP=1: its output would have to cross ranks first."""
-    fn = getattr(get_ops(), "linear_packed_partials", None)
+    (needs_all_reduce) qualifies only at TP=1: its output would have to cross ranks first.  x is a
+    [M, K] tensor or, for an fp8 layer, a QuantizedAct."""
+    from .w8a8_fp8 import W8A8Fp8LinearMethod
+
+    ops = get_ops()
     wp = getattr(layer, "weight_packed", None)
-    if (not DECODE_FUSION or fn is None or wp is None or (needs_all_reduce and getattr(layer, "tp_size", 1) != 1) or x.dim() != 2
-            or not 1 <= x.shape[0] <= SKINNY_MAX_M or x.stride(0) % 8 != 0
-            or not isinstance(layer.quant_method, UnquantizedLinearMethod)):
+    if (not DECODE_FUSION or wp is None or (needs_all_reduce and getattr(layer, "tp_size", 1) != 1)
+            or len(x.shape) != 2 or not 1 <= x.shape[0] <= SKINNY_MAX_M):
         return None
-    part = fn(x, wp, layer.weight.shape[0])
+    n = layer.weight.shape[0]
+    if isinstance(layer.quant_method, W8A8Fp8LinearMethod):
+        if not hasattr(ops, "fp8_packed_partials"):
+            return None
+        if isinstance(x, QuantizedAct):
+            xq, xs = x.xq, x.x_scale
+        else:
+            xq, xs = ops.per_token_quant_fp8(x)
+        part = ops.fp8_packed_partials(xq, wp, n)
+        return None if part is None else SplitKPartials(part, xs, layer.weight_scale.data)
+    if (isinstance(x, QuantizedAct) or not isinstance(layer.quant_method, UnquantizedLinearMethod)
+            or not hasattr(ops, "linear_packed_partials") or x.stride(0) % 8 != 0):
+        return None
+    part = ops.linear_packed_partials(x, wp, n)
     return None if part is None else SplitKPartials(part)
 
 

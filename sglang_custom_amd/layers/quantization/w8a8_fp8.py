@@ -63,7 +63,16 @@ class W8A8Fp8LinearMethod:
             layer.weight_packed = get_ops().pack_weight_fp8(w.data)
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        from .unquant import QuantizedAct
+
         ops = get_ops()
+        if isinstance(x, QuantizedAct):   # quantised by the kernel that produced it (decode path)
+            xq, xs = x.xq, x.x_scale
+            out_dtype = x.dtype
+            wp = getattr(layer, "weight_packed", None)
+            if wp is not None and xq.shape[0] <= SKINNY_MAX_M:
+                return ops.fp8_scaled_mm_packed(xq, wp, layer.weight.shape[0], xs, layer.weight_scale, out_dtype, bias)
+            return ops.fp8_scaled_mm(xq, layer.weight, xs, layer.weight_scale, out_dtype, bias)
         x2 = x.view(-1, x.shape[-1])
         xq, xs = ops.per_token_quant_fp8(x2)
         y = None

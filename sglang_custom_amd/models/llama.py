@@ -19,13 +19,17 @@ from ..layers.layernorm import RMSNorm
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from ..layers.logits_processor import LogitsProcessor
 from ..layers.quantization.unquant import (
+    QuantizedAct,
+    SKINNY_MAX_M,
     UnquantizedLinearMethod,
     decode_linear_deferred,
     gate_up_silu_mul,
     pack_for_decode,
     pack_gate_up_for_decode,
 )
+from ..layers.quantization.w8a8_fp8 import W8A8Fp8LinearMethod
 from ..layers.radix_attention import RadixAttention
+from ..ops_backend import get_ops
 from ..layers.rotary_embedding import get_rope
 from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
 
@@ -44,12 +48,26 @@ class LlamaMLP(nn.Module):
             x = gate_up_silu_mul(self.gate_up_proj, self.act_fn, x)
         else:
             gate_up, _ = self.gate_up_proj(x)
-            x = self.act_fn(gate_up)
+            if wants_fp8_input(self.down_proj, gate_up.shape[0]) and gate_up.dim() == 2:
+                # SiLU-mul and the down projection's per-token quantisation in one launch
+                xq, xs = get_ops().silu_and_mul_quant_fp8(gate_up)
+                x = QuantizedAct(xq, xs, gate_up.dtype)
+            else:
+                x = self.act_fn(gate_up)
         deferred = decode_linear_deferred(self.down_proj, x)   # summed by the next layer's norm
         if deferred is not None:
             return deferred
         x, _ = self.down_proj(x)
         return x
+
+
+def wants_fp8_input(layer, m: int) -> bool:
+    """True when `layer` is an fp8 W8A8 projection on the decode path whose producer may hand it
+    per-token-quantised rows directly (QuantizedAct) instead of a 16-bit tensor."""
+    from ..layers.quantization import unquant
+    return (unquant.DECODE_FUSION and isinstance(layer.quant_method, W8A8Fp8LinearMethod)
+            and 1 <= m <= SKINNY_MAX_M and getattr(layer, "weight_packed", None) is not None
+            and hasattr(get_ops(), "rmsnorm_ex"))
 
 
 class LlamaAttention(nn.Module):
@@ -90,7 +108,7 @@ class LlamaAttention(nn.Module):
         if part is None:
             return None
         return backend.forward_decode_fused_qkv(part.part, positions, self.rotary_emb.cos_sin_cache, self.attn,
-                                                forward_batch)
+                                                forward_batch, part.x_scale, part.w_scale)
 
     def forward(self, positions, hidden_states, forward_batch):
         attn_output = self._fused_decode(positions, hidden_states, forward_batch)
@@ -123,13 +141,21 @@ class LlamaDecoderLayer(nn.Module):
 
     def forward(self, positions, hidden_states, forward_batch,
                 residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        m = hidden_states.shape[0]
+        q_in = wants_fp8_input(self.self_attn.qkv_proj, m)      # norm also quantises for the fp8 GEMM behind it
+        q_mlp = wants_fp8_input(self.mlp.gate_up_proj, m)
         if residual is None:
             residual = hidden_states
-            hidden_states = self.input_layernorm(hidden_states)
+            hidden_states = self.input_layernorm(hidden_states, quant_fp8=True) if q_in else self.input_layernorm(hidden_states)
+        elif q_in:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual, quant_fp8=True)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions, hidden_states, forward_batch)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        if q_mlp:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual, quant_fp8=True)
+        else:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 

@@ -247,11 +247,12 @@ def test_radix_prefix_cache_on_gpu_matches_isolated_generation():
         assert r.output_ids == ref_toks[0].tolist(), r.rid
 
 
+@pytest.mark.parametrize("quant", [None, "w8a8_fp8"])
 @pytest.mark.parametrize("graphs", [False, True])
-def test_decode_fusion_is_bit_identical_end_to_end(graphs):
+def test_decode_fusion_is_bit_identical_end_to_end(graphs, quant):
     """bf16 decode with the fused step (qkv partials -> one attention launch; o/down partials summed by
-    the norms) against the same model with every fusion switched off: logits equal bit for bit at
-    every step, KV cache contents equal."""
+    the norms; for fp8 W8A8 also the quantisation fused into the norms / SiLU-mul) against the same model
+    with every fusion switched off: logits equal bit for bit at every step, KV cache contents equal."""
     from sglang_custom_amd.layers.quantization import unquant
 
     name, preset, dtn, lens, steps = [c for c in cases.E2E_CASES if c[2] == "bf16"][0]
@@ -259,7 +260,7 @@ def test_decode_fusion_is_bit_identical_end_to_end(graphs):
     for fusion in (True, False):
         unquant.DECODE_FUSION = fusion
         try:
-            mr, cfg, _ = make_runner(preset, dtn, graphs)
+            mr, cfg, _ = make_runner(preset, dtn, graphs, quant=quant)
             prompts = cases.e2e_prompts(cfg["vocab_size"], lens)
             toks, logits, locs, _ = run_steps(mr, prompts, steps + 3)
             kb, vb = mr.token_to_kv_pool.get_kv_buffer(0)
