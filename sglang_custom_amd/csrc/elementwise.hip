@@ -31,8 +31,8 @@ static int take_prefetch(WeightPrefetch* d) {
 // pass and the scale pass when it fits (CHUNKS vectors per thread), so HBM sees each element
 // once; longer rows are re-read (from L2).
 // ------------------------------------------------------------------------------------------
-template <typename T, bool ADD, int CHUNKS>
-__global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ x,
+template <typename T, bool ADD, int CHUNKS, int BT = 256>
+__global__ __launch_bounds__(BT) void rmsnorm_vec_kernel(T* __restrict__ out, T* __restrict__ x,
                                                           T* __restrict__ residual,
                                                           const T* __restrict__ w, int64_t hidden,
                                                           int64_t x_stride, int64_t out_stride,
@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
   Vec<T, VE> wv[CHUNKS];
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
-    const int vi = threadIdx.x + c * 256;
+    const int vi = threadIdx.x + c * BT;
     wv[c] = ldvec<T, VE>(w + (int64_t)(vi < nvec ? vi : 0) * VE);
   }
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
-    const int vi = threadIdx.x + c * 256;
+    const int vi = threadIdx.x + c * BT;
     if (vi < nvec) {
       Vec<T, VE> a;
       if (part) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
   float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
-    const int vi = threadIdx.x + c * 256;
+    const int vi = threadIdx.x + c * BT;
     if (vi < nvec) {
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
@@ -132,13 +132,19 @@ __global__ __launch_bounds__(256) void rmsnorm_vec_kernel(T* __restrict__ out, T
     if (q_out) {
       // per-token fp8 quantisation of the normalised row, for the fp8 GEMM that consumes it
       // (same arithmetic as per_token_quant_fp8 on the stored 16-bit row)
-      amax = block_max256(amax, red);
+      amax = wave_max(amax);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+      __syncthreads();
+      amax = red[0];
+#pragma unroll
+      for (int wv_ = 1; wv_ < BT / 64; ++wv_) amax = fmaxf(amax, red[wv_]);
       const float s = fmaxf(amax, 1e-10f) / 448.0f;
       const float qinv = 1.0f / s;
       if (threadIdx.x == 0) q_scale[row] = s;
 #pragma unroll
       for (int c = 0; c < CHUNKS; ++c) {
-        const int vi = threadIdx.x + c * 256;
+        const int vi = threadIdx.x + c * BT;
         if (vi < nvec) *reinterpret_cast<uint2*>(q_out + row * hidden + (int64_t)vi * 8) = quant8_fp8<T>(ov[c], qinv);
       }
     }
@@ -210,13 +216,15 @@ static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, i
     WeightPrefetch pf;
     const int pf_wgs = take_prefetch(&pf);
     grid.x += pf_wgs;
-#define LAUNCH(C)                                                                              \
-  hipLaunchKernelGGL((rmsnorm_vec_kernel<T, ADD, C>), grid, block, 0, st, out, x, residual, w, \
+#define LAUNCH(C, BT_)                                                                                  \
+  hipLaunchKernelGGL((rmsnorm_vec_kernel<T, ADD, C, BT_>), grid, dim3(BT_), 0, st, out, x, residual, w, \
                      hidden, x_stride, out_stride, eps, pf, pf_wgs, part, nsplit, part_xs, part_ws, q_out, q_scale)
-    if (chunks <= 1) LAUNCH(1);
-    else if (chunks <= 2) LAUNCH(2);
-    else if (chunks <= 4) LAUNCH(4);
-    else LAUNCH(8);
+    // (512 lanes per row were measured for decode-sized inputs: 0.5 % on the step, and a different
+    // reduction order than the 256-lane launch -- not worth two result variants)
+    if (chunks <= 1) LAUNCH(1, 256);
+    else if (chunks <= 2) LAUNCH(2, 256);
+    else if (chunks <= 4) LAUNCH(4, 256);
+    else LAUNCH(8, 256);
 #undef LAUNCH
   } else if (ADD) {
     hipLaunchKernelGGL((fused_add_rmsnorm_generic_kernel<T>), grid, block, 0, st, x, residual, w,
@@ -251,14 +259,16 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(T* __restrict__ out,
 
 // SiLU-and-mul fused with the per-token fp8 quantisation of its output (the activation of an fp8
 // down projection): one workgroup per row, the row stays in registers between the activation, the
-// absmax and the conversion.  d % 8 == 0, d <= 16384.  Same values as silu_and_mul followed by
+// absmax and the conversion.  d % 8 == 0, d <= 16384 (1024 threads x 2 vectors of 8).  Same values as silu_and_mul followed by
 // per_token_quant_fp8 on its 16-bit output.
 template <typename T>
-__global__ __launch_bounds__(256) void silu_mul_quant_fp8_kernel(uint8_t* __restrict__ q_out,
-                                                                 float* __restrict__ q_scale,
-                                                                 const T* __restrict__ x, int64_t d) {
-  constexpr int MAXV = 8;
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void silu_mul_quant_fp8_kernel(uint8_t* __restrict__ q_out,
+                                                                  float* __restrict__ q_scale,
+                                                                  const T* __restrict__ x, int64_t d) {
+  // 1024 threads per row: with one workgroup per token the launch is latency-bound, so the row is
+  // spread over as many lanes as a workgroup has (two 16-byte pairs per thread at d = 14336).
+  constexpr int MAXV = 2;
+  __shared__ float red[16];
   const int64_t row = blockIdx.x;
   const T* g = x + row * 2 * d;
   const int nvec = (int)(d >> 3);
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256) void silu_mul_quant_fp8_kernel(uint8_t* __rest
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int idx = threadIdx.x + i * 256;
+    const int idx = threadIdx.x + i * 1024;
     if (idx < nvec) {
       const Vec<T, 8> a = ldvec<T, 8>(g + (int64_t)idx * 8), b = ldvec<T, 8>(g + d + (int64_t)idx * 8);
 #pragma unroll
@@ -276,13 +286,18 @@ __global__ __launch_bounds__(256) void silu_mul_quant_fp8_kernel(uint8_t* __rest
       }
     }
   }
-  amax = block_max256(amax, red);
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) amax = fmaxf(amax, red[w]);
   const float s = fmaxf(amax, 1e-10f) / 448.0f;
   const float inv = 1.0f / s;
   if (threadIdx.x == 0) q_scale[row] = s;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int idx = threadIdx.x + i * 256;
+    const int idx = threadIdx.x + i * 1024;
     if (idx < nvec) *reinterpret_cast<uint2*>(q_out + row * d + (int64_t)idx * 8) = quant8_fp8<T>(o[i], inv);
   }
 }
@@ -570,10 +585,10 @@ int mi355_silu_and_mul_quant_fp8(uint8_t* q_out, float* q_scale, const void* x, 
                 "silu_and_mul_quant_fp8: misaligned pointer");
   if (rows == 0) return MI355_OK;
   if (dtype == MI355_BF16)
-    hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<bf16_t>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
                        q_out, q_scale, (const bf16_t*)x, d);
   else
-    hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<f16_t>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
                        q_out, q_scale, (const f16_t*)x, d);
   MI355_CHECK_LAUNCH("silu_and_mul_quant_fp8");
   return MI355_OK;
