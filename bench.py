@@ -321,6 +321,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 and dist.is_initialized():
+        barrier()   # rank 0 may still have been measuring: nobody tears the group down early
         dist.destroy_process_group()
 
 
