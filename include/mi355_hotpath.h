@@ -130,6 +130,22 @@ int mi355_compute_position(const int32_t* extend_prefix_lens, const int32_t* ext
                            int64_t* positions, int32_t* extend_start_loc, int64_t bs,
                            void* stream);
 
+/* ---- K18 paged slot allocation (page_size > 1) ----------------------------------------------
+ * Page-aligned KV slots for a batch, taken in request order from the front of free_pages (page
+ * ids; slot = page * page_size + offset).  alloc_extend: request b extends from prefix_lens[b] to
+ * seq_lens[b] tokens; its new slots first fill the rest of its last page (last_loc[b] + 1, ...),
+ * then whole new pages, then the head of one more; out_indices is the flat [sum extend] list,
+ * totals[0] = pages consumed, totals[1] = tokens written.  alloc_decode: one token per request
+ * (seq_lens already counts it): last_loc[b] + 1, or the first slot of a new page.  The caller drops
+ * totals[0] pages from its free list -- and must have checked that many are available: free_pages
+ * is read up to that index.
+ * replaces: alloc_extend_kernel / alloc_decode_kernel (mem_cache/allocator.py:276-401). */
+int mi355_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
+                       const int64_t* free_pages, int64_t* out_indices, int64_t* totals, int64_t bs,
+                       int64_t page_size, void* stream);
+int mi355_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
+                       int64_t* out_indices, int64_t* totals, int64_t bs, int64_t page_size, void* stream);
+
 /* ---- decode step bookkeeping (one launch) ---------------------------------------------------
  * seq_lens[b] += 1; positions[b] = max(seq_lens[b]-1, 0);
  * req_to_token[req_pool_indices[b], seq_lens[b]-1] = out_cache_loc[b]

@@ -218,3 +218,40 @@ def fp8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias=No
     if bias is not None:
         out = out + bias
     return out.to(x.dtype)
+
+
+def alloc_extend_pages(prefix_lens, seq_lens, last_loc, free_pages, page_size: int):
+    """Page-aligned slots for an extend batch, request by request
+    (python/sglang/srt/mem_cache/allocator.py:276-360; same arithmetic as the torch variant :573-625):
+    (1) the rest of the request's last page, (2) whole new pages, (3) the head of one more new page;
+    new pages are taken from the front of free_pages in request order.
+    Returns (out_indices int64 [sum extend], pages_used)."""
+    out, used = [], 0
+    for pre, seq, ll in zip([int(v) for v in prefix_lens], [int(v) for v in seq_lens], [int(v) for v in last_loc]):
+        pre_up = (pre + page_size - 1) // page_size * page_size
+        n1 = min(seq, pre_up) - pre
+        out += [ll + 1 + i for i in range(n1)]
+        n_new = (seq + page_size - 1) // page_size - (pre + page_size - 1) // page_size
+        mine = [int(free_pages[used + i]) for i in range(n_new)]
+        if pre + n1 < seq:
+            n2 = seq // page_size * page_size - pre_up
+            out += [mine[i // page_size] * page_size + i % page_size for i in range(n2)]
+            if pre + n1 + n2 < seq:
+                n3 = seq - seq // page_size * page_size
+                out += [mine[-1] * page_size + i for i in range(n3)]
+        used += n_new
+    return torch.tensor(out, dtype=torch.int64), used
+
+
+def alloc_decode_pages(seq_lens, last_loc, free_pages, page_size: int):
+    """One new slot per request for a decode step (allocator.py:364-401): the slot after last_loc,
+    or the first slot of a new page when seq_len - 1 fills whole pages.  seq_lens counts the new token."""
+    out, used = [], 0
+    for seq, ll in zip([int(v) for v in seq_lens], [int(v) for v in last_loc]):
+        if (seq + page_size - 1) // page_size - (seq - 1 + page_size - 1) // page_size:
+            out.append(int(free_pages[used]) * page_size)
+            used += 1
+        else:
+            out.append(ll + 1)
+    return torch.tensor(out, dtype=torch.int64), used
+

@@ -77,6 +77,89 @@ static void kv_indices_launch(const int32_t* r2t, const void* pool, const void* 
                      (const PT*)pool, (const LT*)lens, indptr, start, out, stride);
 }
 
+// Paged slot allocation (page_size > 1): one workgroup per request.  Request b's new tokens go
+// (1) into the rest of its last, partially filled page (slots last_loc + 1 ...), (2) into whole new
+// pages and (3) into the head of one more new page, the new pages being taken in request order
+// from the front of free_pages.  Both exclusive prefix sums (extend tokens and new pages of the
+// requests before b) are computed by the workgroup itself, so the launch has no dependency chain.
+// totals[0] = new pages of the whole batch, totals[1] = extend tokens of the whole batch.
+__global__ __launch_bounds__(256) void alloc_extend_kernel(
+    const int64_t* __restrict__ pre_lens, const int64_t* __restrict__ seq_lens,
+    const int64_t* __restrict__ last_loc, const int64_t* __restrict__ free_pages,
+    int64_t* __restrict__ out_indices, int64_t* __restrict__ totals, int bs, int64_t page) {
+  const int b = blockIdx.x;
+  __shared__ int64_t red[2][4];
+  int64_t tok = 0, pages = 0;
+  for (int i = threadIdx.x; i <= b; i += 256) {
+    const int64_t s = seq_lens[i], pr = pre_lens[i];
+    tok += s - pr;
+    pages += (s + page - 1) / page - (pr + page - 1) / page;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    tok += __shfl_xor(tok, o, 64);
+    pages += __shfl_xor(pages, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = tok;
+    red[1][threadIdx.x >> 6] = pages;
+  }
+  __syncthreads();
+  const int64_t tok_incl = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const int64_t pages_incl = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const int64_t seq = seq_lens[b], pre = pre_lens[b];
+  const int64_t my_pages = (seq + page - 1) / page - (pre + page - 1) / page;
+  const int64_t out0 = tok_incl - (seq - pre), page0 = pages_incl - my_pages;
+  if (b == bs - 1 && threadIdx.x == 0) {
+    totals[0] = pages_incl;
+    totals[1] = tok_incl;
+  }
+  const int64_t pre_up = (pre + page - 1) / page * page;
+  const int64_t n1 = (seq < pre_up ? seq : pre_up) - pre;                      // rest of the old page
+  const int64_t n2 = pre + n1 == seq ? 0 : seq / page * page - pre_up;          // whole new pages
+  const int64_t n3 = pre + n1 + n2 == seq ? 0 : seq - seq / page * page;        // head of the last new page
+  const int64_t ll = last_loc[b];
+  for (int64_t i = threadIdx.x; i < n1; i += 256) out_indices[out0 + i] = ll + 1 + i;
+  for (int64_t i = threadIdx.x; i < n2; i += 256)
+    out_indices[out0 + n1 + i] = free_pages[page0 + i / page] * page + i % page;
+  if (n3 > 0) {
+    const int64_t start = free_pages[page0 + my_pages - 1] * page;
+    for (int64_t i = threadIdx.x; i < n3; i += 256) out_indices[out0 + n1 + n2 + i] = start + i;
+  }
+}
+
+// Decode: one new token per request -- the next slot of its last page, or slot 0 of a new page when
+// seq_len - 1 is a multiple of the page size.  totals[0] = new pages of the batch.
+__global__ __launch_bounds__(256) void alloc_decode_kernel(
+    const int64_t* __restrict__ seq_lens, const int64_t* __restrict__ last_loc,
+    const int64_t* __restrict__ free_pages, int64_t* __restrict__ out_indices,
+    int64_t* __restrict__ totals, int bs, int64_t page) {
+  __shared__ int64_t red[4];
+  // a single workgroup walks the batch in 256-request blocks carrying the page count forward
+  int64_t base = 0;
+  for (int b0 = 0; b0 < bs; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    const int64_t seq = b < bs ? seq_lens[b] : 1;
+    const int64_t need = b < bs ? (seq + page - 1) / page - (seq - 1 + page - 1) / page : 0;
+    // inclusive scan over the 256 lanes of this block
+    int64_t incl = need;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t up = __shfl_up(incl, o, 64);
+      if ((threadIdx.x & 63) >= o) incl += up;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += red[w];
+    const int64_t excl = base + woff + incl - need;
+    if (b < bs) out_indices[b] = need ? free_pages[excl] * page : last_loc[b] + 1;
+    base += red[0] + red[1] + red[2] + red[3];
+  }
+  if (threadIdx.x == 0) totals[0] = base;
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -155,6 +238,31 @@ int mi355_prepare_decode(int32_t* req_to_token, const int64_t* req_pool_indices,
                      (hipStream_t)stream, req_to_token, req_pool_indices, seq_lens, out_cache_loc,
                      positions, req_to_token_stride, bs);
   MI355_CHECK_LAUNCH("prepare_decode");
+  return MI355_OK;
+}
+
+int mi355_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
+                       const int64_t* free_pages, int64_t* out_indices, int64_t* totals, int64_t bs,
+                       int64_t page_size, void* stream) {
+  MI355_REQUIRE(prefix_lens && seq_lens && last_loc && free_pages && out_indices && totals, MI355_ERR_INVALID,
+                "alloc_extend: null pointer");
+  MI355_REQUIRE(bs >= 0 && bs <= 65535 && page_size >= 1, MI355_ERR_INVALID, "alloc_extend: bad shape");
+  if (bs == 0) return MI355_OK;
+  hipLaunchKernelGGL(alloc_extend_kernel, dim3((unsigned)bs), dim3(256), 0, (hipStream_t)stream, prefix_lens,
+                     seq_lens, last_loc, free_pages, out_indices, totals, (int)bs, page_size);
+  MI355_CHECK_LAUNCH("alloc_extend");
+  return MI355_OK;
+}
+
+int mi355_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
+                       int64_t* out_indices, int64_t* totals, int64_t bs, int64_t page_size, void* stream) {
+  MI355_REQUIRE(seq_lens && last_loc && free_pages && out_indices && totals, MI355_ERR_INVALID,
+                "alloc_decode: null pointer");
+  MI355_REQUIRE(bs >= 0 && bs <= (1 << 24) && page_size >= 1, MI355_ERR_INVALID, "alloc_decode: bad shape");
+  if (bs == 0) return MI355_OK;
+  hipLaunchKernelGGL(alloc_decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq_lens, last_loc,
+                     free_pages, out_indices, totals, (int)bs, page_size);
+  MI355_CHECK_LAUNCH("alloc_decode");
   return MI355_OK;
 }
 

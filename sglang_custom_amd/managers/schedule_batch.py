@@ -148,7 +148,19 @@ class ScheduleBatch:
             req.cached_tokens += pre_len - req.already_computed
             req.already_computed = seq_len
 
-        self.out_cache_loc = self.alloc_token_slots(extend_num_tokens)
+        if self.token_to_kv_pool_allocator.page_size == 1:
+            self.out_cache_loc = self.alloc_token_slots(extend_num_tokens)
+        else:
+            # page-aligned slots continue each request's last page (schedule_batch.py alloc_paged_token_slots_extend;
+            # last_loc = the slot of the last prefix token, -1 without a prefix: get_last_loc)
+            last_loc = torch.tensor(
+                [int(r.prefix_indices[-1]) if len(r.prefix_indices) > 0 else -1 for r in reqs], dtype=torch.int64).to(dev)
+            self.out_cache_loc = self.token_to_kv_pool_allocator.alloc_extend(
+                prefix_lens_tensor, self.seq_lens, last_loc, extend_num_tokens,
+                prefix_lens_cpu=prefix_lens, seq_lens_cpu=seq_lens)
+            if self.out_cache_loc is None:
+                raise RuntimeError(f"Out of KV pages: need {extend_num_tokens} tokens, "
+                                   f"available {self.token_to_kv_pool_allocator.available_size()}")
         self.seq_lens_cpu_list = list(seq_lens)
         self.seq_lens_sum = sum(seq_lens)
         self.extend_num_tokens = extend_num_tokens
@@ -166,7 +178,16 @@ class ScheduleBatch:
         bs = len(self.reqs)
         self.input_ids = self.output_ids.to(torch.int64) if self.output_ids.dtype != torch.int64 else self.output_ids
         self.output_ids = None
-        self.out_cache_loc = self.alloc_token_slots(bs)
+        if self.token_to_kv_pool_allocator.page_size == 1:
+            self.out_cache_loc = self.alloc_token_slots(bs)
+        else:
+            # the slot after each request's last token, or a fresh page (alloc_paged_token_slots_decode)
+            rows = self.req_to_token_pool.req_to_token[self.req_pool_indices, self.seq_lens - 1]
+            self.out_cache_loc = self.token_to_kv_pool_allocator.alloc_decode(
+                self.seq_lens + 1, rows.to(torch.int64).contiguous(),
+                seq_lens_cpu=[x + 1 for x in self.seq_lens_cpu_list])
+            if self.out_cache_loc is None:
+                raise RuntimeError(f"Out of KV pages for a decode step of {bs} requests")
         if self.positions is None or self.positions.numel() != bs:
             self.positions = torch.empty(bs, dtype=torch.int64, device=self.device)
         # seq_lens += 1; positions = seq_lens - 1; req_to_token[req, seq_lens - 1] = out_cache_loc

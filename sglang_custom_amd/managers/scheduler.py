@@ -36,6 +36,9 @@ class Scheduler:
         cps = sa.chunked_prefill_size
         self.chunked_prefill_size = cps if cps is not None and cps > 0 else None
         self.max_prefill_tokens = sa.max_prefill_tokens
+        self.page_size = getattr(model_runner.token_to_kv_pool_allocator, "page_size", 1)
+        if self.page_size > 1 and enable_radix_cache:
+            raise NotImplementedError("the prefix tree matches token by token: use page_size 1 with enable_radix_cache")
         self.waiting_queue: List[Req] = []
         self.running_batch: ScheduleBatch = self._new_batch([])
         self.chunked_req: Optional[Req] = None
@@ -60,7 +63,8 @@ class Scheduler:
     # ---- admission (PrefillAdder) ----
     def _reserved_decode_tokens(self) -> int:
         """Slots the running requests may still need (rem_total_tokens of PrefillAdder)."""
-        return sum(r.sampling_params.max_new_tokens - len(r.output_ids) for r in self.running_batch.reqs)
+        return sum(r.sampling_params.max_new_tokens - len(r.output_ids) + (self.page_size if self.page_size > 1 else 0)
+                   for r in self.running_batch.reqs)
 
     def get_new_batch_prefill(self) -> Optional[ScheduleBatch]:
         if not self.waiting_queue and self.chunked_req is None:
@@ -98,6 +102,8 @@ class Scheduler:
                 return False
 
             need_all = req.extend_input_len + req.sampling_params.max_new_tokens - len(req.output_ids)
+            if self.page_size > 1:   # a request occupies whole pages (its last one partly)
+                need_all = (need_all + self.page_size - 1) // self.page_size * self.page_size + self.page_size
             if need_all > rem_total:
                 return refuse()
             n = req.extend_input_len

@@ -13,7 +13,7 @@ from ..layers.attention.mi355_backend import Mi355AttnBackend
 from ..layers.logits_processor import LogitsProcessorOutput
 from ..layers.quantization.w8a8_fp8 import W8A8Fp8LinearMethod
 from ..layers.sampler import Sampler
-from ..mem_cache.allocator import TokenToKVPoolAllocator
+from ..mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
 from ..mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
 from ..models.llama import LlamaForCausalLM
 from ..server_args import ServerArgs
@@ -84,11 +84,18 @@ class ModelRunner:
         max_reqs = sa.max_running_requests or min(
             max(self.max_total_num_tokens // cfg.context_len * 512, 2048), 4096)
         self.req_to_token_pool = ReqToTokenPool(max_reqs, cfg.context_len + 4, self.device)
+        page = max(1, int(getattr(sa, "page_size", 1) or 1))
+        # whole pages only (model_runner.py:1101-1106 rounds the same way)
+        self.max_total_num_tokens = self.max_total_num_tokens // page * page
         self.token_to_kv_pool = MHATokenToKVPool(
-            self.max_total_num_tokens, 1, self.dtype, kv_heads, cfg.head_dim,
+            self.max_total_num_tokens, page, self.dtype, kv_heads, cfg.head_dim,
             cfg.num_hidden_layers, self.device)
-        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(
-            self.max_total_num_tokens, self.dtype, self.device, self.token_to_kv_pool)
+        if page == 1:
+            self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(
+                self.max_total_num_tokens, self.dtype, self.device, self.token_to_kv_pool)
+        else:
+            self.token_to_kv_pool_allocator = PagedTokenToKVPoolAllocator(
+                self.max_total_num_tokens, page, self.dtype, self.device, self.token_to_kv_pool)
 
     # ---- forward ----
     def forward_decode(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:

@@ -218,6 +218,39 @@ def prepare_decode(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
                                        seq_lens.numel(), _stream(seq_lens)), "prepare_decode")
 
 
+def alloc_extend_pages(prefix_lens: torch.Tensor, seq_lens: torch.Tensor, last_loc: torch.Tensor,
+                       free_pages: torch.Tensor, page_size: int, extend_num_tokens: int):
+    """Page-aligned slots for an extend batch (allocator.py:276-360).  Returns (out_indices int64
+    [extend_num_tokens], pages consumed from the front of free_pages).  The caller made sure
+    free_pages holds enough pages."""
+    _gpu(prefix_lens, seq_lens, last_loc, free_pages)
+    for t in (prefix_lens, seq_lens, last_loc, free_pages):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    bs = seq_lens.numel()
+    out = torch.empty(extend_num_tokens, dtype=torch.int64, device=seq_lens.device)
+    totals = torch.zeros(2, dtype=torch.int64, device=seq_lens.device)
+    check(_lib_().mi355_alloc_extend(prefix_lens.data_ptr(), seq_lens.data_ptr(), last_loc.data_ptr(),
+                                     free_pages.data_ptr(), out.data_ptr(), totals.data_ptr(), bs, page_size,
+                                     _stream(seq_lens)), "alloc_extend")
+    pages, tokens = totals.tolist()
+    assert tokens == extend_num_tokens, (tokens, extend_num_tokens)
+    return out, pages
+
+
+def alloc_decode_pages(seq_lens: torch.Tensor, last_loc: torch.Tensor, free_pages: torch.Tensor, page_size: int):
+    """One slot per request for a decode step (allocator.py:364-401); seq_lens counts the new token.
+    Returns (out_indices int64 [bs], pages consumed)."""
+    _gpu(seq_lens, last_loc, free_pages)
+    for t in (seq_lens, last_loc, free_pages):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    bs = seq_lens.numel()
+    out = torch.empty(bs, dtype=torch.int64, device=seq_lens.device)
+    totals = torch.zeros(2, dtype=torch.int64, device=seq_lens.device)
+    check(_lib_().mi355_alloc_decode(seq_lens.data_ptr(), last_loc.data_ptr(), free_pages.data_ptr(), out.data_ptr(),
+                                     totals.data_ptr(), bs, page_size, _stream(seq_lens)), "alloc_decode")
+    return out, int(totals[0].item())
+
+
 # ---------------------------------------------------------------------------------- attention
 def decode_num_splits(bs: int, hkv: int, max_seq_len: int, max_splits: int) -> int:
     return _lib_().mi355_decode_num_splits(bs, hkv, max_seq_len, max_splits)

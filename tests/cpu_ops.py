@@ -129,3 +129,14 @@ def top_k_top_p_min_p_sample(probs, top_ks, top_ps, min_ps, uniform):
     kept = ops_ref.kept_distribution(probs, top_ks, top_ps, min_ps)
     cdf = kept.cumsum(-1)
     return (cdf < uniform.view(-1, 1) * cdf[:, -1:]).sum(-1).clamp(max=probs.shape[1] - 1).to(torch.int32)
+
+
+def alloc_extend_pages(prefix_lens, seq_lens, last_loc, free_pages, page_size, extend_num_tokens):
+    out, used = ops_ref.alloc_extend_pages(prefix_lens, seq_lens, last_loc, free_pages, page_size)
+    assert out.numel() == extend_num_tokens
+    return out, used
+
+
+def alloc_decode_pages(seq_lens, last_loc, free_pages, page_size):
+    return ops_ref.alloc_decode_pages(seq_lens, last_loc, free_pages, page_size)
+

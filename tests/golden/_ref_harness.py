@@ -38,7 +38,9 @@ class _StubModule(types.ModuleType):
         if name.startswith("__"):
             raise AttributeError(name)
         return _Meta(name, (), {"__init__": lambda self, *a, **k: None,
-                                "__call__": lambda self, *a, **k: None})
+                                "__call__": lambda self, *a, **k: None,
+                                # class Foo(stub.Struct, array_like=True, ...) must be definable
+                                "__init_subclass__": classmethod(lambda cls, **k: None)})
 
 
 class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
