@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--quantization", default=None, choices=[None, "w8a8_fp8"])
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
+                    help="fp8_e4m3: optional reduced-precision KV cache (NOT the headline configuration)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="measurement aid (not the contract metric): run ONE rank's shard of a TP=N "
@@ -223,7 +225,7 @@ def main():
                     max_running_requests=max(bs, 8) + 8, context_length=in_len + out_len + 16,
                     disable_cuda_graph=args.no_graph, cuda_graph_bs=[bs], tp_size=tp,
                     quantization=args.quantization, random_seed=rank if tp == 1 else 0,
-                    simulate_tp_shard=bool(sim))
+                    simulate_tp_shard=bool(sim), kv_cache_dtype=args.kv_cache_dtype)
     mc = ModelConfig(cfg, dtype=args.dtype, context_length=in_len + out_len + 16)
     graph_ok = True
     try:
@@ -279,7 +281,8 @@ def main():
     dtype_bytes = 2 if args.dtype != "float32" else 4
     wbytes, _ = weight_bytes_per_step(cfg, tp, dtype_bytes, args.quantization)
     mean_ctx = in_len + args.warmup + (args.steps + 1) / 2.0
-    kv_tok = 2 * max(1, cfg["num_key_value_heads"] // tp) * cfg["head_dim"] * cfg["num_hidden_layers"] * dtype_bytes
+    kv_bytes = 1 if args.kv_cache_dtype == "fp8_e4m3" else dtype_bytes
+    kv_tok = 2 * max(1, cfg["num_key_value_heads"] // tp) * cfg["head_dim"] * cfg["num_hidden_layers"] * kv_bytes
     bytes_step = wbytes + bs * mean_ctx * kv_tok + bs * kv_tok
     step_gbs = bytes_step / (ms_per_step * 1e-3) / 1e9
 
@@ -290,7 +293,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None,
         "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype]
-                 + ("+fp8-w8a8" if args.quantization else ""),
+                 + ("+fp8-w8a8" if args.quantization else "") + ("+fp8-kv" if args.kv_cache_dtype != "auto" else ""),
         "data": "synthetic (random-init weights of the named shape, np.random prompts seed 0)",
         "config": {"workload": f"{args.model} {args.dtype} decode, static batch {bs}, {in_len}-token prompts, "
                                f"greedy, context {in_len + args.warmup}..{in_len + args.warmup + args.steps}",

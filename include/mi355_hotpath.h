@@ -34,6 +34,11 @@ extern "C" {
 /* index type codes */
 #define MI355_I32 0
 #define MI355_I64 1
+/* OR into the `dtype` argument of the attention / KV-write entry points that document it: the KV
+ * cache buffers hold OCP e4m3fn bytes (kv_cache_dtype fp8_e4m3, mem_cache/memory_pool.py:118-122,
+ * 436-446) while q / k / v / o keep the 16-bit dtype in the low byte.  Values are stored as
+ * clamp(x, +-448) rounded to nearest even and read back by exact widening. */
+#define MI355_KV_FP8 0x100
 
 #define MI355_ABI_VERSION 1
 int mi355_abi_version(void);

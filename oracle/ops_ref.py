@@ -255,3 +255,10 @@ def alloc_decode_pages(seq_lens, last_loc, free_pages, page_size: int):
             out.append(ll + 1)
     return torch.tensor(out, dtype=torch.int64), used
 
+
+def kv_to_fp8_and_back(x: torch.Tensor) -> torch.Tensor:
+    """What an fp8 KV cache (kv_cache_dtype fp8_e4m3, mem_cache/memory_pool.py:436-446) hands to
+    the attention kernels: x cast to e4m3fn (round to nearest even; values beyond +-448 saturate)
+    and widened back to x.dtype (the Triton kernels cast K / V to the query dtype before the dot)."""
+    return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+

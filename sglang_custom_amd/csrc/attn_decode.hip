@@ -554,14 +554,22 @@ constexpr int DV_ROW = 128 + 16;   // V tile row in LDS (elements): 288 B -> con
 // RoPE kernel, the wave that owns the newest key writes k_new / v_new into the cache and uses
 // them from registers for that key's tile.  One workgroup per (sequence, kv head, split) is
 // required (G = all query heads of the kv head), so nobody else reads or writes that slot.
-template <typename T, int G, bool CAP, bool FUSED = false>
+// KV8: the cache holds e4m3fn bytes (kbuf / vbuf are byte buffers behind the T pointers): rows are
+// widened to T on load, the new token's rows are stored quantised and used at their stored value.
+template <typename T, int G, bool CAP, bool FUSED = false, bool KV8 = false>
 __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __restrict__ q,
                                                                   const T* kbuf, const T* vbuf,
                                                                   T* __restrict__ o, DecodeParams p,
                                                                   FusedQkv fz = FusedQkv()) {
+#pragma clang fp contract(off)   // see the note in `compute`
+  using KVT = typename std::conditional<KV8, uint8_t, T>::type;
   constexpr int D = 128, VE = 8;
   using frag = typename Mfma<T>::frag;
   using frag4 = typename Mfma16<T>::frag;
+  // what the K/V register buffers hold between load and use: with an fp8 cache the raw 8 bytes
+  // (widened when the tile is computed), so that two buffered tiles cost half the registers
+  using KRaw = typename std::conditional<KV8, uint2, frag>::type;
+  using VRaw = typename std::conditional<KV8, uint2, Vec<T, VE>>::type;
   __shared__ float sm_acc[4][G][D];
   __shared__ float sm_m[4][G];
   __shared__ float sm_l[4][G];
@@ -663,8 +671,8 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 
   const int32_t* pt = p.page_table + page_off;
   const int64_t row_stride = (int64_t)p.hkv * D;
-  const T* kbase = kbuf + (int64_t)kvh * D + 8 * c4;     // + slot * row_stride + 32 s
-  const T* vbase = vbuf + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
+  const KVT* kbase = reinterpret_cast<const KVT*>(kbuf) + (int64_t)kvh * D + 8 * c4;     // + slot * row_stride + 32 s
+  const KVT* vbase = reinterpret_cast<const KVT*>(vbuf) + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
   const int64_t wave_first = k0 + (int64_t)wave * 16;
   const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 63) / 64) : 0;
   const int64_t last_key = len - 1;
@@ -697,16 +705,31 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
     }
   };
 
-  auto load_kv = [&](const int32_t& sk, const int32_t (&sv)[4], frag (&kf)[4], Vec<T, VE> (&vv)[4]) {
-    const T* krow = kbase + (int64_t)sk * row_stride;
+  auto load_kv = [&](const int32_t& sk, const int32_t (&sv)[4], KRaw (&kf)[4], VRaw (&vv)[4]) {
+    const KVT* krow = kbase + (int64_t)sk * row_stride;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const KRaw*>(krow + 32 * s);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)sv[u] * row_stride);
+    for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const VRaw*>(vbase + (int64_t)sv[u] * row_stride);
   };
   // One 16-key tile.  A tile past the end of the range is harmless: every key is masked, so the
   // probabilities are zero and the rescale factor is one.
-  auto compute = [&](frag (&kf)[4], Vec<T, VE> (&vv)[4], int it) {
+  auto compute = [&](const KRaw (&kraw)[4], const VRaw (&vraw)[4], int it) {
+    // No multiply-add contraction in the softmax: the fused and the plain instantiation of this
+    // kernel must round identically (the compiler otherwise contracts differently per instantiation).
+#pragma clang fp contract(off)
+    frag kf[4];
+    Vec<T, VE> vv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (KV8) kf[s] = __builtin_bit_cast(frag, cvt8_from_fp8<T>(kraw[s]));
+      else kf[s] = kraw[s];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if constexpr (KV8) vv[u] = cvt8_from_fp8<T>(vraw[u]);
+      else vv[u] = vraw[u];
+    }
     if constexpr (FUSED) {
       if (owner && it == it_new) {   // this tile's row rl was loaded before the cache held it
 #pragma unroll
@@ -763,8 +786,8 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   // Two K/V register buffers: the loads of tile it+1 are in flight while tile it is computed, so a
   // wave keeps 8-16 KiB outstanding at all times.  Addresses past the range are clamped (valid).
   int32_t skA, svA[4], skB, svB[4];
-  frag kfA[4], kfB[4];
-  Vec<T, VE> vvA[4], vvB[4];
+  KRaw kfA[4], kfB[4];
+  VRaw vvA[4], vvB[4];
   if (n_iter > 0) {
     load_slots(0, skA, svA);
     load_slots(1, skB, svB);
@@ -796,12 +819,26 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
       frags_from_lds(G, knew);
       vnew = ldvec<T, VE>(&sm_qkv[(G + 1) * D + 8 * r16]);
       const int64_t slot = fz.out_loc[b];
-      if (r16 == 0) {
-        T* kd = const_cast<T*>(kbuf) + slot * row_stride + (int64_t)kvh * D + 8 * c4;
+      KVT* kd = const_cast<KVT*>(reinterpret_cast<const KVT*>(kbuf)) + slot * row_stride + (int64_t)kvh * D + 8 * c4;
+      KVT* vd = const_cast<KVT*>(reinterpret_cast<const KVT*>(vbuf)) + slot * row_stride + (int64_t)kvh * D + 8 * r16;
+      if constexpr (KV8) {
+        // quantise once; the attention below sees exactly what a later step will read from the cache
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<frag*>(kd + 32 * s) = knew[s];
+        for (int s = 0; s < 4; ++s) {
+          const uint2 qv = quant8_fp8<T>(__builtin_bit_cast(Vec<T, 8>, knew[s]), 1.0f);
+          if (r16 == 0) *reinterpret_cast<uint2*>(kd + 32 * s) = qv;
+          knew[s] = __builtin_bit_cast(frag, cvt8_from_fp8<T>(qv));
+        }
+        const uint2 qv = quant8_fp8<T>(vnew, 1.0f);
+        if (c4 == 0) *reinterpret_cast<uint2*>(vd) = qv;
+        vnew = cvt8_from_fp8<T>(qv);
+      } else {
+        if (r16 == 0) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) *reinterpret_cast<frag*>(kd + 32 * s) = knew[s];
+        }
+        if (c4 == 0) stvec<T, VE>(vd, vnew);
       }
-      if (c4 == 0) stvec<T, VE>(const_cast<T*>(vbuf) + slot * row_stride + (int64_t)kvh * D + 8 * r16, vnew);
     }
   }
   if (n_iter > 0) {
@@ -1140,6 +1177,8 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const float* __restri
 
 int g_decode_variant = 0;   // 0 = P.V on MFMA, 1 = P.V on the vector ALU (mi355_debug_set key 6)
 
+static thread_local bool g_kv8 = false;   // set by the entry point for the duration of one launch_decode call (fp8 KV cache)
+
 template <typename T, int D, int U, bool CAP>
 static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const DecodeParams& p,
                              int64_t bs, hipStream_t st) {
@@ -1148,6 +1187,15 @@ static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const D
   const dim3 grid((unsigned)(p.hkv * (gtotal / G)), (unsigned)p.num_splits, (unsigned)bs);
   const dim3 block(256);
   if constexpr (D == 128 && !std::is_same<T, float>::value) {
+    if (g_kv8) {
+      switch (G) {
+        case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        default: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+      }
+      return;
+    }
     if (g_decode_variant == 0) {
       switch (G) {
         case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
@@ -1191,6 +1239,10 @@ static int launch_decode(const void* q_, const void* kb_, const void* vb_, void*
   const bool vec = D == Dv && aligned16(q) && aligned16(kb) && aligned16(vb) &&
                    p.q_stride % V16<T>::n == 0;
   constexpr int VE = V16<T>::n;
+  if (g_kv8 && !(vec && D == 128 && !std::is_same<T, float>::value)) {
+    set_error("decode_attention: an fp8 KV cache needs head_dim 128, a 16-bit dtype and 16-B aligned pointers");
+    return MI355_ERR_UNSUPPORTED;
+  }
   if (vec && D == 64) launch_decode_d<T, 64, 4>(q, kb, vb, o, p, bs, st);
   else if (vec && D == 128) launch_decode_d<T, 128, 4>(q, kb, vb, o, p, bs, st);
   else if (vec && D == 256 && D / VE <= 64) launch_decode_d<T, 256, 2>(q, kb, vb, o, p, bs, st);
@@ -1213,6 +1265,21 @@ static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParam
                                int64_t bs, hipStream_t st) {
   const int G = p.hq / p.hkv;
   const dim3 grid((unsigned)p.hkv, (unsigned)p.num_splits, (unsigned)bs), block(256);
+  if (g_kv8) {
+    switch (G) {
+      case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      case 1: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      default:
+        set_error("decode_attention_fused_qkv: %d query heads per kv head (needs 1, 2, 4 or 8)", G);
+        return MI355_ERR_UNSUPPORTED;
+    }
+    if (p.num_splits > 1)
+      hipLaunchKernelGGL((decode_merge_kernel<T>), dim3((unsigned)(bs * p.hq)), dim3(128), 0, st,
+                         p.part_o, p.part_lse, o, p.num_splits, 128);
+    return MI355_OK;
+  }
   switch (G) {
     case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
     case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
@@ -1293,9 +1360,12 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   p.k_slot_stride = (int64_t)hkv * head_dim;
   p.v_slot_stride = (int64_t)hkv * v_head_dim;
   int rc = MI355_OK;
+  g_kv8 = (dtype & MI355_KV_FP8) != 0;
+  dtype &= 0xff;
   MI355_DISPATCH_DTYPE(dtype, "decode_attention",
                        rc = launch_decode<T>(q, k_buffer, v_buffer, o, p, bs, head_dim, v_head_dim,
                                              (hipStream_t)stream));
+  g_kv8 = false;
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("decode_attention");
   return MI355_OK;
@@ -1321,6 +1391,8 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
   MI355_REQUIRE(bs >= 0 && bs <= 65535 && hq > 0 && hkv > 0 && hq % hkv == 0 && num_slots > 0 && nsplit >= 1 &&
                     nsplit <= 64,
                 MI355_ERR_INVALID, "decode_attention_fused_qkv: bad shape hq=%d hkv=%d nsplit=%d", hq, hkv, nsplit);
+  const bool kv8 = (dtype & MI355_KV_FP8) != 0;
+  dtype &= 0xff;
   MI355_REQUIRE(head_dim == 128 && (dtype == MI355_BF16 || dtype == MI355_F16), MI355_ERR_UNSUPPORTED,
                 "decode_attention_fused_qkv: needs head_dim 128 and a 16-bit dtype");
   MI355_REQUIRE(cache_dtype == MI355_F32 || cache_dtype == dtype, MI355_ERR_UNSUPPORTED,
@@ -1362,8 +1434,10 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
   fz.cache_f32 = cache_dtype == MI355_F32;
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  g_kv8 = kv8;
   if (dtype == MI355_BF16) rc = launch_decode_fused<bf16_t>((const bf16_t*)k_buffer, (const bf16_t*)v_buffer, (bf16_t*)o, p, fz, bs, st);
   else rc = launch_decode_fused<f16_t>((const f16_t*)k_buffer, (const f16_t*)v_buffer, (f16_t*)o, p, fz, bs, st);
+  g_kv8 = false;
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("decode_attention_fused_qkv");
   return MI355_OK;

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const T* __restrict
 constexpr int XK_ROW = 128 + 8;    // K tile row (elements): 272 B -> conflict-free ds_read_b128
 constexpr int XV_ROW = 128 + 16;   // V tile row: 288 B -> conflict-free transposed reads
 
-template <typename T>
+// KV8: the prefix lives in an e4m3fn cache (kbuf / vbuf are byte buffers); its rows are widened to T
+// while they are staged.  The extend part (k_ext / v_ext) is always T.
+template <typename T, bool KV8 = false>
 __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restrict__ q_ext,
                                                                const T* __restrict__ k_ext,
                                                                const T* __restrict__ v_ext,
@@ -367,6 +369,14 @@ __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restri
     for (int i = 0; i < 4; ++i) {
       int key = kt * 64 + srow + 16 * i;
       key = key < total ? key : total - 1;
+      if (KV8 && key < prefix) {
+        const int64_t slot = p.kv_indices[kv_start + key];
+        const uint8_t* kp8 = reinterpret_cast<const uint8_t*>(kbuf) + (slot * p.hkv + kvh) * D + sch * 8;
+        const uint8_t* vp8 = reinterpret_cast<const uint8_t*>(vbuf) + (slot * p.hkv + kvh) * D + sch * 8;
+        kreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(kp8));
+        vreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(vp8));
+        continue;
+      }
       const T *kp, *vp;
       if (key < prefix) {
         const int64_t slot = p.kv_indices[kv_start + key];
@@ -507,6 +517,8 @@ static int launch_extend_cfg(const void* q, const void* k, const void* v, void* 
   return MI355_OK;
 }
 
+static thread_local bool g_ext_kv8 = false;   // fp8 KV cache, set by the entry point around one launch
+
 template <typename T>
 static int launch_extend(const void* q, const void* k, const void* v, void* o, const void* kb,
                          const void* vb, const ExtendParams& p, int64_t bs, int64_t max_len_extend,
@@ -519,10 +531,19 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
   if constexpr (!std::is_same<T, float>::value) {
     if (vec && p.D == 128 && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 && p.logit_cap <= 0.f) {
       const dim3 grid((unsigned)((max_len_extend + 63) / 64), (unsigned)p.hq, (unsigned)bs);
-      hipLaunchKernelGGL((extend_attn_mfma_kernel<T>), grid, dim3(256), 0, st, (const T*)q, (const T*)k,
-                         (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p);
+      if (g_ext_kv8)
+        hipLaunchKernelGGL((extend_attn_mfma_kernel<T, true>), grid, dim3(256), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p);
+      else
+        hipLaunchKernelGGL((extend_attn_mfma_kernel<T, false>), grid, dim3(256), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p);
       return MI355_OK;
     }
+  }
+  if (g_ext_kv8) {
+    set_error("extend_attention: an fp8 KV cache needs head_dim 128, a 16-bit dtype, a causal or full mask, "
+              "no sliding window and no logit cap");
+    return MI355_ERR_UNSUPPORTED;
   }
   if (dmax <= 64) return launch_extend_cfg<T, 64, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
   if (dmax <= 128) return launch_extend_cfg<T, 128, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
@@ -588,9 +609,12 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
   p.sm_scale = sm_scale;
   p.logit_cap = logit_cap;
   int rc = MI355_OK;
+  g_ext_kv8 = (dtype & MI355_KV_FP8) != 0;
+  dtype &= 0xff;
   MI355_DISPATCH_DTYPE(dtype, "extend_attention",
                        rc = launch_extend<T>(q_extend, k_extend, v_extend, o_extend, k_buffer,
                                              v_buffer, p, bs, max_len_extend, (hipStream_t)stream));
+  g_ext_kv8 = false;
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("extend_attention");
   return MI355_OK;

@@ -118,6 +118,21 @@ template <typename T> __device__ __forceinline__ uint2 quant8_fp8(const Vec<T, 8
   }
   return uint2{out[0], out[1]};
 }
+// Eight OCP e4m3fn bytes -> eight values of T (exact: every e4m3 value is a bf16 / f16 / f32 value).
+template <typename T> __device__ __forceinline__ Vec<T, 8> cvt8_from_fp8(uint2 raw) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  Vec<T, 8> o;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int word = (int)(h ? raw.y : raw.x);
+    const f2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(word, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(word, true);
+    o.v[4 * h + 0] = from_f32<T>(lo[0]);
+    o.v[4 * h + 1] = from_f32<T>(lo[1]);
+    o.v[4 * h + 2] = from_f32<T>(hi[0]);
+    o.v[4 * h + 3] = from_f32<T>(hi[1]);
+  }
+  return o;
+}
 // Row maximum over a 256-thread workgroup (4 waves); `red` is 4 floats of LDS.
 __device__ __forceinline__ float block_max256(float x, float* red) {
   x = wave_max(x);

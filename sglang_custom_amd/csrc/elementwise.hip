@@ -424,6 +424,24 @@ __global__ __launch_bounds__(256) void set_kv_kernel(T* __restrict__ kb, T* __re
     stvec<T, VE>(vd + i, ldvec<T, VE>(vs + i));
 }
 
+// KV-cache scatter into an e4m3fn cache: rows are stored as clamp(x, +-448) rounded to nearest even
+// (cache_k.to(float8_e4m3fn), mem_cache/memory_pool.py:436-446, saturating instead of overflowing).
+// Rows are multiples of 8 elements.
+template <typename T, typename LT>
+__global__ __launch_bounds__(256) void set_kv_fp8_kernel(uint8_t* __restrict__ kb, uint8_t* __restrict__ vb,
+                                                         const T* __restrict__ k, const T* __restrict__ v,
+                                                         const LT* __restrict__ loc, int64_t k_row,
+                                                         int64_t v_row, int64_t k_stride, int64_t v_stride) {
+  const int64_t t = blockIdx.x;
+  const int64_t slot = (int64_t)loc[t];
+  const T* ks = k + t * k_stride;
+  const T* vs = v + t * v_stride;
+  for (int64_t i = threadIdx.x * 8; i < k_row; i += 256 * 8)
+    *reinterpret_cast<uint2*>(kb + slot * k_row + i) = quant8_fp8<T>(ldvec<T, 8>(ks + i), 1.0f);
+  for (int64_t i = threadIdx.x * 8; i < v_row; i += 256 * 8)
+    *reinterpret_cast<uint2*>(vb + slot * v_row + i) = quant8_fp8<T>(ldvec<T, 8>(vs + i), 1.0f);
+}
+
 // ------------------------------------------------------------------------------------------
 // Embedding gather
 // ------------------------------------------------------------------------------------------
@@ -684,6 +702,22 @@ int mi355_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const voi
                 MI355_ERR_INVALID, "set_kv_buffer: bad shape");
   if (tokens == 0) return MI355_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype & MI355_KV_FP8) {   // e4m3fn cache, 16-bit k / v
+    const int dt = dtype & 0xff;
+    MI355_REQUIRE((dt == MI355_BF16 || dt == MI355_F16) && k_row_elems % 8 == 0 && v_row_elems % 8 == 0 &&
+                      k_stride % 8 == 0 && v_stride % 8 == 0 && aligned16(k) && aligned16(v) &&
+                      (reinterpret_cast<uintptr_t>(k_buffer) & 7) == 0 && (reinterpret_cast<uintptr_t>(v_buffer) & 7) == 0,
+                  MI355_ERR_UNSUPPORTED, "set_kv_buffer: an fp8 cache needs 16-bit inputs, rows of 8-element multiples, aligned pointers");
+    const dim3 grid((unsigned)tokens), block(256);
+#define KV8_LAUNCH(T_, LT_)                                                                                 \
+  hipLaunchKernelGGL((set_kv_fp8_kernel<T_, LT_>), grid, block, 0, st, (uint8_t*)k_buffer, (uint8_t*)v_buffer, \
+                     (const T_*)k, (const T_*)v, (const LT_*)loc, k_row_elems, v_row_elems, k_stride, v_stride)
+    if (dt == MI355_BF16) { if (loc_itype == MI355_I32) KV8_LAUNCH(bf16_t, int32_t); else KV8_LAUNCH(bf16_t, int64_t); }
+    else { if (loc_itype == MI355_I32) KV8_LAUNCH(f16_t, int32_t); else KV8_LAUNCH(f16_t, int64_t); }
+#undef KV8_LAUNCH
+    MI355_CHECK_LAUNCH("set_kv_buffer");
+    return MI355_OK;
+  }
   MI355_DISPATCH_DTYPE(dtype, "set_kv_buffer",
                        set_kv_launch<T>(k_buffer, v_buffer, k, v, loc, loc_itype, tokens,
                                         k_row_elems, v_row_elems, k_stride, v_stride, st));

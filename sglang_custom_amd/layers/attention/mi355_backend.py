@@ -128,12 +128,12 @@ class Mi355AttnBackend(AttentionBackend):
         return o
 
     def forward_decode_fused_qkv(self, qkv_part, positions, cos_sin_cache, layer, forward_batch,
-                                 part_x_scale=None, part_w_scale=None):
+                                 part_x_scale=None, part_w_scale=None, out_dtype=None):
         """Decode step from the qkv GEMM's split-K partials: reduction, RoPE, KV-cache write and
         attention in one launch (ops.decode_attention_fused_qkv).  Same result as rotary_emb +
         forward_decode(save_kv_cache=True) on the reduced projection."""
         o = torch.empty((qkv_part.shape[1], layer.tp_q_head_num * layer.v_head_dim),
-                        dtype=forward_batch.token_to_kv_pool.dtype, device=qkv_part.device)
+                        dtype=out_dtype or forward_batch.token_to_kv_pool.dtype, device=qkv_part.device)
         pool = forward_batch.token_to_kv_pool
         md = self.forward_metadata
         get_ops().decode_attention_fused_qkv(

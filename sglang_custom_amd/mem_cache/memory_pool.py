@@ -79,7 +79,14 @@ class MHATokenToKVPool:
     def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor,
                       k_scale=None, v_scale=None, layer_id_override: Optional[int] = None):
         layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
-        if cache_k.dtype != self.dtype:
+        if self.dtype == torch.float8_e4m3fn:
+            # fp8 cache (memory_pool.py:436-446): optional per-layer scales divide first, the cast to
+            # e4m3fn happens inside the scatter kernel (saturating at +-448)
+            if k_scale is not None:
+                cache_k = cache_k / k_scale
+            if v_scale is not None:
+                cache_v = cache_v / v_scale
+        elif cache_k.dtype != self.dtype:
             cache_k = cache_k.to(self.dtype)
             cache_v = cache_v.to(self.dtype)
         get_ops().set_kv_buffer(self.k_buffer[layer_id], self.v_buffer[layer_id], loc, cache_k, cache_v)

@@ -74,7 +74,11 @@ class ModelRunner:
     def init_memory_pool(self):
         cfg, sa = self.model_config, self.server_args
         kv_heads = cfg.get_num_kv_heads(self.tp_size)
-        cell = 2 * kv_heads * cfg.head_dim * cfg.num_hidden_layers * torch.finfo(self.dtype).bits // 8
+        kvd = getattr(sa, "kv_cache_dtype", "auto") or "auto"
+        if kvd not in ("auto", "fp8_e4m3"):
+            raise ValueError(f"kv_cache_dtype {kvd!r}: expected 'auto' or 'fp8_e4m3'")
+        self.kv_cache_dtype = torch.float8_e4m3fn if kvd == "fp8_e4m3" else self.dtype
+        cell = 2 * kv_heads * cfg.head_dim * cfg.num_hidden_layers * torch.finfo(self.kv_cache_dtype).bits // 8
         if sa.max_total_tokens is not None:
             self.max_total_num_tokens = sa.max_total_tokens
         else:
@@ -88,7 +92,7 @@ class ModelRunner:
         # whole pages only (model_runner.py:1101-1106 rounds the same way)
         self.max_total_num_tokens = self.max_total_num_tokens // page * page
         self.token_to_kv_pool = MHATokenToKVPool(
-            self.max_total_num_tokens, page, self.dtype, kv_heads, cfg.head_dim,
+            self.max_total_num_tokens, page, self.kv_cache_dtype, kv_heads, cfg.head_dim,
             cfg.num_hidden_layers, self.device)
         if page == 1:
             self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(

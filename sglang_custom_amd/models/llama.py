@@ -101,14 +101,15 @@ class LlamaAttention(nn.Module):
         backend = forward_batch.attn_backend
         pool = forward_batch.token_to_kv_pool
         if (not forward_batch.forward_mode.is_decode() or not hasattr(backend, "forward_decode_fused_qkv")
-                or getattr(pool, "dtype", None) != hidden_states.dtype
+                or getattr(pool, "dtype", None) not in (hidden_states.dtype, torch.float8_e4m3fn)
                 or not backend.supports_fused_qkv(self.attn, self.rotary_emb, hidden_states.dtype)):
             return None
         part = decode_linear_deferred(self.qkv_proj, hidden_states, needs_all_reduce=False)
         if part is None:
             return None
         return backend.forward_decode_fused_qkv(part.part, positions, self.rotary_emb.cos_sin_cache, self.attn,
-                                                forward_batch, part.x_scale, part.w_scale)
+                                                forward_batch, part.x_scale, part.w_scale,
+                                                out_dtype=hidden_states.dtype)
 
     def forward(self, positions, hidden_states, forward_batch):
         attn_output = self._fused_decode(positions, hidden_states, forward_batch)
@@ -121,8 +122,12 @@ class LlamaAttention(nn.Module):
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         pool = forward_batch.token_to_kv_pool
         kb, vb = pool.get_kv_buffer(self.attn.layer_id)
-        self.rotary_emb.forward_with_kv_write(positions, q, k, v, kb, vb, forward_batch.out_cache_loc)
-        attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        if kb.dtype == q.dtype:
+            self.rotary_emb.forward_with_kv_write(positions, q, k, v, kb, vb, forward_batch.out_cache_loc)
+            attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        else:   # fp8 KV cache: the attention backend's own (quantising) KV write
+            q, k = self.rotary_emb(positions, q, k)
+            attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=True)
         deferred = decode_linear_deferred(self.o_proj, attn_output)   # summed by post_attention_layernorm
         if deferred is not None:
             return deferred

@@ -38,6 +38,14 @@ def _gpu(*ts):
             raise RuntimeError("mi355 hot-path ops need tensors on the GPU (no CPU fallback)")
 
 
+KV_FP8 = 0x100   # MI355_KV_FP8: OR'ed into the dtype code when the KV cache holds e4m3fn bytes
+
+
+def _kvdt(t: torch.Tensor, cache: torch.Tensor) -> int:
+    """dtype code of the 16-bit tensors, flagged when `cache` is an fp8 KV buffer."""
+    return _dt(t) | (KV_FP8 if cache.dtype == torch.float8_e4m3fn else 0)
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -131,14 +139,15 @@ def set_kv_buffer(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Ten
     k2, v2 = cache_k.view(T, -1), cache_v.view(T, -1)
     assert k2.stride(1) == 1 and v2.stride(1) == 1 and loc.is_contiguous()
     assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
-    assert k_buffer.dtype == cache_k.dtype == cache_v.dtype == v_buffer.dtype
+    assert cache_k.dtype == cache_v.dtype and k_buffer.dtype == v_buffer.dtype
+    assert k_buffer.dtype in (cache_k.dtype, torch.float8_e4m3fn)
     k_row = k_buffer.numel() // k_buffer.shape[0]
     v_row = v_buffer.numel() // v_buffer.shape[0]
     assert k2.shape[1] == k_row and v2.shape[1] == v_row
     check(_lib_().mi355_set_kv_buffer(k_buffer.data_ptr(), v_buffer.data_ptr(), k2.data_ptr(),
                                       v2.data_ptr(), loc.data_ptr(), _IT[loc.dtype], T, k_row,
                                       v_row, k2.stride(0), v2.stride(0), k_buffer.shape[0],
-                                      _dt(cache_k), _stream(cache_k)), "set_kv_buffer")
+                                      _kvdt(cache_k, k_buffer), _stream(cache_k)), "set_kv_buffer")
 
 
 def embedding(ids: torch.Tensor, table: torch.Tensor, vocab_start: int = 0,
@@ -294,7 +303,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
         req_to_token.stride(0), _p(attn_logits), _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, Dv,
-        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _dt(q), _stream(q)),
+        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer), _stream(q)),
         "decode_attention")
 
 
@@ -310,7 +319,8 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
     assert qkv_part.dim() == 3 and qkv_part.is_contiguous() and qkv_part.dtype == torch.float32
     assert qkv_part.shape[1] == B and qkv_part.shape[2] == (Hq + 2 * Hkv) * D
     assert k_buffer.is_contiguous() and v_buffer.is_contiguous() and o.is_contiguous()
-    assert k_buffer.shape[1:] == (Hkv, D) and v_buffer.shape == k_buffer.shape and k_buffer.dtype == o.dtype == v_buffer.dtype
+    assert k_buffer.shape[1:] == (Hkv, D) and v_buffer.shape == k_buffer.shape
+    assert k_buffer.dtype == v_buffer.dtype and k_buffer.dtype in (o.dtype, torch.float8_e4m3fn)
     assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == B
     assert out_cache_loc.dtype == torch.int64 and out_cache_loc.is_contiguous() and out_cache_loc.numel() == B
     assert cos_sin_cache.is_contiguous() and cos_sin_cache.shape[1] == D
@@ -324,7 +334,7 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
         out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
         _dt(cos_sin_cache), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0), _p(attn_logits),
-        _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _dt(o), _stream(o)),
+        _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _kvdt(o, k_buffer), _stream(o)),
         "decode_attention_fused_qkv")
 
 
@@ -375,7 +385,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         1 if is_causal else 0, 1 if skip_prefix_custom_mask else 0, bs, int(max_len_extend), Hq,
         Hkv, D, Dv, q_extend.stride(0), k_extend.stride(0), v_extend.stride(0),
         k_buffer.shape[0], float(sm_scale), float(logit_cap), int(sliding_window_size),
-        _dt(q_extend), _stream(q_extend)), "extend_attention")
+        _kvdt(q_extend, k_buffer), _stream(q_extend)), "extend_attention")
 
 
 # ---------------------------------------------------------------------------------- linear

@@ -23,6 +23,7 @@ class ServerArgs:
     random_seed: int = 0
     simulate_tp_shard: bool = False             # measurement aid: one TP rank, collectives stubbed
     chunked_prefill_size: Optional[int] = None   # None / -1: prompts are never split
+    kv_cache_dtype: str = "auto"                  # "auto" = model dtype | "fp8_e4m3"
     page_size: int = 1                            # KV slots per page (> 1: page-aligned allocation)
     max_prefill_tokens: int = 16384
     dist_backend: Optional[str] = None          # default: nccl (RCCL) on GPU, gloo on CPU

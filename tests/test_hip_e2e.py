@@ -25,7 +25,7 @@ def t(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def make_runner(preset, dtn, graphs, quant=None, max_total_tokens=2048):
+def make_runner(preset, dtn, graphs, quant=None, max_total_tokens=2048, kv_cache_dtype="auto"):
     from sglang_custom_amd.configs.model_config import ModelConfig
     from sglang_custom_amd.model_executor.model_runner import ModelRunner
     from sglang_custom_amd.server_args import ServerArgs
@@ -34,7 +34,8 @@ def make_runner(preset, dtn, graphs, quant=None, max_total_tokens=2048):
     cfg = hf_config_dict(preset, tname)
     w = make_synthetic_llama_weights(cfg, seed=1234, dtype=DT[dtn])
     sa = ServerArgs(dtype=tname, max_total_tokens=max_total_tokens, max_running_requests=16,
-                    disable_cuda_graph=not graphs, cuda_graph_bs=[1, 2, 4], quantization=quant)
+                    disable_cuda_graph=not graphs, cuda_graph_bs=[1, 2, 4], quantization=quant,
+                    kv_cache_dtype=kv_cache_dtype)
     mr = ModelRunner(ModelConfig(cfg, dtype=tname), sa, weights={k: v.cuda() for k, v in w.items()})
     return mr, cfg, w
 
@@ -247,20 +248,20 @@ def test_radix_prefix_cache_on_gpu_matches_isolated_generation():
         assert r.output_ids == ref_toks[0].tolist(), r.rid
 
 
-@pytest.mark.parametrize("quant", [None, "w8a8_fp8"])
+@pytest.mark.parametrize("quant,kvd", [(None, "auto"), ("w8a8_fp8", "auto"), (None, "fp8_e4m3")])
 @pytest.mark.parametrize("graphs", [False, True])
-def test_decode_fusion_is_bit_identical_end_to_end(graphs, quant):
+def test_decode_fusion_is_bit_identical_end_to_end(graphs, quant, kvd):
     """bf16 decode with the fused step (qkv partials -> one attention launch; o/down partials summed by
     the norms; for fp8 W8A8 also the quantisation fused into the norms / SiLU-mul) against the same model
     with every fusion switched off: logits equal bit for bit at every step, KV cache contents equal."""
     from sglang_custom_amd.layers.quantization import unquant
 
-    name, preset, dtn, lens, steps = [c for c in cases.E2E_CASES if c[2] == "bf16"][0]
+    name, preset, dtn, lens, steps = [c for c in cases.E2E_CASES if c[2] == "bf16" and "d128" in c[1]][0]
     outs = []
     for fusion in (True, False):
         unquant.DECODE_FUSION = fusion
         try:
-            mr, cfg, _ = make_runner(preset, dtn, graphs, quant=quant)
+            mr, cfg, _ = make_runner(preset, dtn, graphs, quant=quant, kv_cache_dtype=kvd)
             prompts = cases.e2e_prompts(cfg["vocab_size"], lens)
             toks, logits, locs, _ = run_steps(mr, prompts, steps + 3)
             kb, vb = mr.token_to_kv_pool.get_kv_buffer(0)
@@ -270,4 +271,26 @@ def test_decode_fusion_is_bit_identical_end_to_end(graphs, quant):
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
-    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    u8 = lambda t_: t_.view(torch.uint8)
+    assert torch.equal(u8(outs[0][2]), u8(outs[1][2])) and torch.equal(u8(outs[0][3]), u8(outs[1][3]))
+
+
+def test_fp8_kv_cache_end_to_end_close_to_16bit_cache():
+    """kv_cache_dtype fp8_e4m3 on the bf16 model (prefill, chunk-free, then decode under graphs): the
+    cache holds e4m3 bytes, logits stay within fp8 rounding of the 16-bit-cache run and the greedy
+    tokens agree wherever the top-2 margin is decisive."""
+    name, preset, dtn, lens, steps = [c for c in cases.E2E_CASES if c[2] == "bf16" and "d128" in c[1]][0]
+    runs = {}
+    for kvd in ("auto", "fp8_e4m3"):
+        mr, cfg, _ = make_runner(preset, dtn, True, kv_cache_dtype=kvd)
+        prompts = cases.e2e_prompts(cfg["vocab_size"], lens)
+        forced = runs["auto"][0] if kvd != "auto" else None
+        toks, logits, _, _ = run_steps(mr, prompts, steps, forced_tokens=forced)
+        runs[kvd] = (toks, logits, mr.token_to_kv_pool.get_key_buffer(0).dtype)
+    assert runs["fp8_e4m3"][2] == torch.float8_e4m3fn
+    for s, (a, b) in enumerate(zip(runs["auto"][1], runs["fp8_e4m3"][1])):
+        assert (a - b).abs().max() < 0.25, s
+        top2 = a.topk(2, dim=-1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > 0.5
+        assert torch.equal(runs["auto"][0][decisive, s], runs["fp8_e4m3"][0][decisive, s])
+

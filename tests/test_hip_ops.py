@@ -763,3 +763,80 @@ def test_fp8_fused_producers_and_deferred_reduction_are_bit_identical(ops):
         torch.cuda.synchronize()
         assert torch.equal(r0, r1) and torch.equal(y, y1), (m, n, k, part.shape[0])
         assert torch.equal(q0.view(torch.uint8), q1.view(torch.uint8)) and torch.equal(s0, s1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+def test_fp8_kv_cache_write_decode_extend_and_fused(ops, dtn):
+    """kv_cache_dtype fp8_e4m3: set_kv_buffer stores clamp-round-to-e4m3 bytes (== torch's cast), decode
+    and prefix-extend attention over the fp8 cache equal the same kernels over a 16-bit cache holding
+    the widened values bit for bit, and the fused decode launch equals the unfused fp8 sequence."""
+    dt = DT[dtn]
+    torch.manual_seed(8)
+    Hq, Hkv, D = 8, 2, 128
+    lens = [70, 1, 33, 129, 16]
+    B, total = len(lens), sum(lens)
+    slots = total + 5
+    k = torch.randn(total, Hkv, D, device=DEV, dtype=dt) * 3
+    v = torch.randn(total, Hkv, D, device=DEV, dtype=dt) * 3
+    k[0, 0, :4] = torch.tensor([500.0, -1000.0, 448.0, 1e-4], device=DEV, dtype=dt)     # saturation / underflow
+    loc = (torch.randperm(slots - 1, device=DEV)[:total] + 1)
+    kb8 = torch.zeros(slots, Hkv, D, device=DEV, dtype=torch.float8_e4m3fn)
+    vb8 = torch.zeros_like(kb8)
+    ops.set_kv_buffer(kb8, vb8, loc, k, v)
+    ref_k = ops_ref.kv_to_fp8_and_back(k.cpu())
+    assert torch.equal(kb8[loc].view(torch.uint8).cpu(), k.float().clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).cpu())
+    kbw, vbw = kb8.to(dt), vb8.to(dt)                      # the widened cache
+    assert torch.equal(kbw[loc].cpu(), ref_k)
+    r2t = torch.zeros(B, max(lens), dtype=torch.int32, device=DEV)
+    off = 0
+    for b, n in enumerate(lens):
+        r2t[b, :n] = loc[off:off + n].int()
+        off += n
+    rpi = torch.arange(B, device=DEV)
+    sl = torch.tensor(lens, device=DEV, dtype=torch.int64)
+    q = torch.randn(B, Hq, D, device=DEV, dtype=dt)
+    for splits in (1, 3):
+        lg = torch.empty(B, Hq, splits, D, dtype=torch.float32, device=DEV)
+        ls = torch.empty(B, Hq, splits, dtype=torch.float32, device=DEV)
+        o8, ow = torch.empty_like(q), torch.empty_like(q)
+        ops.decode_attention_paged(q, kb8, vb8, o8, r2t, rpi, sl, lg, ls, splits, D ** -0.5)
+        ops.decode_attention_paged(q, kbw, vbw, ow, r2t, rpi, sl, lg, ls, splits, D ** -0.5)
+        assert torch.equal(o8, ow), splits
+    # extend over an fp8 prefix: the last `ext` tokens of every sequence attend over prefix + themselves
+    ext = [min(n, 9) for n in lens]
+    pre = [n - e for n, e in zip(lens, ext)]
+    rows = [torch.arange(sum(lens[:b]) + pre[b], sum(lens[:b]) + lens[b], device=DEV) for b in range(B)]
+    qe = torch.randn(sum(ext), Hq, D, device=DEV, dtype=dt)
+    ke, ve = kbw[loc][torch.cat(rows)].contiguous(), vbw[loc][torch.cat(rows)].contiguous()
+    qo = torch.tensor([0] + list(np.cumsum(ext)), dtype=torch.int32, device=DEV)
+    kvp = torch.tensor([0] + list(np.cumsum(pre)), dtype=torch.int32, device=DEV)
+    kvi = torch.cat([r2t[b, :pre[b]] for b in range(B)] + [torch.zeros(1, dtype=torch.int32, device=DEV)])
+    oe8, oew = torch.empty_like(qe), torch.empty_like(qe)
+    ops.extend_attention_fwd(qe, ke, ve, oe8, kb8, vb8, qo, kvp, kvi, None, True, None, max(ext), D ** -0.5)
+    ops.extend_attention_fwd(qe, ke, ve, oew, kbw, vbw, qo, kvp, kvi, None, True, None, max(ext), D ** -0.5)
+    assert torch.equal(oe8, oew)
+    # fused decode launch over the fp8 cache == linear -> rope -> set_kv (fp8) -> decode attention
+    hidden = 512
+    n = (Hq + 2 * Hkv) * D
+    w = torch.randn(n, hidden, device=DEV, dtype=dt) * 0.04
+    wp = ops.pack_weight(w)
+    x = torch.randn(B, hidden, device=DEV, dtype=dt)
+    newloc = torch.stack([r2t[b, lens[b] - 1] for b in range(B)]).to(torch.int64)
+    cache = torch.cat([torch.randn(200, D // 2, device=DEV).cos(), torch.randn(200, D // 2, device=DEV).sin()], 1).contiguous()
+    lg = torch.empty(B, Hq, 1, D, dtype=torch.float32, device=DEV)
+    ls = torch.empty(B, Hq, 1, dtype=torch.float32, device=DEV)
+    ka, va = kb8.clone(), vb8.clone()
+    qkv = ops.linear_packed(x, wp, n)
+    q2, k2, v2 = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    ops.rope_inplace(sl - 1, q2, k2, D, cache, True)
+    ops.set_kv_buffer(ka, va, newloc, k2.reshape(B, Hkv, D), v2.reshape(B, Hkv, D))
+    o_ref = torch.empty(B, Hq, D, device=DEV, dtype=dt)
+    ops.decode_attention_paged(q2.reshape(B, Hq * D).contiguous().view(B, Hq, D), ka, va, o_ref, r2t, rpi, sl, lg, ls, 1, D ** -0.5)
+    kf, vf = kb8.clone(), vb8.clone()
+    o = torch.empty_like(o_ref)
+    ops.decode_attention_fused_qkv(ops.linear_packed_partials(x, wp, n), sl - 1, newloc, cache, kf, vf, o, r2t, rpi, sl,
+                                   lg, ls, 1, D ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(ka.view(torch.uint8), kf.view(torch.uint8)) and torch.equal(va.view(torch.uint8), vf.view(torch.uint8))
+    assert torch.equal(o, o_ref)

@@ -13,6 +13,9 @@ slots = bs * max(1100, SP + 80) + 16
 torch.manual_seed(0)
 kb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
 vb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
+import os
+if os.environ.get('KV8'):
+    kb = [t.to(torch.float8_e4m3fn) for t in kb]; vb = [t.to(torch.float8_e4m3fn) for t in vb]
 q = torch.randn(bs, hq, D, device='cuda').bfloat16()
 o = torch.empty_like(q)
 # prompt tokens contiguous per request, decode tokens interleaved across requests (as the allocator hands them out)
@@ -37,11 +40,11 @@ def timeit(fn, reps=12):
     return e0.elapsed_time(e1) / (3 * reps) * 1e3
 # reference
 idx = r2t[:, :ctx].long()
-K = kb[0][idx].float(); V = vb[0][idx].float()            # [bs, ctx, hkv, D]
+K = kb[0].float()[idx]; V = vb[0].float()[idx]            # [bs, ctx, hkv, D]
 qg = q.float().view(bs, hkv, hq // hkv, D)
 s = torch.einsum('bhgd,bkhd->bhgk', qg, K) * D ** -0.5
 ref = torch.einsum('bhgk,bkhd->bhgd', s.softmax(-1), V).reshape(bs, hq, D)
-nbytes = bs * ctx * hkv * D * 2 * 2
+nbytes = bs * ctx * hkv * D * 2 * kb[0].element_size()
 for dbg in (1, 0):
     lib.mi355_debug_set(6, dbg)   # 1 = P.V on the vector ALU, 0 = on MFMA
     for ns in (1, 2, 3, 4):
