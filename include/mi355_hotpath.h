@@ -135,6 +135,13 @@ int mi355_compute_position(const int32_t* extend_prefix_lens, const int32_t* ext
                            int64_t* positions, int32_t* extend_start_loc, int64_t bs,
                            void* stream);
 
+/* dst[i][0..n) = src[i][0..n) for i < count <= 5 int64 device vectors, one launch: the refresh of a
+ * captured decode step's static inputs (input_ids, req_pool_indices, seq_lens, out_cache_loc,
+ * positions).  dst / src are HOST arrays of device pointers.
+ * replaces: the five tensor.copy_ calls of CudaGraphRunner.replay_prepare
+ *           (model_executor/cuda_graph_runner.py:652-676). */
+int mi355_copy_decode_inputs(int64_t* const* dst, const int64_t* const* src, int count, int64_t n, void* stream);
+
 /* ---- K18 paged slot allocation (page_size > 1) ----------------------------------------------
  * Page-aligned KV slots for a batch, taken in request order from the front of free_pages (page
  * ids; slot = page * page_size + offset).  alloc_extend: request b extends from prefix_lens[b] to

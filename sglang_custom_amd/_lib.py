@@ -48,6 +48,7 @@ _SIGNATURES = {
     "mi355_debug_xcc_map": (I, [P, I, P]),
     "mi355_prefetch_next": (I, [P, L, L, L, I, L]),
     "mi355_decode_attention_fused_qkv": (I, [P, I, P, P, P, P, P, I, P, P, P, P, I, P, P, P, L, P, P, I, L, I, I, I, L, F, I, P]),
+    "mi355_copy_decode_inputs": (I, [P, P, I, L, P]),
     "mi355_alloc_extend": (I, [P, P, P, P, P, P, L, L, P]),
     "mi355_alloc_decode": (I, [P, P, P, P, P, L, L, P]),
     "mi355_fp8_packed_splits": (I, [L, L, L]),

@@ -160,6 +160,16 @@ __global__ __launch_bounds__(256) void alloc_decode_kernel(
   if (threadIdx.x == 0) totals[0] = base;
 }
 
+// Five int64 vectors of n elements copied in one launch (the static inputs of a captured decode step).
+struct Copy5 {
+  int64_t* dst[5];
+  const int64_t* src[5];
+};
+__global__ __launch_bounds__(256) void copy5_kernel(Copy5 c, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) c.dst[blockIdx.y][i] = c.src[blockIdx.y][i];
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -263,6 +273,20 @@ int mi355_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const i
   hipLaunchKernelGGL(alloc_decode_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq_lens, last_loc,
                      free_pages, out_indices, totals, (int)bs, page_size);
   MI355_CHECK_LAUNCH("alloc_decode");
+  return MI355_OK;
+}
+
+int mi355_copy_decode_inputs(int64_t* const* dst, const int64_t* const* src, int count, int64_t n, void* stream) {
+  MI355_REQUIRE(dst && src && count >= 1 && count <= 5 && n >= 0, MI355_ERR_INVALID, "copy_decode_inputs: bad arguments");
+  if (n == 0) return MI355_OK;
+  Copy5 c;
+  for (int i = 0; i < 5; ++i) {
+    c.dst[i] = dst[i < count ? i : 0];
+    c.src[i] = src[i < count ? i : 0];
+    MI355_REQUIRE(c.dst[i] && c.src[i], MI355_ERR_INVALID, "copy_decode_inputs: null pointer");
+  }
+  hipLaunchKernelGGL(copy5_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)count), dim3(256), 0, (hipStream_t)stream, c, n);
+  MI355_CHECK_LAUNCH("copy_decode_inputs");
   return MI355_OK;
 }
 

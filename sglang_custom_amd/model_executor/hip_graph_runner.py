@@ -9,6 +9,7 @@ from typing import Dict, List
 import torch
 
 from ..layers.logits_processor import LogitsProcessorOutput
+from ..ops_backend import get_ops
 from .forward_batch_info import ForwardBatch, ForwardMode
 
 
@@ -82,11 +83,15 @@ class HipGraphRunner:
             self.seq_lens.fill_(self.seq_len_fill_value)
             self.out_cache_loc.zero_()
             self.req_pool_indices.zero_()
-        self.input_ids[:raw_bs].copy_(forward_batch.input_ids)
-        self.req_pool_indices[:raw_bs].copy_(forward_batch.req_pool_indices)
-        self.seq_lens[:raw_bs].copy_(forward_batch.seq_lens)
-        self.out_cache_loc[:raw_bs].copy_(forward_batch.out_cache_loc)
-        self.positions[:raw_bs].copy_(forward_batch.positions)
+        dsts = [self.input_ids, self.req_pool_indices, self.seq_lens, self.out_cache_loc, self.positions]
+        srcs = [forward_batch.input_ids, forward_batch.req_pool_indices, forward_batch.seq_lens,
+                forward_batch.out_cache_loc, forward_batch.positions]
+        ops = get_ops()
+        if hasattr(ops, "copy_decode_inputs") and all(t.dtype == torch.int64 and t.is_contiguous() for t in srcs):
+            ops.copy_decode_inputs(dsts, srcs, raw_bs)   # one launch instead of five copies
+        else:
+            for d, s_ in zip(dsts, srcs):
+                d[:raw_bs].copy_(s_)
         self.model_runner.attn_backend.init_forward_metadata_replay_cuda_graph(
             bs, self.req_pool_indices, self.seq_lens, forward_batch.seq_lens_sum, None,
             ForwardMode.DECODE, None, forward_batch.seq_lens_cpu)

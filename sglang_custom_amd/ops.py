@@ -227,6 +227,21 @@ def prepare_decode(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
                                        seq_lens.numel(), _stream(seq_lens)), "prepare_decode")
 
 
+def copy_decode_inputs(dsts, srcs, n: int) -> None:
+    """dsts[i][:n] = srcs[i][:n] for up to five int64 device vectors in one launch (the static inputs
+    of a captured decode step, cuda_graph_runner.py:652-676)."""
+    import ctypes
+
+    assert 1 <= len(dsts) == len(srcs) <= 5
+    for d, s_ in zip(dsts, srcs):
+        _gpu(d, s_)
+        assert d.dtype == s_.dtype == torch.int64 and d.is_contiguous() and s_.is_contiguous()
+        assert d.numel() >= n and s_.numel() >= n
+    arr = ctypes.c_void_p * len(dsts)
+    check(_lib_().mi355_copy_decode_inputs(arr(*[d.data_ptr() for d in dsts]), arr(*[s_.data_ptr() for s_ in srcs]),
+                                           len(dsts), n, _stream(dsts[0])), "copy_decode_inputs")
+
+
 def alloc_extend_pages(prefix_lens: torch.Tensor, seq_lens: torch.Tensor, last_loc: torch.Tensor,
                        free_pages: torch.Tensor, page_size: int, extend_num_tokens: int):
     """Page-aligned slots for an extend batch (allocator.py:276-360).  Returns (out_indices int64
