@@ -272,15 +272,28 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   };
   auto compute = [&](const frag (&wc)[NT][S], int buf) {
     const T* xt = xs + buf * (R * ROW) + r16 * ROW + q * VE;
+    // The activation fragments of step s + 2 are requested before the MFMAs of step s issue, so
+    // the LDS latency sits under matrix work instead of between every read and its MFMA.
+    frag xf[3][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[0][mt] = *reinterpret_cast<const frag*>(xt + mt * 16 * ROW);
+    if (S > 1) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[1][mt] = *reinterpret_cast<const frag*>(xt + mt * 16 * ROW + KSTEP);
+    }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      frag xf[MT];
+      if (s + 2 < S) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const frag*>(xt + mt * 16 * ROW + s * KSTEP);
+        for (int mt = 0; mt < MT; ++mt)
+          xf[(s + 2) % 3][mt] = *reinterpret_cast<const frag*>(xt + mt * 16 * ROW + (s + 2) * KSTEP);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the matrix work (the scheduler would sink them)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = Mfma<T>::run(wc[nt][s], xf[mt], acc[nt][mt]);
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = Mfma<T>::run(wc[nt][s], xf[s % 3][mt], acc[nt][mt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto rotate = [&]() {
@@ -325,9 +338,23 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   // ACT (SiLU-and-mul fused, weights packed with gate/up rows interleaved 8 + 8 per tile): rows
   // 0..7 of a tile are gate features 8 tile .. 8 tile + 7, rows 8..15 the matching up features, so
   // lane (m, q < 2) holds gate values whose up partners sit 32 lanes higher.
+  // four consecutive output features of row m, stored as one 8 / 16-byte access when they all exist
+  auto store4 = [&](OUT* row, int n, int limit, const OUT (&o)[4]) {
+    if (n + 3 < limit && (limit & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+      Vec<OUT, 4> pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pk.v[r] = o[r];
+      stvec<OUT, 4>(row + n, pk);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < limit) row[n + r] = o[r];
+    }
+  };
   auto emit = [&](int nt, int mt, f32x4 v) {
     const int tile = tile0 + WAVES * nt;
     const int m = mt * 16 + r16;
+    OUT o4[4];
     if constexpr (ACT && !FP8) {
       float mine[4], other[4];
 #pragma unroll
@@ -338,29 +365,26 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
       if (q < 2 && m < M) {
         const int half_n = N >> 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = tile * 8 + 4 * q + r;
-          if (n < half_n)
-            y[(int64_t)m * half_n + n] = (OUT)silu_mul_one<T>(from_f32<T>(mine[r]), from_f32<T>(other[r]));
-        }
+        for (int r = 0; r < 4; ++r) o4[r] = (OUT)silu_mul_one<T>(from_f32<T>(mine[r]), from_f32<T>(other[r]));
+        store4(y + (int64_t)m * half_n, tile * 8 + 4 * q, half_n, o4);
       }
     } else {
       if (m >= M) return;
       const int n0 = tile * 16 + q * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + r;
-        if (n >= N) continue;
+        const int n = n0 + r < N ? n0 + r : N - 1;
         if constexpr (FP8) {
           // apply_fp8_linear's epilogue: (acc * x_scale[m]) * w_scale[n] (+ bias), cast once
           float o = (v[r] * x_scale[m]) * w_scale[n];
           if (bias_) o += (float)static_cast<const OUT*>(bias_)[n];
-          y[(int64_t)m * N + n] = (OUT)o;
+          o4[r] = (OUT)o;
         } else {
           const T* bias = static_cast<const T*>(bias_);
-          y[(int64_t)m * N + n] = finish<T, OUT>(v[r], bias ? to_f32(bias[n]) : 0.f);
+          o4[r] = finish<T, OUT>(v[r], bias ? to_f32(bias[n]) : 0.f);
         }
       }
+      store4(y + (int64_t)m * N, n0, N, o4);
     }
   };
 
