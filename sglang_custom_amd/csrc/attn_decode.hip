@@ -707,29 +707,24 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 
   auto load_kv = [&](const int32_t& sk, const int32_t (&sv)[4], KRaw (&kf)[4], VRaw (&vv)[4]) {
     const KVT* krow = kbase + (int64_t)sk * row_stride;
+    if constexpr (KV8) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const KRaw*>(krow + 32 * s);
+      for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const uint2*>(krow + 32 * s);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const VRaw*>(vbase + (int64_t)sv[u] * row_stride);
+      for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const uint2*>(vbase + (int64_t)sv[u] * row_stride);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)sv[u] * row_stride);
+    }
   };
   // One 16-key tile.  A tile past the end of the range is harmless: every key is masked, so the
   // probabilities are zero and the rescale factor is one.
-  auto compute = [&](const KRaw (&kraw)[4], const VRaw (&vraw)[4], int it) {
+  auto compute_tile = [&](frag (&kf)[4], Vec<T, VE> (&vv)[4], int it) {
     // No multiply-add contraction in the softmax: the fused and the plain instantiation of this
     // kernel must round identically (the compiler otherwise contracts differently per instantiation).
 #pragma clang fp contract(off)
-    frag kf[4];
-    Vec<T, VE> vv[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if constexpr (KV8) kf[s] = __builtin_bit_cast(frag, cvt8_from_fp8<T>(kraw[s]));
-      else kf[s] = kraw[s];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if constexpr (KV8) vv[u] = cvt8_from_fp8<T>(vraw[u]);
-      else vv[u] = vraw[u];
-    }
     if constexpr (FUSED) {
       if (owner && it == it_new) {   // this tile's row rl was loaded before the cache held it
 #pragma unroll
@@ -774,13 +769,33 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 #pragma unroll
     for (int u = 0; u < 4; ++u) stvec<T, VE>(v_wr + u * DV_ROW, vv[u]);
     __builtin_amdgcn_wave_barrier();
+    // the running maximum rarely moves after the first tiles: skip the rescale (a multiplication by
+    // exactly 1, so skipping it changes no bit) unless some lane of the wave needs it
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) acc[dt] *= alpha;
+    }
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
       const auto va = TrRead<T>::run(v_rd + 16 * dt);
-      acc[dt] *= alpha;
       acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, va), pb, acc[dt]);
     }
     __builtin_amdgcn_wave_barrier();
+  };
+
+  // widen an fp8 tile on use; a 16-bit tile is computed in place
+  auto compute = [&](KRaw (&kraw)[4], VRaw (&vraw)[4], int it) {
+    if constexpr (KV8) {
+      frag kf[4];
+      Vec<T, VE> vv[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[s] = __builtin_bit_cast(frag, cvt8_from_fp8<T>(kraw[s]));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[u] = cvt8_from_fp8<T>(vraw[u]);
+      compute_tile(kf, vv, it);
+    } else {
+      compute_tile(kraw, vraw, it);
+    }
   };
 
   // Two K/V register buffers: the loads of tile it+1 are in flight while tile it is computed, so a
