@@ -364,7 +364,19 @@ __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restri
   // tile staging: thread -> rows (threadIdx.x >> 4) + 16 i, 16-B chunk (threadIdx.x & 15)
   const int srow = threadIdx.x >> 4, sch = threadIdx.x & 15;
   Vec<T, 8> kreg[4], vreg[4];
+  // rows of the extend part are a fixed stride apart: one base pointer per staged row, no index math
+  const T* k_lin = k_ext + (int64_t)(q_start - prefix + srow) * p.k_stride + (int64_t)kvh * D + sch * 8;
+  const T* v_lin = v_ext + (int64_t)(q_start - prefix + srow) * p.v_stride + (int64_t)kvh * D + sch * 8;
   auto load_tile = [&](int kt) {
+    if (kt * 64 >= prefix && kt * 64 + 63 < total) {   // whole tile in the extend part (workgroup-uniform)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t key = kt * 64 + 16 * i;
+        kreg[i] = ldvec<T, 8>(k_lin + key * p.k_stride);
+        vreg[i] = ldvec<T, 8>(v_lin + key * p.v_stride);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int key = kt * 64 + srow + 16 * i;
@@ -417,15 +429,27 @@ __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restri
     if (kt + 1 < n_tiles) load_tile(kt + 1);
 
     // S^T tile: st[t][r] = score of key 64 kt + 16 t + 4 c + r for this lane's query
+    // k-step major with the four key sub-tiles as independent accumulators; the K fragments of step
+    // s + 1 are requested before the MFMAs of step s issue (the scheduler would otherwise sink every
+    // LDS read next to its MFMA and the product would run at LDS latency)
     f32x4 st[4];
+    frag kf[2][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      kf[0][t] = *reinterpret_cast<const frag*>(k_rd + (16 * t) * XK_ROW);
+    }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const frag kf = *reinterpret_cast<const frag*>(k_rd + (16 * t) * XK_ROW + 32 * s);
-        st[t] = Mfma<T>::run(kf, qf[s], st[t]);
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          kf[(s + 1) & 1][t] = *reinterpret_cast<const frag*>(k_rd + (16 * t) * XK_ROW + 32 * (s + 1));
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st[t] = Mfma<T>::run(kf[s & 1][t], qf[s], st[t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     const bool need_mask = kt * 64 + 63 > wave_min_limit;   // wave-uniform
     float mloc = -INFINITY;
@@ -456,8 +480,11 @@ __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restri
         pb[t >> 1][(t & 1) * 4 + r] = pt;
       }
     lsum = lsum * alpha + psum;
+    // multiplying by exactly 1 changes nothing: rescale only when some lane's maximum moved
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) ot[dt] *= alpha;
+      for (int dt = 0; dt < 8; ++dt) ot[dt] *= alpha;
+    }
 
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
