@@ -62,51 +62,70 @@ __global__ __launch_bounds__(BT) void rmsnorm_vec_kernel(T* __restrict__ out, T*
     const int vi = threadIdx.x + c * BT;
     wv[c] = ldvec<T, VE>(w + (int64_t)(vi < nvec ? vi : 0) * VE);
   }
+  // Phase 1: every load of the row is issued before anything is consumed or stored (a store to the
+  // residual between two chunks would otherwise pin the second chunk's loads behind it): the launch
+  // pays one memory round trip, not one per chunk.  Split-K partials are summed split-major so that
+  // the loads of all chunks of a split are in flight together; the order per element stays split 0, 1, ...
+  Vec<T, VE> a[CHUNKS], b[CHUNKS];
+  float sum[CHUNKS][VE];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int vi = threadIdx.x + c * BT;
+    const int64_t vo = (int64_t)(vi < nvec ? vi : 0) * VE;
+    if (ADD) b[c] = ldvec<T, VE>(rr + vo);
+    if (!part) a[c] = ldvec<T, VE>(xr + vo);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) sum[c][j] = 0.f;
+  }
+  if (part) {
+    // x is still the split-K partials of the GEMM that produced it ([split][rows][hidden] fp32):
+    // sum in split order and round once, exactly as that GEMM's own combine would have.
+    const int64_t split_stride = (int64_t)(gridDim.x - pf_wgs) * hidden;
+    const float* pr = part + row * hidden;
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) {
+#pragma unroll
+      for (int c = 0; c < CHUNKS; ++c) {
+        const int vi = threadIdx.x + c * BT;
+        const int64_t vo = (int64_t)(vi < nvec ? vi : 0) * VE;
+#pragma unroll
+        for (int j4 = 0; j4 < VE; j4 += 4) {
+          const float4 f = *reinterpret_cast<const float4*>(pr + sp * split_stride + vo + j4);
+          sum[c][j4] += f.x; sum[c][j4 + 1] += f.y; sum[c][j4 + 2] += f.z; sum[c][j4 + 3] += f.w;
+        }
+      }
+    }
+    const float xs = part_xs ? part_xs[row] : 1.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int vi = threadIdx.x + c * BT;
+      const int64_t vo = (int64_t)(vi < nvec ? vi : 0) * VE;
+      if (part_xs) {   // partials of an fp8 GEMM: (acc * x_scale[m]) * w_scale[n], its own epilogue
+#pragma unroll
+        for (int j = 0; j < VE; ++j) a[c].v[j] = from_f32<T>((sum[c][j] * xs) * part_ws[vo + j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) a[c].v[j] = from_f32<T>(sum[c][j] + 0.f);
+      }
+    }
+  }
+  // Phase 2: add, store the new residual, accumulate the sum of squares
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) {
     const int vi = threadIdx.x + c * BT;
     if (vi < nvec) {
-      Vec<T, VE> a;
-      if (part) {
-        // x is still the split-K partials of the GEMM that produced it ([split][rows][hidden] fp32):
-        // sum in split order and round once, exactly as that GEMM's own combine would have.
-        const int64_t split_stride = (int64_t)(gridDim.x - pf_wgs) * hidden;
-        const float* pr = part + row * hidden + (int64_t)vi * VE;
-        float sum[VE];
-#pragma unroll
-        for (int j = 0; j < VE; ++j) sum[j] = 0.f;
-#pragma unroll 4
-        for (int sp = 0; sp < nsplit; ++sp) {
-#pragma unroll
-          for (int j4 = 0; j4 < VE; j4 += 4) {
-            const float4 f = *reinterpret_cast<const float4*>(pr + sp * split_stride + j4);
-            sum[j4] += f.x; sum[j4 + 1] += f.y; sum[j4 + 2] += f.z; sum[j4 + 3] += f.w;
-          }
-        }
-        if (part_xs) {   // partials of an fp8 GEMM: (acc * x_scale[m]) * w_scale[n], its own epilogue
-          const float xs = part_xs[row];
-#pragma unroll
-          for (int j = 0; j < VE; ++j) a.v[j] = from_f32<T>((sum[j] * xs) * part_ws[(int64_t)vi * VE + j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < VE; ++j) a.v[j] = from_f32<T>(sum[j] + 0.f);
-        }
-      } else {
-        a = ldvec<T, VE>(xr + (int64_t)vi * VE);
-      }
       if (ADD) {
-        Vec<T, VE> b = ldvec<T, VE>(rr + (int64_t)vi * VE);
         Vec<T, VE> s;
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
-          float f = to_f32(a.v[j]) + to_f32(b.v[j]);
+          float f = to_f32(a[c].v[j]) + to_f32(b[c].v[j]);
           vals[c][j] = f;
           s.v[j] = from_f32<T>(f);
         }
         stvec<T, VE>(rr + (int64_t)vi * VE, s);
       } else {
 #pragma unroll
-        for (int j = 0; j < VE; ++j) vals[c][j] = to_f32(a.v[j]);
+        for (int j = 0; j < VE; ++j) vals[c][j] = to_f32(a[c].v[j]);
       }
 #pragma unroll
       for (int j = 0; j < VE; ++j) ss += vals[c][j] * vals[c][j];
