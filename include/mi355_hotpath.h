@@ -382,6 +382,39 @@ int mi355_fp8_scaled_mm_packed(void* y, const uint8_t* xq, const uint8_t* wq_pac
                                const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
                                void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
 
+/* ---- sum all-reduce over the GPUs of one xGMI hive (tensor parallelism) ------------------------
+ * One process per GPU.  Every rank allocates one shared region, publishes its IPC handle, opens
+ * its peers' handles, and builds a communicator over the n region addresses (its own at [rank]).
+ * A call is one kernel launch (capturable in a HIP graph: it touches only `in`, `out` and the
+ * regions): the input is copied into the rank's region, same-numbered workgroups of all ranks meet
+ * at a flag barrier, partial tensors are pulled over xGMI and summed in fp32 in rank order 0..n-1
+ * with one rounding, so every rank gets the same bits and both algorithms give the same bits.
+ * `in == out` is allowed.  A barrier wait gives up after one second and is counted; mi355_ar_status
+ * reports it.  Calls of one communicator must be issued in the same order, with the same count,
+ * dtype and algo, on every rank, and must not overlap each other.
+ * replaces: init_custom_ar / all_reduce_reg / all_reduce_unreg / dispose / meta_size /
+ *           allocate_meta_buffer / get_meta_buffer_ipc_handle (sgl-kernel/csrc/allreduce/
+ *           custom_all_reduce.hip:13-51,89-110,112-117,146-172), the kernels
+ *           cross_device_reduce_1stage / _2stage (custom_all_reduce_hip.cuh:260-343) and the
+ *           algorithm choice of CustomAllreduce::allreduce (custom_all_reduce_hip.cuh:499-568). */
+int64_t mi355_ar_region_bytes(int64_t max_bytes);           /* max_bytes: positive multiple of 256; -1 otherwise */
+int mi355_ar_alloc_region(void** region, int64_t max_bytes); /* uncached device memory, zeroed; synchronous */
+int mi355_ar_free_region(void* region);
+int mi355_ar_ipc_handle_bytes(void);                         /* 64 */
+int mi355_ar_get_ipc_handle(const void* region, uint8_t* handle);
+int mi355_ar_open_ipc_handle(const uint8_t* handle, void** region);
+int mi355_ar_close_ipc_handle(void* region);
+/* regions[r]: rank r's region as mapped in this process; world in {2, 4, 6, 8} */
+int mi355_ar_init(void** comm, void* const* regions, int rank, int world, int64_t max_bytes);
+int mi355_ar_dispose(void* comm);
+/* 1 = one-shot, 2 = two-shot (reduce-scatter + all-gather) for `bytes` on `world` ranks */
+int mi355_ar_choose_algo(int world, int64_t bytes);
+/* count * element size: a multiple of 16, at most max_bytes; algo 0 = mi355_ar_choose_algo */
+int mi355_ar_all_reduce(void* comm, void* out, const void* in, int64_t count, int dtype, int algo,
+                        void* stream);
+/* waits for `stream`, then MI355_OK, or MI355_ERR_LAUNCH if any barrier wait has timed out so far */
+int mi355_ar_status(void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

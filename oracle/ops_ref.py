@@ -262,3 +262,13 @@ def kv_to_fp8_and_back(x: torch.Tensor) -> torch.Tensor:
     and widened back to x.dtype (the Triton kernels cast K / V to the query dtype before the dot)."""
     return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
 
+
+
+def custom_all_reduce(inputs):
+    """Sum of the ranks' tensors as the reference's one-stage kernel forms it: upcast to fp32,
+    accumulate in rank order 0..n-1, round once to the tensor's dtype
+    (sgl-kernel/csrc/allreduce/custom_all_reduce_hip.cuh:250-258 packed_reduce, :273-279)."""
+    acc = inputs[0].float()
+    for t in inputs[1:]:
+        acc = acc + t.float()
+    return acc.to(inputs[0].dtype)

@@ -57,6 +57,18 @@ _SIGNATURES = {
     "mi355_silu_and_mul_quant_fp8": (I, [P, P, P, L, L, I, P]),
     "mi355_linear_packed_splits": (I, [L, L, L]),
     "mi355_linear_packed_partials": (I, [P, P, P, L, L, L, L, I, P]),
+    "mi355_ar_region_bytes": (L, [L]),
+    "mi355_ar_alloc_region": (I, [P, L]),
+    "mi355_ar_free_region": (I, [P]),
+    "mi355_ar_ipc_handle_bytes": (I, []),
+    "mi355_ar_get_ipc_handle": (I, [P, P]),
+    "mi355_ar_open_ipc_handle": (I, [P, P]),
+    "mi355_ar_close_ipc_handle": (I, [P]),
+    "mi355_ar_init": (I, [P, P, I, I, L]),
+    "mi355_ar_dispose": (I, [P]),
+    "mi355_ar_choose_algo": (I, [I, L]),
+    "mi355_ar_all_reduce": (I, [P, P, P, L, I, I, P]),
+    "mi355_ar_status": (I, [P, P]),
     "mi355_fused_add_rmsnorm_partials": (I, [P, P, P, P, I, L, L, F, I, P]),
     "mi355_per_token_quant_fp8": (I, [P, P, P, L, L, L, I, P]),
     "mi355_fp8_workspace_bytes": (L, [L, L, L]),

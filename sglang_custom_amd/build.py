@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355_hotpath.so")
 SOURCES = ["elementwise.hip", "index_ops.hip", "attn_decode.hip", "attn_extend.hip", "gemm.hip",
-           "sampling.hip", "quant_fp8.hip", "debug_bw.hip"]
+           "sampling.hip", "quant_fp8.hip", "debug_bw.hip", "allreduce.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"),
            os.path.join(os.path.dirname(HERE), "include", "mi355_hotpath.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-gpu-rdc",

@@ -1,0 +1,365 @@
+// Sum all-reduce across the GPUs of one xGMI hive for decode-sized tensors (a few KiB to a few
+// MiB), where a ring collective is bound by its 2(n-1) hops of latency rather than by bandwidth.
+//
+// Every rank owns one shared region (uncached device memory, opened by its peers through IPC):
+//
+//     [ ArSignal | staging: max_bytes | scatter: max_bytes ]
+//
+// One launch does the whole collective.  A workgroup first copies its share of the rank's input
+// into the rank's own staging area, then meets the same-numbered workgroup of every peer at a flag
+// barrier, then pulls that share from every peer's staging area over xGMI (every link is busy at
+// once: xGMI is point to point) and sums it in fp32 in rank order 0..n-1, rounding once.  All ranks
+// therefore produce the same bits, and both algorithms below produce the same bits as each other:
+//
+//   one-shot   every rank sums the whole tensor: (n-1) * bytes pulled per rank, two barriers
+//   two-shot   rank r sums slice r into its scatter area, a barrier, then every rank gathers the n
+//              reduced slices: 2 (n-1)/n * bytes pulled per rank, three barriers
+//
+// Barriers are per workgroup: a workgroup touches only indices that the same-numbered workgroup of
+// a peer wrote (the index sets are built to make that true), so workgroup b never waits for any
+// other workgroup.  Flags are 32-bit counters that only grow (compared through their signed
+// difference, so wrap-around is harmless); they are written with vector atomic stores at system
+// scope.  A wait gives up after AR_TIMEOUT_TICKS of the 100 MHz wall clock and counts the event in
+// the communicator's status word: a lost peer ends in an error code, not in a hung GPU.
+//
+// Follows what the reference's kernels do (sgl-kernel/csrc/allreduce/custom_all_reduce_hip.cuh:
+// 151-248 barriers, 260-282 one stage, 293-343 two stages) with three differences: the copy of the
+// input into IPC-visible memory is part of the kernel (the reference issues a separate device copy
+// outside graphs and registers graph buffers inside them, custom_all_reduce.hip:97-110), the
+// two-stage reduction keeps rank order instead of rotating it, and waits are bounded.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "common.cuh"
+
+namespace mi355 {
+
+constexpr int AR_MAX_RANKS = 8;
+constexpr int AR_MAX_BLOCKS = 64;
+constexpr int AR_THREADS = 512;
+constexpr long long AR_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz constant clock
+
+struct ArSignal {
+  // sig[b][r]: written by rank r's workgroup b, read by the owner's workgroup b
+  alignas(128) uint32_t sig[AR_MAX_BLOCKS][AR_MAX_RANKS];
+  // epoch[b]: how many barriers the owner's workgroup b has passed (only the owner touches it)
+  alignas(128) uint32_t epoch[AR_MAX_BLOCKS];
+};
+static_assert(sizeof(ArSignal) % 256 == 0, "staging area must stay 256-byte aligned");
+
+struct ArPeers {
+  char* base[AR_MAX_RANKS];   // every rank's region as mapped into this process
+};
+
+struct ArComm {
+  int rank, world;
+  int64_t max_bytes;
+  ArPeers peers;
+  uint32_t* status;           // device word: number of waits that timed out
+};
+
+__device__ __forceinline__ ArSignal* ar_signal(char* base) { return reinterpret_cast<ArSignal*>(base); }
+__device__ __forceinline__ char* ar_staging(char* base) { return base + sizeof(ArSignal); }
+__device__ __forceinline__ char* ar_scatter(char* base, int64_t max_bytes) { return base + sizeof(ArSignal) + max_bytes; }
+
+// Meet workgroup blockIdx.x of every peer.  Everything this workgroup stored before the call is
+// visible to the peers' workgroups after it, and the other way round.
+// `epoch` is the workgroup's barrier count, loaded once per launch and stored back at its end.
+template <int NR>
+__device__ __forceinline__ void ar_barrier(const ArPeers& p, int rank, uint32_t& epoch, uint32_t* status) {
+  // Every wave completes its own stores and meets the others; the first wave then publishes them
+  // for the whole workgroup with ONE system-scope release (a write-back of the cache level that
+  // other devices do not see) instead of one per wave, and takes ONE system-scope acquire after
+  // the last flag has arrived instead of one per poll.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  ArSignal* self = ar_signal(p.base[rank]);
+  const uint32_t want = ++epoch;
+  if (threadIdx.x < NR) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __scoped_atomic_store_n(&ar_signal(p.base[threadIdx.x])->sig[blockIdx.x][rank], want, __ATOMIC_RELAXED,
+                            __MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();
+    while ((int32_t)(__scoped_atomic_load_n(&self->sig[blockIdx.x][threadIdx.x], __ATOMIC_RELAXED,
+                                            __MEMORY_SCOPE_SYSTEM) - want) < 0) {
+      if (wall_clock64() - t0 > AR_TIMEOUT_TICKS) {
+        atomicAdd(status, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ uint32_t ar_load_epoch(const ArPeers& p, int rank) {
+  return ar_signal(p.base[rank])->epoch[blockIdx.x];
+}
+__device__ __forceinline__ void ar_store_epoch(const ArPeers& p, int rank, uint32_t epoch) {
+  if (threadIdx.x == 0) ar_signal(p.base[rank])->epoch[blockIdx.x] = epoch;
+}
+
+using ArVec = uint4;   // 16 bytes: 8 16-bit values or 4 floats
+
+template <typename T> struct ArAcc {
+  static constexpr int N = 16 / sizeof(T);
+  float v[N];
+  __device__ __forceinline__ void set(const ArVec& raw) {
+    const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = to_f32(e[i]);
+  }
+  __device__ __forceinline__ void add(const ArVec& raw) {
+    const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += to_f32(e[i]);
+  }
+  __device__ __forceinline__ ArVec get() const {
+    ArVec raw;
+    T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = from_f32<T>(v[i]);
+    return raw;
+  }
+};
+
+template <typename T, int NR>
+__device__ __forceinline__ ArVec ar_reduce(const ArVec* const* src, int64_t idx) {
+  ArVec raw[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) raw[r] = src[r][idx];   // all pulls in flight together
+  ArAcc<T> acc;
+  acc.set(raw[0]);
+#pragma unroll
+  for (int r = 1; r < NR; ++r) acc.add(raw[r]);
+  return acc.get();
+}
+
+template <typename T, int NR>
+__global__ __launch_bounds__(AR_THREADS) void ar_one_shot_kernel(ArPeers p, const ArVec* in, ArVec* out,
+                                                                 int64_t nvec, int rank, uint32_t* status) {
+  const int64_t tid = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
+  ArVec* mine = reinterpret_cast<ArVec*>(ar_staging(p.base[rank]));
+  uint32_t epoch = ar_load_epoch(p, rank);
+  for (int64_t i = tid; i < nvec; i += stride) mine[i] = in[i];
+  ar_barrier<NR>(p, rank, epoch, status);
+  const ArVec* src[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]));
+  for (int64_t i = tid; i < nvec; i += stride) out[i] = ar_reduce<T, NR>(src, i);
+  // nobody may overwrite its staging area (the next call) while a peer still reads it
+  ar_barrier<NR>(p, rank, epoch, status);
+  ar_store_epoch(p, rank, epoch);
+}
+
+template <typename T, int NR>
+__global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArPeers p, const ArVec* in, ArVec* out,
+                                                                 int64_t nvec, int rank, int64_t max_bytes,
+                                                                 uint32_t* status) {
+  const int64_t tid = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
+  const int64_t part = nvec / NR;                       // slice r = [r*part, (r+1)*part), the last one
+  const int64_t last = nvec - part * (NR - 1);          // takes the remainder
+  ArVec* mine = reinterpret_cast<ArVec*>(ar_staging(p.base[rank]));
+  uint32_t epoch = ar_load_epoch(p, rank);
+  // copy-in, slice by slice: thread t of workgroup b writes, in every slice, exactly the offsets
+  // that thread t of workgroup b of the slice's owner reads below
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int64_t len = r == NR - 1 ? last : part;
+    for (int64_t i = tid; i < len; i += stride) mine[r * part + i] = in[r * part + i];
+  }
+  ar_barrier<NR>(p, rank, epoch, status);
+  const ArVec* src[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r])) + rank * part;
+  ArVec* reduced = reinterpret_cast<ArVec*>(ar_scatter(p.base[rank], max_bytes));
+  const int64_t my_len = rank == NR - 1 ? last : part;
+  for (int64_t i = tid; i < my_len; i += stride) reduced[i] = ar_reduce<T, NR>(src, i);
+  ar_barrier<NR>(p, rank, epoch, status);
+  for (int64_t i = tid; i < last; i += stride) {
+    ArVec raw[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (r == NR - 1 || i < part) raw[r] = reinterpret_cast<const ArVec*>(ar_scatter(p.base[r], max_bytes))[i];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (r == NR - 1 || i < part) out[r * part + i] = raw[r];
+  }
+  ar_barrier<NR>(p, rank, epoch, status);
+  ar_store_epoch(p, rank, epoch);
+}
+
+template <typename T, int NR>
+static void ar_launch(const ArComm* c, void* out, const void* in, int64_t nvec, int algo, hipStream_t st) {
+  const int grid = (int)std::min<int64_t>(AR_MAX_BLOCKS, std::max<int64_t>(1, (nvec + AR_THREADS - 1) / AR_THREADS));
+  if (algo == 1)
+    ar_one_shot_kernel<T, NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank, c->status);
+  else
+    ar_two_shot_kernel<T, NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank,
+                                                          c->max_bytes, c->status);
+}
+
+template <typename T>
+static int ar_dispatch_world(const ArComm* c, void* out, const void* in, int64_t nvec, int algo, hipStream_t st) {
+  switch (c->world) {
+    case 2: ar_launch<T, 2>(c, out, in, nvec, algo, st); break;
+    case 4: ar_launch<T, 4>(c, out, in, nvec, algo, st); break;
+    case 6: ar_launch<T, 6>(c, out, in, nvec, algo, st); break;
+    case 8: ar_launch<T, 8>(c, out, in, nvec, algo, st); break;
+    default: set_error("mi355_ar_all_reduce: world size %d (2, 4, 6 or 8)", c->world); return MI355_ERR_UNSUPPORTED;
+  }
+  return MI355_OK;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+#define AR_HIP(call, name)                                                 \
+  do {                                                                     \
+    hipError_t e__ = (call);                                               \
+    if (e__ != hipSuccess) {                                               \
+      set_error("%s: %s: %s", name, #call, hipGetErrorString(e__));        \
+      return MI355_ERR_LAUNCH;                                             \
+    }                                                                      \
+  } while (0)
+
+extern "C" {
+
+int64_t mi355_ar_region_bytes(int64_t max_bytes) {
+  if (max_bytes <= 0 || max_bytes % 256 != 0) return -1;
+  return (int64_t)sizeof(ArSignal) + 2 * max_bytes;
+}
+
+int mi355_ar_alloc_region(void** region, int64_t max_bytes) {
+  MI355_REQUIRE(region && mi355_ar_region_bytes(max_bytes) > 0, MI355_ERR_INVALID,
+                "mi355_ar_alloc_region: max_bytes must be a positive multiple of 256");
+  const size_t bytes = (size_t)mi355_ar_region_bytes(max_bytes);
+  // uncached: flags and payload written by one GPU (or one XCD) must be seen by the others without
+  // waiting for a kernel boundary
+  AR_HIP(hipExtMallocWithFlags(region, bytes, hipDeviceMallocUncached), "mi355_ar_alloc_region");
+  AR_HIP(hipMemset(*region, 0, bytes), "mi355_ar_alloc_region");
+  AR_HIP(hipDeviceSynchronize(), "mi355_ar_alloc_region");
+  return MI355_OK;
+}
+
+int mi355_ar_free_region(void* region) {
+  AR_HIP(hipFree(region), "mi355_ar_free_region");
+  return MI355_OK;
+}
+
+int mi355_ar_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+int mi355_ar_get_ipc_handle(const void* region, uint8_t* handle) {
+  MI355_REQUIRE(region && handle, MI355_ERR_INVALID, "mi355_ar_get_ipc_handle: null argument");
+  hipIpcMemHandle_t h;
+  AR_HIP(hipIpcGetMemHandle(&h, const_cast<void*>(region)), "mi355_ar_get_ipc_handle");
+  std::memcpy(handle, &h, sizeof(h));
+  return MI355_OK;
+}
+
+int mi355_ar_open_ipc_handle(const uint8_t* handle, void** region) {
+  MI355_REQUIRE(region && handle, MI355_ERR_INVALID, "mi355_ar_open_ipc_handle: null argument");
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, sizeof(h));
+  AR_HIP(hipIpcOpenMemHandle(region, h, hipIpcMemLazyEnablePeerAccess), "mi355_ar_open_ipc_handle");
+  return MI355_OK;
+}
+
+int mi355_ar_close_ipc_handle(void* region) {
+  AR_HIP(hipIpcCloseMemHandle(region), "mi355_ar_close_ipc_handle");
+  return MI355_OK;
+}
+
+int mi355_ar_init(void** comm, void* const* regions, int rank, int world, int64_t max_bytes) {
+  MI355_REQUIRE(comm && regions, MI355_ERR_INVALID, "mi355_ar_init: null argument");
+  MI355_REQUIRE(world == 2 || world == 4 || world == 6 || world == 8, MI355_ERR_UNSUPPORTED,
+                "mi355_ar_init: world size %d (2, 4, 6 or 8)", world);
+  MI355_REQUIRE(rank >= 0 && rank < world, MI355_ERR_INVALID, "mi355_ar_init: rank %d of %d", rank, world);
+  MI355_REQUIRE(mi355_ar_region_bytes(max_bytes) > 0, MI355_ERR_INVALID,
+                "mi355_ar_init: max_bytes must be a positive multiple of 256");
+  ArComm* c = new (std::nothrow) ArComm();
+  MI355_REQUIRE(c, MI355_ERR_INVALID, "mi355_ar_init: out of host memory");
+  c->rank = rank;
+  c->world = world;
+  c->max_bytes = max_bytes;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) c->peers.base[r] = nullptr;
+  for (int r = 0; r < world; ++r) {
+    if (!regions[r] || !aligned16(regions[r])) {
+      delete c;
+      set_error("mi355_ar_init: region of rank %d is null or misaligned", r);
+      return MI355_ERR_INVALID;
+    }
+    c->peers.base[r] = static_cast<char*>(regions[r]);
+  }
+  if (hipMalloc(&c->status, 256) != hipSuccess || hipMemset(c->status, 0, 256) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    delete c;
+    set_error("mi355_ar_init: could not allocate the status word");
+    return MI355_ERR_LAUNCH;
+  }
+  *comm = c;
+  return MI355_OK;
+}
+
+int mi355_ar_dispose(void* comm) {
+  if (!comm) return MI355_OK;
+  ArComm* c = static_cast<ArComm*>(comm);
+  (void)hipFree(c->status);
+  delete c;
+  return MI355_OK;
+}
+
+int mi355_ar_choose_algo(int world, int64_t bytes) {
+  // one-shot pulls (n-1) * bytes over n-1 links and saves a barrier; two-shot pulls 2 (n-1)/n of
+  // them.  With two ranks the volumes are equal; from 4 ranks on the extra barrier (one xGMI round
+  // trip, ~2 us) is repaid once a link carries more than ~128 KiB.
+  if (world <= 2) return 1;
+  // Same switch points as the reference (custom_all_reduce_hip.cuh:543-550).
+  return bytes < (world <= 4 ? 512 : 256) * 1024 ? 1 : 2;
+}
+
+int mi355_ar_all_reduce(void* comm, void* out, const void* in, int64_t count, int dtype, int algo, void* stream) {
+  MI355_REQUIRE(comm && out && in, MI355_ERR_INVALID, "mi355_ar_all_reduce: null argument");
+  const ArComm* c = static_cast<const ArComm*>(comm);
+  const int64_t esize = dtype == MI355_F32 ? 4 : 2;
+  const int64_t bytes = count * esize;
+  MI355_REQUIRE(count > 0 && bytes % 16 == 0, MI355_ERR_INVALID,
+                "mi355_ar_all_reduce: %lld bytes is not a positive multiple of 16", (long long)bytes);
+  MI355_REQUIRE(bytes <= c->max_bytes, MI355_ERR_INVALID, "mi355_ar_all_reduce: %lld bytes exceed the region's %lld",
+                (long long)bytes, (long long)c->max_bytes);
+  MI355_REQUIRE(aligned16(in) && aligned16(out), MI355_ERR_INVALID, "mi355_ar_all_reduce: buffers must be 16-byte aligned");
+  MI355_REQUIRE(algo >= 0 && algo <= 2, MI355_ERR_INVALID, "mi355_ar_all_reduce: algo %d (0 auto, 1 one-shot, 2 two-shot)", algo);
+  if (algo == 0) algo = mi355_ar_choose_algo(c->world, bytes);
+  const int64_t nvec = bytes / 16;
+  if (algo == 2 && nvec < c->world) algo = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = MI355_OK;
+  MI355_DISPATCH_DTYPE(dtype, "mi355_ar_all_reduce", rc = ar_dispatch_world<T>(c, out, in, nvec, algo, st));
+  if (rc != MI355_OK) return rc;
+  MI355_CHECK_LAUNCH("mi355_ar_all_reduce");
+  return MI355_OK;
+}
+
+int mi355_ar_status(void* comm, void* stream) {
+  MI355_REQUIRE(comm, MI355_ERR_INVALID, "mi355_ar_status: null communicator");
+  const ArComm* c = static_cast<const ArComm*>(comm);
+  uint32_t n = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  AR_HIP(hipStreamSynchronize(st), "mi355_ar_status");
+  AR_HIP(hipMemcpy(&n, c->status, sizeof(n), hipMemcpyDeviceToHost), "mi355_ar_status");
+  if (n) {
+    set_error("mi355_ar_status: %u barrier waits timed out (a peer did not arrive)", n);
+    return MI355_ERR_LAUNCH;
+  }
+  return MI355_OK;
+}
+
+}  // extern "C"

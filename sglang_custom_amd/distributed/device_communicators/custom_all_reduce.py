@@ -1,0 +1,144 @@
+"""One-launch sum all-reduce over the GPUs of an xGMI hive for decode-sized tensors.
+
+Mirrors the reference's CustomAllreduce
+(python/sglang/srt/distributed/device_communicators/custom_all_reduce.py:146-509): same
+constructor (a non-NCCL process group for the handle exchange, a device, max_size), the same
+`should_custom_ar` rule (byte size a multiple of 16, contiguous, below max_size), and
+`custom_all_reduce(x)` returning a new tensor or None when the tensor does not qualify.
+
+What differs is underneath: the kernels copy their input into the rank's own IPC region as the
+first stage of the launch, so there is no buffer registration, no separate device copy outside
+graphs and nothing to collect after a graph capture (`capture()` is kept as a no-op context for
+call-site compatibility with parallel_state.py:377-378 of the reference).
+"""
+import ctypes
+from contextlib import contextmanager
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from sglang_custom_amd import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+
+
+def is_weak_contiguous(inp: torch.Tensor) -> bool:
+    """Contiguous, or a view covering its whole storage tail (custom_all_reduce.py:139-143)."""
+    return inp.is_contiguous() or (
+        inp.untyped_storage().nbytes() - inp.storage_offset() * inp.element_size()
+        == inp.numel() * inp.element_size())
+
+
+class CustomAllreduce:
+    _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
+    # the reference's ROCm crossover to the ring collective (custom_all_reduce.py:149-151)
+    _MAX_CAR_SIZE = 2 * 8192 * 1024
+
+    def __init__(self, group: dist.ProcessGroup, device, max_size: int = _MAX_CAR_SIZE) -> None:
+        self.disabled = True
+        self._comm = None
+        self._region = None
+        self._opened: List[int] = []
+        self._IS_CAPTURING = False
+        self.group = group
+        assert dist.get_backend(group) != dist.Backend.NCCL, \
+            "CustomAllreduce exchanges IPC handles as Python objects: attach it to a non-NCCL group"
+        rank = dist.get_rank(group=group)
+        world_size = dist.get_world_size(group=group)
+        if world_size == 1 or world_size not in self._SUPPORTED_WORLD_SIZES:
+            return
+        if isinstance(device, int):
+            device = torch.device(f"cuda:{device}")
+        elif isinstance(device, str):
+            device = torch.device(device)
+        self.device = device
+        self.rank, self.world_size, self.max_size = rank, world_size, int(max_size)
+        lib = _lib.load()
+        self._lib = lib
+        with torch.cuda.device(device):
+            region = ctypes.c_void_p()
+            _lib.check(lib.mi355_ar_alloc_region(ctypes.byref(region), self.max_size), "mi355_ar_alloc_region")
+            self._region = region.value
+            hbytes = lib.mi355_ar_ipc_handle_bytes()
+            buf = (ctypes.c_uint8 * hbytes)()
+            _lib.check(lib.mi355_ar_get_ipc_handle(self._region, buf), "mi355_ar_get_ipc_handle")
+            handles = self._gather(bytes(buf))
+            ptrs = (ctypes.c_void_p * world_size)()
+            for r, h in enumerate(handles):
+                if r == rank:
+                    ptrs[r] = self._region
+                else:
+                    p = ctypes.c_void_p()
+                    hb = (ctypes.c_uint8 * hbytes).from_buffer_copy(h)
+                    _lib.check(lib.mi355_ar_open_ipc_handle(hb, ctypes.byref(p)), "mi355_ar_open_ipc_handle")
+                    ptrs[r] = p.value
+                    self._opened.append(p.value)
+            comm = ctypes.c_void_p()
+            _lib.check(lib.mi355_ar_init(ctypes.byref(comm), ptrs, rank, world_size, self.max_size), "mi355_ar_init")
+            self._comm = comm.value
+        # every rank's region is zeroed and mapped everywhere before the first launch
+        dist.barrier(group=group)
+        self.disabled = False
+
+    def _gather(self, obj):
+        """all_gather of a Python object by per-rank broadcasts (all_gather_object does not work on
+        gloo under inference mode; the reference does the same, custom_all_reduce.py:360-382)."""
+        out = []
+        for src in sorted(dist.get_process_group_ranks(self.group)):
+            box = [obj if dist.get_rank() == src else None]
+            dist.broadcast_object_list(box, src=src, group=self.group, device="cpu")
+            out.append(box[0])
+        return out
+
+    @contextmanager
+    def capture(self):
+        """Graph capture needs no registration here; kept for the reference's call sites."""
+        self._IS_CAPTURING = True
+        try:
+            yield
+        finally:
+            self._IS_CAPTURING = False
+
+    def should_custom_ar(self, inp: torch.Tensor) -> bool:
+        if self.disabled:
+            return False
+        inp_size = inp.numel() * inp.element_size()
+        if inp_size == 0 or inp_size % 16 != 0 or inp.dtype not in _DT:
+            return False
+        if not is_weak_contiguous(inp):
+            return False
+        return inp_size < self.max_size
+
+    def all_reduce(self, inp: torch.Tensor, *, out: Optional[torch.Tensor] = None, algo: int = 0) -> torch.Tensor:
+        """out = sum over ranks of inp (out may be inp). algo 0 chooses by size, 1 one-shot, 2 two-shot."""
+        if out is None:
+            out = torch.empty_like(inp)
+        stream = torch.cuda.current_stream(inp.device).cuda_stream
+        _lib.check(self._lib.mi355_ar_all_reduce(self._comm, out.data_ptr(), inp.data_ptr(), inp.numel(),
+                                                 _DT[inp.dtype], algo, stream), "mi355_ar_all_reduce")
+        return out
+
+    def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
+        """The reference's entry point (custom_all_reduce.py:475-498): None when the tensor does not
+        qualify, else a new tensor holding the sum."""
+        if self.disabled or not self.should_custom_ar(input):
+            return None
+        return self.all_reduce(input)
+
+    def check_status(self) -> None:
+        """Synchronises the current stream; raises if any barrier wait has timed out."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.mi355_ar_status(self._comm, stream), "mi355_ar_status")
+
+    def close(self) -> None:
+        if self._comm:
+            torch.cuda.synchronize(self.device)
+            # nobody unmaps a region that a peer's last launch may still be reading
+            dist.barrier(group=self.group)
+            self._lib.mi355_ar_dispose(self._comm)
+            for p in self._opened:
+                self._lib.mi355_ar_close_ipc_handle(p)
+            self._lib.mi355_ar_free_region(self._region)
+            self._comm, self._region, self._opened = None, None, []
+        self.disabled = True

@@ -14,12 +14,18 @@ import torch.distributed as dist
 _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANK = 0
 _TP_SIZE = 1
+_CA_COMM = None      # CustomAllreduce over the TP group, when enabled
 
 
 def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: str = "nccl",
-                                 init_method: Optional[str] = None) -> None:
-    """Create the default process group (if world_size > 1) and use it as the TP group."""
-    global _TP_GROUP, _TP_RANK, _TP_SIZE
+                                 init_method: Optional[str] = None, use_custom_all_reduce: bool = False,
+                                 local_device: int = 0) -> None:
+    """Create the default process group (if world_size > 1) and use it as the TP group.
+
+    use_custom_all_reduce: also build the one-launch xGMI all-reduce for tensors below its size
+    limit (the reference's GroupCoordinator does the same, parallel_state.py:285-297); handles are
+    exchanged over a gloo group created beside the device group.  All ranks must be in one node."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM
     _TP_RANK, _TP_SIZE = rank, world_size
     if world_size == 1:
         _TP_GROUP = None
@@ -28,6 +34,14 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: st
         dist.init_process_group(backend=backend, init_method=init_method or "env://",
                                 world_size=world_size, rank=rank)
     _TP_GROUP = dist.group.WORLD
+    if use_custom_all_reduce and backend == "nccl":
+        from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
+
+        _CA_COMM = CustomAllreduce(dist.new_group(backend="gloo"), local_device)
+
+
+def get_custom_all_reduce():
+    return _CA_COMM
 
 
 _SIMULATED = False
@@ -43,8 +57,10 @@ def init_simulated_shard(world_size: int, rank: int = 0) -> None:
 
 
 def destroy_model_parallel() -> None:
-    global _TP_GROUP, _TP_RANK, _TP_SIZE
-    _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM
+    if _CA_COMM is not None:
+        _CA_COMM.close()
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM = None, 0, 1, None
 
 
 def get_tensor_model_parallel_world_size() -> int:
@@ -63,6 +79,9 @@ def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group (communication_op.py:11-13)."""
     if _TP_SIZE == 1 or _SIMULATED:
         return x
+    if _CA_COMM is not None and _CA_COMM.should_custom_ar(x):
+        # decode-sized: one launch, fp32 sum in rank order (parallel_state.py:466-481 of the reference)
+        return _CA_COMM.all_reduce(x, out=x)
     dist.all_reduce(x, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return x
 

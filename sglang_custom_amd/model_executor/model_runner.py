@@ -68,8 +68,10 @@ class ModelRunner:
             return
         backend = self.server_args.dist_backend or (
             "nccl" if str(self.device).startswith("cuda") else "gloo")
-        parallel_state.init_distributed_environment(self.tp_size, self.tp_rank, backend,
-                                                    self.server_args.dist_init_method)
+        parallel_state.init_distributed_environment(
+            self.tp_size, self.tp_rank, backend, self.server_args.dist_init_method,
+            use_custom_all_reduce=not self.server_args.disable_custom_all_reduce,
+            local_device=torch.device(self.device).index or 0)
 
     def init_memory_pool(self):
         cfg, sa = self.model_config, self.server_args

@@ -25,6 +25,9 @@ class ServerArgs:
     chunked_prefill_size: Optional[int] = None   # None / -1: prompts are never split
     kv_cache_dtype: str = "auto"                  # "auto" = model dtype | "fp8_e4m3"
     page_size: int = 1                            # KV slots per page (> 1: page-aligned allocation)
+    # The reference's flag (server_args.py: disable_custom_all_reduce, default False).  True here: the
+    # one-launch all-reduce has been exercised with ranks sharing one GPU, not yet across xGMI.
+    disable_custom_all_reduce: bool = True
     max_prefill_tokens: int = 16384
     dist_backend: Optional[str] = None          # default: nccl (RCCL) on GPU, gloo on CPU
     dist_init_method: Optional[str] = None

@@ -1,0 +1,155 @@
+"""The one-launch all-reduce (mi355_ar_*) with 2 and 4 ranks.
+
+A test box has one GPU, so the ranks are separate processes that all use cuda:0: each allocates its
+own region, the regions are opened through IPC exactly as between GPUs, and the kernels of the
+ranks meet at the flag barriers while running side by side on the one device.  What this covers is
+the protocol (barriers, index sets, both algorithms, in-place use, back-to-back calls, graph
+replay) and the arithmetic, bit for bit against the oracle's rank-ordered fp32 sum; what it cannot
+cover is xGMI itself.
+
+The rank processes come from a fork server that is started while this module is imported, i.e.
+before anything in the pytest process has touched the GPU: a process that has initialised the GPU
+must not fork-and-exec on the test machines.
+"""
+import multiprocessing as mp
+import os
+import socket
+import traceback
+
+import pytest
+
+_CTX = mp.get_context("forkserver")
+_CTX.set_forkserver_preload([])
+from multiprocessing import forkserver as _forkserver  # noqa: E402
+
+_forkserver.ensure_running()
+
+DTYPES = ("bfloat16", "float16", "float32")
+# element counts: one 16-byte vector, fewer vectors than ranks, ragged slices, one decode step's
+# hidden states at batch 1 / 64 (Llama-3-8B), and the largest the region takes
+COUNTS = (8, 24, 1000 * 8, 4096, 64 * 4096 + 40, (1 << 20) - 8)
+MAX_BYTES = 4 << 20
+
+
+def _inputs(case, world, count, dtype):
+    import torch
+
+    g = torch.Generator().manual_seed(1000 * case + world)
+    return [(torch.randn(count, generator=g) * (r + 1)).to(dtype) for r in range(world)]
+
+
+def _rank_main(rank, world, port, queue):
+    try:
+        import torch
+        import torch.distributed as dist
+
+        from oracle import ops_ref
+        from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
+
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        ca = CustomAllreduce(dist.group.WORLD, 0, max_size=MAX_BYTES)
+        assert not ca.disabled
+        case = 0
+        for dtn in DTYPES:
+            dtype = getattr(torch, dtn)
+            for count in COUNTS:
+                if count * dtype.itemsize > MAX_BYTES or (count * dtype.itemsize) % 16:
+                    continue
+                for algo in (1, 2, 0):
+                    case += 1
+                    ins = _inputs(case, world, count, dtype)
+                    x = ins[rank].cuda()
+                    assert ca.should_custom_ar(x) == (x.numel() * x.element_size() < MAX_BYTES)
+                    out = ca.all_reduce(x, algo=algo)
+                    ca.check_status()
+                    want = ops_ref.custom_all_reduce(ins)
+                    assert torch.equal(out.cpu(), want), (dtn, count, algo)
+                    assert torch.equal(x.cpu(), ins[rank]), "input modified"
+        # back to back without host synchronisation, sizes and algorithms changing, in place
+        pending = []
+        for i, (count, algo) in enumerate([(4096, 1), (64 * 4096, 2), (8, 1), (64 * 4096, 1), (4096 * 3, 2)] * 4):
+            ins = _inputs(500 + i, world, count, torch.bfloat16)
+            x = ins[rank].cuda()
+            ca.all_reduce(x, out=x, algo=algo)
+            pending.append((x, ops_ref.custom_all_reduce(ins)))
+        ca.check_status()
+        for x, want in pending:
+            assert torch.equal(x.cpu(), want)
+        # the reference's entry point: a new tensor, or None for what does not qualify
+        ins = _inputs(900, world, 4096, torch.bfloat16)
+        got = ca.custom_all_reduce(ins[rank].cuda())
+        assert torch.equal(got.cpu(), ops_ref.custom_all_reduce(ins))
+        assert ca.custom_all_reduce(torch.zeros(3, device="cuda", dtype=torch.bfloat16)) is None
+        assert ca.custom_all_reduce(torch.zeros(MAX_BYTES, device="cuda", dtype=torch.bfloat16)) is None
+        # inside a HIP graph: two launches per replay, replayed with new contents
+        ins_a, ins_b = _inputs(901, world, 64 * 4096, torch.bfloat16), _inputs(902, world, 4096, torch.bfloat16)
+        a, b = ins_a[rank].cuda(), ins_b[rank].cuda()
+        oa, ob = torch.empty_like(a), torch.empty_like(b)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ca.all_reduce(a, out=oa)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        dist.barrier()
+        graph = torch.cuda.CUDAGraph()
+        with ca.capture(), torch.cuda.graph(graph):
+            ca.all_reduce(a, out=oa)
+            ca.all_reduce(b, out=ob)
+        for rep in range(3):
+            na, nb = _inputs(910 + rep, world, 64 * 4096, torch.bfloat16), _inputs(920 + rep, world, 4096, torch.bfloat16)
+            a.copy_(na[rank])
+            b.copy_(nb[rank])
+            graph.replay()
+            ca.check_status()
+            assert torch.equal(oa.cpu(), ops_ref.custom_all_reduce(na))
+            assert torch.equal(ob.cpu(), ops_ref.custom_all_reduce(nb))
+        del graph
+        ca.close()
+        dist.destroy_process_group()
+        queue.put((rank, "ok"))
+    except BaseException:  # noqa: BLE001  (reported to the parent, which fails the test)
+        queue.put((rank, traceback.format_exc()))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_all_reduce_ranks_on_one_gpu(world):
+    port = _free_port()
+    queue = _CTX.Queue()
+    procs = [_CTX.Process(target=_rank_main, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            rank, msg = queue.get(timeout=100)
+            results[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in sorted(results.items()))
+
+
+def test_all_reduce_argument_checks_need_no_gpu():
+    """Size rules of the entry points that return before touching a device."""
+    from sglang_custom_amd import _lib
+
+    lib = _lib.load()
+    assert lib.mi355_ar_ipc_handle_bytes() == 64
+    assert lib.mi355_ar_region_bytes(0) == -1 and lib.mi355_ar_region_bytes(100) == -1
+    assert lib.mi355_ar_region_bytes(1 << 20) > 2 << 20
+    # switch points: two ranks always one-shot; the reference's 512 KiB / 256 KiB for 4 / 8 ranks
+    assert [lib.mi355_ar_choose_algo(2, b) for b in (16, 1 << 24)] == [1, 1]
+    assert [lib.mi355_ar_choose_algo(4, b) for b in (512 * 1024 - 16, 512 * 1024)] == [1, 2]
+    assert [lib.mi355_ar_choose_algo(8, b) for b in (256 * 1024 - 16, 256 * 1024)] == [1, 2]
+    assert lib.mi355_ar_all_reduce(None, None, None, 8, _lib.BF16, 0, None) == -1
