@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
                     help="fp8_e4m3: optional reduced-precision KV cache (NOT the headline configuration)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--custom-all-reduce", action="store_true",
+                    help="with --parallelism tp: row-parallel sums and the logits gather through the "
+                         "one-launch xGMI collectives instead of RCCL")
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="measurement aid (not the contract metric): run ONE rank's shard of a TP=N "
                          "configuration on one GPU with the collectives stubbed out")
@@ -225,7 +228,8 @@ def main():
                     max_running_requests=max(bs, 8) + 8, context_length=in_len + out_len + 16,
                     disable_cuda_graph=args.no_graph, cuda_graph_bs=[bs], tp_size=tp,
                     quantization=args.quantization, random_seed=rank if tp == 1 else 0,
-                    simulate_tp_shard=bool(sim), kv_cache_dtype=args.kv_cache_dtype)
+                    simulate_tp_shard=bool(sim), kv_cache_dtype=args.kv_cache_dtype,
+                    disable_custom_all_reduce=not args.custom_all_reduce)
     mc = ModelConfig(cfg, dtype=args.dtype, context_length=in_len + out_len + 16)
     graph_ok = True
     try:

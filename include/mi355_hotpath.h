@@ -412,6 +412,11 @@ int mi355_ar_choose_algo(int world, int64_t bytes);
 /* count * element size: a multiple of 16, at most max_bytes; algo 0 = mi355_ar_choose_algo */
 int mi355_ar_all_reduce(void* comm, void* out, const void* in, int64_t count, int dtype, int algo,
                         void* stream);
+/* out[r * bytes ...] = rank r's `in` (bytes: a multiple of 16, at most max_bytes; out holds
+ * world * bytes; not in place).  Same launch structure and ordering rules as the all-reduce.
+ * replaces: GroupCoordinator.all_gather on the logits (distributed/parallel_state.py:528-597) at
+ *           decode sizes; the reference has no custom kernel for it and goes through RCCL. */
+int mi355_ar_all_gather(void* comm, void* out, const void* in, int64_t bytes, void* stream);
 /* waits for `stream`, then MI355_OK, or MI355_ERR_LAUNCH if any barrier wait has timed out so far */
 int mi355_ar_status(void* comm, void* stream);
 

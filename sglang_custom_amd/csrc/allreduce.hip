@@ -196,6 +196,28 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArPeers p, cons
   ar_store_epoch(p, rank, epoch);
 }
 
+// out[r] = rank r's input, r = 0..n-1: the concatenating all-gather of vocab-sharded logits, with
+// the same copy-in / barrier / pull structure (no arithmetic, so no element type).
+template <int NR>
+__global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, const ArVec* in, ArVec* out, int64_t nvec,
+                                                                   int rank, uint32_t* status) {
+  const int64_t tid = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
+  ArVec* mine = reinterpret_cast<ArVec*>(ar_staging(p.base[rank]));
+  uint32_t epoch = ar_load_epoch(p, rank);
+  for (int64_t i = tid; i < nvec; i += stride) mine[i] = in[i];
+  ar_barrier<NR>(p, rank, epoch, status);
+  for (int64_t i = tid; i < nvec; i += stride) {
+    ArVec raw[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) raw[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]))[i];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) out[r * nvec + i] = raw[r];
+  }
+  ar_barrier<NR>(p, rank, epoch, status);
+  ar_store_epoch(p, rank, epoch);
+}
+
 template <typename T, int NR>
 static void ar_launch(const ArComm* c, void* out, const void* in, int64_t nvec, int algo, hipStream_t st) {
   const int grid = (int)std::min<int64_t>(AR_MAX_BLOCKS, std::max<int64_t>(1, (nvec + AR_THREADS - 1) / AR_THREADS));
@@ -345,6 +367,31 @@ int mi355_ar_all_reduce(void* comm, void* out, const void* in, int64_t count, in
   MI355_DISPATCH_DTYPE(dtype, "mi355_ar_all_reduce", rc = ar_dispatch_world<T>(c, out, in, nvec, algo, st));
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("mi355_ar_all_reduce");
+  return MI355_OK;
+}
+
+int mi355_ar_all_gather(void* comm, void* out, const void* in, int64_t bytes, void* stream) {
+  MI355_REQUIRE(comm && out && in, MI355_ERR_INVALID, "mi355_ar_all_gather: null argument");
+  const ArComm* c = static_cast<const ArComm*>(comm);
+  MI355_REQUIRE(bytes > 0 && bytes % 16 == 0 && bytes <= c->max_bytes, MI355_ERR_INVALID,
+                "mi355_ar_all_gather: %lld bytes per rank (a positive multiple of 16, at most %lld)", (long long)bytes,
+                (long long)c->max_bytes);
+  MI355_REQUIRE(aligned16(in) && aligned16(out), MI355_ERR_INVALID, "mi355_ar_all_gather: buffers must be 16-byte aligned");
+  MI355_REQUIRE(in != out, MI355_ERR_INVALID, "mi355_ar_all_gather: in place is not supported");
+  const int64_t nvec = bytes / 16;
+  const int grid = (int)std::min<int64_t>(AR_MAX_BLOCKS, (nvec + AR_THREADS - 1) / AR_THREADS);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define AR_GATHER(NR) \
+  case NR: ar_all_gather_kernel<NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank, c->status); break
+  switch (c->world) {
+    AR_GATHER(2);
+    AR_GATHER(4);
+    AR_GATHER(6);
+    AR_GATHER(8);
+    default: set_error("mi355_ar_all_gather: world size %d (2, 4, 6 or 8)", c->world); return MI355_ERR_UNSUPPORTED;
+  }
+#undef AR_GATHER
+  MI355_CHECK_LAUNCH("mi355_ar_all_gather");
   return MI355_OK;
 }
 

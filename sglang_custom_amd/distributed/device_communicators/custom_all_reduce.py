@@ -126,6 +126,18 @@ class CustomAllreduce:
             return None
         return self.all_reduce(input)
 
+    def should_custom_ag(self, inp: torch.Tensor) -> bool:
+        size = inp.numel() * inp.element_size()
+        return (not self.disabled) and size > 0 and size % 16 == 0 and size <= self.max_size and inp.is_contiguous()
+
+    def all_gather(self, inp: torch.Tensor) -> torch.Tensor:
+        """[world, *inp.shape]: every rank's tensor, rank-major (one launch, any dtype)."""
+        out = torch.empty((self.world_size,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
+        stream = torch.cuda.current_stream(inp.device).cuda_stream
+        _lib.check(self._lib.mi355_ar_all_gather(self._comm, out.data_ptr(), inp.data_ptr(),
+                                                 inp.numel() * inp.element_size(), stream), "mi355_ar_all_gather")
+        return out
+
     def check_status(self) -> None:
         """Synchronises the current stream; raises if any barrier wait has timed out."""
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -15,6 +15,7 @@ _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANK = 0
 _TP_SIZE = 1
 _CA_COMM = None      # CustomAllreduce over the TP group, when enabled
+_BACKEND = "nccl"
 
 
 def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: str = "nccl",
@@ -25,8 +26,8 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: st
     use_custom_all_reduce: also build the one-launch xGMI all-reduce for tensors below its size
     limit (the reference's GroupCoordinator does the same, parallel_state.py:285-297); handles are
     exchanged over a gloo group created beside the device group.  All ranks must be in one node."""
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM
-    _TP_RANK, _TP_SIZE = rank, world_size
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM, _BACKEND
+    _TP_RANK, _TP_SIZE, _BACKEND = rank, world_size, backend
     if world_size == 1:
         _TP_GROUP = None
         return
@@ -34,10 +35,11 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: st
         dist.init_process_group(backend=backend, init_method=init_method or "env://",
                                 world_size=world_size, rank=rank)
     _TP_GROUP = dist.group.WORLD
-    if use_custom_all_reduce and backend == "nccl":
+    if use_custom_all_reduce:
         from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
 
-        _CA_COMM = CustomAllreduce(dist.new_group(backend="gloo"), local_device)
+        side = _TP_GROUP if backend == "gloo" else dist.new_group(backend="gloo")
+        _CA_COMM = CustomAllreduce(side, local_device)
 
 
 def get_custom_all_reduce():
@@ -82,6 +84,11 @@ def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     if _CA_COMM is not None and _CA_COMM.should_custom_ar(x):
         # decode-sized: one launch, fp32 sum in rank order (parallel_state.py:466-481 of the reference)
         return _CA_COMM.all_reduce(x, out=x)
+    if _BACKEND == "gloo" and x.is_cuda:
+        # rehearsal set-up (device tensors, CPU process group): stage through the host
+        h = x.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=_TP_GROUP)
+        return x.copy_(h)
     dist.all_reduce(x, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return x
 
@@ -95,6 +102,19 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
     if _SIMULATED:
         return torch.cat([x] * _TP_SIZE, dim=dim)
     x = x.contiguous()
+    if _CA_COMM is not None and x.is_cuda and _CA_COMM.should_custom_ag(x):
+        out = _CA_COMM.all_gather(x).movedim(0, dim)
+        shape = list(x.shape)
+        shape[dim] *= _TP_SIZE
+        return out.reshape(shape)
+    if _BACKEND == "gloo" and x.is_cuda:
+        h = x.cpu()
+        out = torch.empty((_TP_SIZE * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h, group=_TP_GROUP)
+        out = out.to(x.device).view((_TP_SIZE,) + tuple(x.shape)).movedim(0, dim)
+        shape = list(x.shape)
+        shape[dim] *= _TP_SIZE
+        return out.reshape(shape)
     # rank-major concatenation along dim 0: the one output layout every backend accepts
     out = torch.empty((_TP_SIZE * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x, group=_TP_GROUP)

@@ -113,6 +113,91 @@ def _rank_main(rank, world, port, queue):
         queue.put((rank, traceback.format_exc()))
 
 
+def _tp_rank_main(rank, world, port, queue, preset, dtn):
+    """One tensor-parallel rank of the tiny Llama on cuda:0: HIP kernels on the rank's shard, the
+    row-parallel sums and the logits gather through the one-launch collectives (also inside the
+    decode graph), the process group itself on gloo."""
+    try:
+        import numpy as np
+        import torch
+
+        from oracle.llama_ref import OracleLlama
+        from sglang_custom_amd import bench_one_batch as bob
+        from sglang_custom_amd.configs.model_config import ModelConfig
+        from sglang_custom_amd.distributed import parallel_state
+        from sglang_custom_amd.managers.schedule_batch import Req
+        from sglang_custom_amd.model_executor.model_runner import ModelRunner
+        from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+        from sglang_custom_amd.server_args import ServerArgs
+
+        torch.cuda.set_device(0)
+        dt = getattr(torch, dtn)
+        cfg = hf_config_dict(preset, dtn)
+        w = make_synthetic_llama_weights(cfg, seed=1234, dtype=dt)
+        rng = np.random.RandomState(0)
+        prompts = [rng.randint(0, cfg["vocab_size"], n).tolist() for n in (5, 17, 32)]
+        sa = ServerArgs(dtype=dtn, max_total_tokens=512, max_running_requests=8, cuda_graph_bs=[4],
+                        dist_backend="gloo", dist_init_method=f"tcp://127.0.0.1:{port}",
+                        disable_custom_all_reduce=False)
+        mr = ModelRunner(ModelConfig(cfg, dtype=dtn), sa, tp_rank=rank, tp_size=world,
+                         weights={k: v.cuda() for k, v in w.items()})
+        ca = parallel_state.get_custom_all_reduce()
+        assert ca is not None and not ca.disabled
+        assert mr.graph_runner is not None
+        nxt, logits, batch = bob.extend([Req(i, p) for i, p in enumerate(prompts)], mr)
+        toks, lgs = [nxt.cpu()], [logits.float().cpu()]
+        for _ in range(3):
+            nxt, logits = bob.decode(nxt, batch, mr)
+            toks.append(nxt.cpu())
+            lgs.append(logits.float().cpu())
+        ca.check_status()
+        toks = torch.stack(toks, 1)
+        if dt == torch.float32:
+            ref_toks, ref_logits = OracleLlama(cfg, w, dt, max_total_tokens=512).generate_greedy(prompts, 4)
+            assert torch.equal(toks, ref_toks), (toks, ref_toks)
+            err = max((a - b.float()).abs().max().item() for a, b in zip(lgs, ref_logits))
+            assert err < 1e-3, err
+        else:
+            # 16-bit: each rank rounds its partial sums before they are added, so the logits are
+            # close to, not equal to, the one-process model's; the prefill step needs no teacher
+            w32 = {k: v.float() for k, v in w.items()}
+            cfg32 = hf_config_dict(preset, "float32")
+            _, ref_logits = OracleLlama(cfg32, w32, torch.float32, max_total_tokens=512).generate_greedy(prompts, 1)
+            err = (lgs[0] - ref_logits[0].float()).abs().max().item()
+            assert err < 6e-2, err
+        parallel_state.destroy_model_parallel()
+        queue.put((rank, (toks.numpy(), torch.stack(lgs).numpy())))
+    except BaseException:  # noqa: BLE001
+        queue.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,dtn", [("tiny-llama-d64", "float32"), ("tiny-llama-d128", "bfloat16")])
+def test_tensor_parallel_two_ranks_on_one_gpu(preset, dtn):
+    import numpy as np
+
+    port = _free_port()
+    queue = _CTX.Queue()
+    procs = [_CTX.Process(target=_tp_rank_main, args=(r, 2, port, queue, preset, dtn)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(2):
+            rank, msg = queue.get(timeout=140)
+            results[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    for r in range(2):
+        assert not isinstance(results[r], str), f"rank {r}: {results[r]}"
+    # both ranks hold the same gathered logits and chose the same tokens
+    assert np.array_equal(results[0][0], results[1][0])
+    assert np.array_equal(results[0][1], results[1][1])
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
