@@ -150,7 +150,7 @@ int mi355_copy_decode_inputs(int64_t* const* dst, const int64_t* const* src, int
  * totals[0] = pages consumed, totals[1] = tokens written.  alloc_decode: one token per request
  * (seq_lens already counts it): last_loc[b] + 1, or the first slot of a new page.  The caller drops
  * totals[0] pages from its free list -- and must have checked that many are available: free_pages
- * is read up to that index.
+ * is read up to that index (it may be null when the list is empty and no new page is needed).
  * replaces: alloc_extend_kernel / alloc_decode_kernel (mem_cache/allocator.py:276-401). */
 int mi355_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
                        const int64_t* free_pages, int64_t* out_indices, int64_t* totals, int64_t bs,

@@ -254,7 +254,8 @@ int mi355_prepare_decode(int32_t* req_to_token, const int64_t* req_pool_indices,
 int mi355_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
                        const int64_t* free_pages, int64_t* out_indices, int64_t* totals, int64_t bs,
                        int64_t page_size, void* stream) {
-  MI355_REQUIRE(prefix_lens && seq_lens && last_loc && free_pages && out_indices && totals, MI355_ERR_INVALID,
+  // free_pages may be null: an empty free list is legal when no request needs a new page
+  MI355_REQUIRE(prefix_lens && seq_lens && last_loc && out_indices && totals, MI355_ERR_INVALID,
                 "alloc_extend: null pointer");
   MI355_REQUIRE(bs >= 0 && bs <= 65535 && page_size >= 1, MI355_ERR_INVALID, "alloc_extend: bad shape");
   if (bs == 0) return MI355_OK;
@@ -266,7 +267,7 @@ int mi355_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, cons
 
 int mi355_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
                        int64_t* out_indices, int64_t* totals, int64_t bs, int64_t page_size, void* stream) {
-  MI355_REQUIRE(seq_lens && last_loc && free_pages && out_indices && totals, MI355_ERR_INVALID,
+  MI355_REQUIRE(seq_lens && last_loc && out_indices && totals, MI355_ERR_INVALID,
                 "alloc_decode: null pointer");
   MI355_REQUIRE(bs >= 0 && bs <= (1 << 24) && page_size >= 1, MI355_ERR_INVALID, "alloc_decode: bad shape");
   if (bs == 0) return MI355_OK;

@@ -38,6 +38,7 @@ class Req:
         self.already_computed = 0
         self.finished = False
         self.last_node = None   # radix-tree node its cached prefix ends in (locked while the request runs)
+        self.is_retracted = False
         self.is_chunked = 0   # > 0 while a prompt is being prefilled in chunks (schedule_batch.py Req.is_chunked)
 
     def init_next_round_input(self, prefix_indices=None):
@@ -46,6 +47,16 @@ class Req:
         self.fill_ids = self.origin_input_ids + self.output_ids
         self.prefix_indices = [] if prefix_indices is None else prefix_indices
         self.extend_input_len = len(self.fill_ids) - len(self.prefix_indices)
+
+    def reset_for_retract(self):
+        """(Req.reset_for_retract) back to a waiting request that keeps its outputs so far."""
+        self.prefix_indices = []
+        self.last_node = None
+        self.req_pool_idx = None
+        self.extend_input_len = 0
+        self.already_computed = 0
+        self.is_chunked = 0
+        self.is_retracted = True
 
     @property
     def seqlen(self) -> int:
@@ -195,6 +206,25 @@ class ScheduleBatch:
                                  self.seq_lens, self.out_cache_loc, self.positions)
         self.seq_lens_cpu_list = [x + 1 for x in self.seq_lens_cpu_list]
         self.seq_lens_sum += bs
+
+    def mix_with_running(self, running_batch: "ScheduleBatch"):
+        """Append the running decode requests (already through prepare_for_decode) to this prefill
+        batch as extends of length 1 over their own KV as prefix (schedule_batch.py:1310-1338)."""
+        self.forward_mode = ForwardMode.MIXED
+        running_bs = running_batch.batch_size()
+        for req in running_batch.reqs:
+            req.fill_ids = req.origin_input_ids + req.output_ids
+            req.extend_input_len = 1
+        input_ids = torch.cat([self.input_ids, running_batch.input_ids])
+        out_cache_loc = torch.cat([self.out_cache_loc, running_batch.out_cache_loc])
+        decode_prefix = [n - 1 for n in running_batch.seq_lens_cpu_list]   # KV before this step's token
+        self.merge_batch(running_batch)
+        self.input_ids = input_ids
+        self.out_cache_loc = out_cache_loc
+        self.prefix_lens = list(self.prefix_lens) + decode_prefix
+        self.extend_lens = list(self.extend_lens) + [1] * running_bs
+        self.extend_num_tokens += running_bs
+        self.positions = None
 
     def get_model_worker_batch(self) -> ModelWorkerBatch:
         if self.forward_mode.is_decode_or_idle():

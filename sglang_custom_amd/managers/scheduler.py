@@ -13,8 +13,14 @@ decode batch, per-step retirement of finished requests with slot release.
 Optional radix prefix cache (mem_cache/radix_cache.py): new requests start from the longest cached
 prefix (its slots become prefix_indices of the extend), finished and chunk-boundary requests hand
 their KV to the tree, and tree leaves are evicted LRU-first when the allocator runs short.
-Left out on purpose: retraction under memory pressure (admission is conservative instead), mixed
-prefill+decode batches, priorities, streaming, the IPC around it."""
+Retraction under memory pressure (update_running_batch :1828-1866, ScheduleBatch.retract_decode
+schedule_batch.py:1362-1484): admission reserves only new_token_ratio of what the running requests
+may still generate; when a decode step finds the pool short, the requests with the fewest outputs
+(longest prompts first among equals) give their slots back and return to the waiting queue with
+their outputs so far, to be prefilled again over prompt + outputs, and the ratio is re-estimated.
+Mixed batches (enable_mixed_chunk): the running decode requests join a prefill batch as extends of
+length 1 (ScheduleBatch.mix_with_running, schedule_batch.py:1310-1338).
+Left out on purpose: priorities, streaming, the IPC around it."""
 from typing import Dict, List, Optional
 
 import torch
@@ -22,6 +28,16 @@ import torch
 from ..mem_cache.radix_cache import RadixCache
 from ..model_executor.forward_batch_info import ForwardBatch
 from .schedule_batch import Req, ScheduleBatch
+
+
+# global_config.py of the reference: retract_decode_steps, default_init_new_token_ratio,
+# default_min_new_token_ratio_factor, default_new_token_ratio_decay_steps
+RETRACT_DECODE_STEPS = 20
+DEFAULT_INIT_NEW_TOKEN_RATIO = 0.7
+MIN_NEW_TOKEN_RATIO_FACTOR = 0.14
+NEW_TOKEN_RATIO_DECAY_STEPS = 600
+# schedule_policy.py CLIP_MAX_NEW_TOKENS_ESTIMATION
+CLIP_MAX_NEW_TOKENS = 4096
 
 
 class Scheduler:
@@ -46,6 +62,14 @@ class Scheduler:
         self.num_prefill_batches = 0
         self.num_decode_steps = 0
         self.evicted_tokens = 0
+        # scheduler.py:478-491
+        self.init_new_token_ratio = min(DEFAULT_INIT_NEW_TOKEN_RATIO * getattr(sa, "schedule_conservativeness", 1.0), 1.0)
+        self.min_new_token_ratio = min(self.init_new_token_ratio * MIN_NEW_TOKEN_RATIO_FACTOR, 1.0)
+        self.new_token_ratio_decay = (self.init_new_token_ratio - self.min_new_token_ratio) / NEW_TOKEN_RATIO_DECAY_STEPS
+        self.new_token_ratio = self.init_new_token_ratio
+        self.total_retracted_reqs = 0
+        self.enable_mixed_chunk = bool(getattr(sa, "enable_mixed_chunk", False))
+        self.num_mixed_batches = 0
 
     # ---- queue ----
     def add_request(self, req: Req) -> None:
@@ -62,9 +86,10 @@ class Scheduler:
 
     # ---- admission (PrefillAdder) ----
     def _reserved_decode_tokens(self) -> int:
-        """Slots the running requests may still need (rem_total_tokens of PrefillAdder)."""
-        return sum(r.sampling_params.max_new_tokens - len(r.output_ids) + (self.page_size if self.page_size > 1 else 0)
-                   for r in self.running_batch.reqs)
+        """Slots the running requests are expected to still need: the estimated fraction
+        new_token_ratio of what they may generate (PrefillAdder.rem_total_tokens, schedule_policy.py)."""
+        return int(sum(min(r.sampling_params.max_new_tokens - len(r.output_ids), CLIP_MAX_NEW_TOKENS) * self.new_token_ratio
+                       + (self.page_size if self.page_size > 1 else 0) for r in self.running_batch.reqs))
 
     def get_new_batch_prefill(self) -> Optional[ScheduleBatch]:
         if not self.waiting_queue and self.chunked_req is None:
@@ -73,6 +98,14 @@ class Scheduler:
         rem_total = alloc.available_size() + self.tree_cache.evictable_size() - self._reserved_decode_tokens()
         rem_input = self.max_prefill_tokens
         rem_chunk = self.chunked_prefill_size
+        if self.enable_mixed_chunk:
+            # the decode tokens that will ride along count against every budget (PrefillAdder
+            # mixed_with_decode_tokens, schedule_policy.py)
+            mixed = len(self.running_batch.reqs)
+            rem_total -= mixed * self.page_size
+            rem_input -= mixed
+            if rem_chunk is not None:
+                rem_chunk -= mixed
         free_reqs = self.mr.req_to_token_pool.available_size()
         can_run: List[Req] = []
 
@@ -152,6 +185,13 @@ class Scheduler:
         self._make_room(sum(r.extend_input_len for r in can_run))
         batch = self._new_batch(can_run)
         batch.prepare_for_extend()
+        # mixed chunk (scheduler.py get_new_batch_prefill, is_mixed_chunk branch): the running
+        # requests take their decode step inside this forward instead of waiting for it
+        if self.enable_mixed_chunk and not self.running_batch.is_empty() and self.check_decode_mem(self.running_batch):
+            self.running_batch.prepare_for_decode()
+            batch.mix_with_running(self.running_batch)
+            self.running_batch = self._new_batch([])
+            self.num_mixed_batches += 1
         return batch
 
     def _make_room(self, need: int) -> None:
@@ -167,9 +207,62 @@ class Scheduler:
             return new_batch
         if self.running_batch.is_empty():
             return None
-        self._make_room(len(self.running_batch.reqs))
-        self.running_batch.prepare_for_decode()
-        return self.running_batch
+        return self.update_running_batch(self.running_batch)
+
+    # ---- decode under memory pressure ----
+    def _decode_slots_needed(self, batch: ScheduleBatch) -> int:
+        """Slots the next decode step allocates (new_page_count_next_decode * page_size)."""
+        if self.page_size == 1:
+            return len(batch.reqs)
+        return sum(1 for n in batch.seq_lens_cpu_list if n % self.page_size == 0) * self.page_size
+
+    def check_decode_mem(self, batch: ScheduleBatch) -> bool:
+        need = self._decode_slots_needed(batch)
+        self._make_room(need)
+        return self.mr.token_to_kv_pool_allocator.available_size() >= need
+
+    def retract_decode(self, batch: ScheduleBatch) -> List[Req]:
+        alloc, pool = self.mr.token_to_kv_pool_allocator, self.mr.req_to_token_pool
+        reqs = batch.reqs
+        # popped from the end: fewest outputs first, longest prompt first among equals
+        order = sorted(range(len(reqs)), key=lambda i: (len(reqs[i].output_ids), -len(reqs[i].origin_input_ids)),
+                       reverse=True)
+        per_req = RETRACT_DECODE_STEPS + (self.page_size if self.page_size > 1 else 0)
+        retracted: List[Req] = []
+        first = True
+        while alloc.available_size() < len(order) * per_req or first:
+            if len(order) == 1:
+                if alloc.available_size() < self._decode_slots_needed(batch) and not retracted:
+                    raise RuntimeError("No space left for only one request")
+                break
+            first = False
+            idx = order.pop()
+            req = reqs[idx]
+            retracted.append(req)
+            # what the prefix tree holds stays there (unlocked); the rest goes back to the allocator
+            own_from = len(req.prefix_indices)
+            slots = pool.req_to_token[req.req_pool_idx, own_from:batch.seq_lens_cpu_list[idx]].to(torch.int64)
+            alloc.free(slots)
+            pool.free(req.req_pool_idx)
+            if req.last_node is not None:
+                self.tree_cache.dec_lock_ref(req.last_node)
+            self._make_room(len(order) * per_req)
+            req.reset_for_retract()
+        batch.filter_batch(keep_indices=sorted(order))
+        decoded = sum(len(r.output_ids) for r in batch.reqs)
+        budget = sum(r.sampling_params.max_new_tokens for r in batch.reqs)
+        self.new_token_ratio = min(1.0, (decoded + RETRACT_DECODE_STEPS * len(batch.reqs)) / max(budget, 1))
+        return retracted
+
+    def update_running_batch(self, batch: ScheduleBatch) -> ScheduleBatch:
+        if not self.check_decode_mem(batch):
+            retracted = self.retract_decode(batch)
+            self.waiting_queue.extend(retracted)
+            self.total_retracted_reqs += len(retracted)
+        else:
+            self.new_token_ratio = max(self.new_token_ratio - self.new_token_ratio_decay, self.min_new_token_ratio)
+        batch.prepare_for_decode()
+        return batch
 
     @torch.no_grad()
     def run_batch(self, batch: ScheduleBatch) -> torch.Tensor:
@@ -235,6 +328,7 @@ class Scheduler:
     def step(self) -> bool:
         batch = self.get_next_batch_to_run()
         if batch is None:
+            self.new_token_ratio = self.init_new_token_ratio   # idle: forget the estimate (scheduler.py:813)
             return False
         self.process_batch_result(batch, self.run_batch(batch))
         return True

@@ -24,6 +24,8 @@ class ServerArgs:
     simulate_tp_shard: bool = False             # measurement aid: one TP rank, collectives stubbed
     chunked_prefill_size: Optional[int] = None   # None / -1: prompts are never split
     kv_cache_dtype: str = "auto"                  # "auto" = model dtype | "fp8_e4m3"
+    enable_mixed_chunk: bool = False              # decode requests ride along prefill batches as 1-token extends
+    schedule_conservativeness: float = 1.0        # scales the initial new-token estimate (0.7) of admission
     page_size: int = 1                            # KV slots per page (> 1: page-aligned allocation)
     # The reference's flag (server_args.py: disable_custom_all_reduce, default False).  True here: the
     # one-launch all-reduce has been exercised with ranks sharing one GPU, not yet across xGMI.

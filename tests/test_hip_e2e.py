@@ -159,8 +159,8 @@ def test_sampler_nongreedy_runs_in_kept_set():
         assert (dist.gather(1, ids.long()[:, None]) > 0).all()
 
 
-@pytest.mark.parametrize("graphs", [False, True])
-def test_continuous_batching_on_gpu_matches_isolated_generation(graphs):
+@pytest.mark.parametrize("graphs,mixed", [(False, False), (True, False), (True, True)])
+def test_continuous_batching_on_gpu_matches_isolated_generation(graphs, mixed):
     """Scheduler-driven run (staggered arrivals, 16-token prefill chunks, a KV pool that cannot hold
     every request at once, decode batches that shrink and grow under HIP-graph padding): each
     request's fp32 greedy tokens equal the oracle's for that prompt alone."""
@@ -175,7 +175,8 @@ def test_continuous_batching_on_gpu_matches_isolated_generation(graphs):
     cfg = hf_config_dict("tiny-llama-d64", "float32")
     w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
     sa = ServerArgs(dtype="float32", max_total_tokens=160, max_running_requests=4, disable_cuda_graph=not graphs,
-                    cuda_graph_bs=[1, 2, 4], chunked_prefill_size=16, max_prefill_tokens=64)
+                    cuda_graph_bs=[1, 2, 4], chunked_prefill_size=16, max_prefill_tokens=64,
+                    enable_mixed_chunk=mixed)
     mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights={k: v.cuda() for k, v in w.items()})
     rng = np.random.RandomState(3)
     spec = [(5, 6), (40, 3), (17, 9), (33, 1), (70, 4), (9, 12), (24, 5)]
@@ -193,11 +194,56 @@ def test_continuous_batching_on_gpu_matches_isolated_generation(graphs):
         it += 1
         assert it < 500
     assert len(sch.finished) == len(reqs)
+    assert (sch.num_mixed_batches > 0) == mixed   # mixed: decode rows ran as 1-token extends over their own KV
     assert mr.token_to_kv_pool_allocator.available_size() == mr.max_total_num_tokens
     oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
     for r, (n, m) in zip(reqs, spec):
         ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
         assert r.output_ids == ref_toks[0].tolist(), (r.rid, graphs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_retraction_on_gpu_matches_isolated_generation(page_size):
+    """A KV pool too small for the admitted requests to finish together: decode retracts requests
+    (slots or pages back, outputs kept), prefills them again later over prompt + outputs, and every
+    request still gets the oracle's tokens for its prompt alone."""
+    from oracle.llama_ref import OracleLlama
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.managers.scheduler import Scheduler
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.sampling.sampling_params import SamplingParams
+    from sglang_custom_amd.server_args import ServerArgs
+
+    cfg = hf_config_dict("tiny-llama-d64", "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    # pages: a request is admitted against whole pages plus one, so it takes longer outputs and a
+    # bolder estimate of the running requests' needs to over-commit the pool
+    sa = ServerArgs(dtype="float32", max_total_tokens=160 if page_size == 1 else 256, max_running_requests=6,
+                    cuda_graph_bs=[1, 2, 4], max_prefill_tokens=128, page_size=page_size,
+                    schedule_conservativeness=1.0 if page_size == 1 else 0.1)
+    mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights={k: v.cuda() for k, v in w.items()})
+    rng = np.random.RandomState(11)
+    spec = [(20, 40), (24, 40), (18, 44), (22, 36), (10, 30)]
+    if page_size > 1:
+        spec = [(n, 2 * m) for n, m in spec]
+    reqs = [Req(i, rng.randint(0, cfg["vocab_size"], n).tolist(), SamplingParams(max_new_tokens=m, temperature=0))
+            for i, (n, m) in enumerate(spec)]
+    sch = Scheduler(mr)
+    for r in reqs:
+        sch.add_request(r)
+    it = 0
+    while sch.waiting_queue or not sch.running_batch.is_empty():
+        assert sch.step(), "scheduler stalled"
+        it += 1
+        assert it < 2000
+    assert len(sch.finished) == len(reqs) and sch.total_retracted_reqs > 0
+    assert mr.token_to_kv_pool_allocator.available_size() == mr.max_total_num_tokens
+    oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
+    for r, (n, m) in zip(reqs, spec):
+        ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
+        assert r.output_ids == ref_toks[0].tolist(), r.rid
 
 
 @pytest.mark.gpu

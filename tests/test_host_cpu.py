@@ -154,9 +154,11 @@ def _scheduler_case(mr, cfg, w, dt, tol):
     for r, (n, m) in zip(reqs, spec):
         ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
         assert r.output_ids == ref_toks[0].tolist(), (r.rid, r.output_ids, ref_toks[0].tolist())
+    return sch
 
 
-def test_continuous_batching_scheduler_matches_isolated_generation():
+@pytest.mark.parametrize("mixed", [False, True])
+def test_continuous_batching_scheduler_matches_isolated_generation(mixed):
     import cpu_ops
     from sglang_custom_amd import ops_backend
     from sglang_custom_amd.configs.model_config import ModelConfig
@@ -168,9 +170,68 @@ def test_continuous_batching_scheduler_matches_isolated_generation():
     cfg = hf_config_dict("tiny-llama-d64", "float32")
     w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
     sa = ServerArgs(dtype="float32", device="cpu", max_total_tokens=160, max_running_requests=4,
-                    disable_cuda_graph=True, chunked_prefill_size=16, max_prefill_tokens=64)
+                    disable_cuda_graph=True, chunked_prefill_size=16, max_prefill_tokens=64,
+                    enable_mixed_chunk=mixed)
     mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights=w)
-    _scheduler_case(mr, cfg, w, torch.float32, 1e-4)
+    sch = _scheduler_case(mr, cfg, w, torch.float32, 1e-4)
+    # with mixing on, decode requests rode along prefill chunks instead of waiting for them
+    assert (sch.num_mixed_batches > 0) == mixed
+    if mixed:
+        assert sch.num_decode_steps < 30
+
+
+@pytest.mark.parametrize("radix", [False, True])
+def test_scheduler_retracts_decoding_requests_when_the_pool_runs_out(radix):
+    """Admission reserves only a fraction of what running requests may still generate, so a pool
+    that cannot hold every admitted request to its end runs short mid-decode: requests are
+    retracted (slots back, outputs kept), re-prefilled over prompt + outputs later, and still
+    produce exactly the tokens the oracle generates for them alone."""
+    import cpu_ops
+    from oracle.llama_ref import OracleLlama
+    from sglang_custom_amd import ops_backend
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.managers.scheduler import Scheduler
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+    from sglang_custom_amd.sampling.sampling_params import SamplingParams
+    from sglang_custom_amd.server_args import ServerArgs
+
+    ops_backend.set_ops_backend(cpu_ops)
+    cfg = hf_config_dict("tiny-llama-d64", "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    sa = ServerArgs(dtype="float32", device="cpu", max_total_tokens=160, max_running_requests=6,
+                    disable_cuda_graph=True, max_prefill_tokens=128)
+    mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights=w)
+    rng = np.random.RandomState(11)
+    spec = [(20, 40), (24, 40), (18, 44), (22, 36), (10, 30)]
+    shared = rng.randint(0, cfg["vocab_size"], 8).tolist()
+    reqs = [Req(i, shared + rng.randint(0, cfg["vocab_size"], n - 8).tolist(),
+                SamplingParams(max_new_tokens=m, temperature=0)) for i, (n, m) in enumerate(spec)]
+    sch = Scheduler(mr, enable_radix_cache=radix)
+    assert sch.new_token_ratio == pytest.approx(0.7)
+    for r in reqs:
+        sch.add_request(r)
+    peak_running, ratios = 0, set()
+    it = 0
+    while sch.waiting_queue or not sch.running_batch.is_empty():
+        assert sch.step(), "scheduler stalled"
+        peak_running = max(peak_running, len(sch.running_batch.reqs))
+        ratios.add(round(sch.new_token_ratio, 6))
+        it += 1
+        assert it < 2000
+    assert len(sch.finished) == len(reqs)
+    assert sch.total_retracted_reqs > 0 and any(r.is_retracted for r in reqs)
+    assert peak_running >= 3                      # more were admitted than fit to the end (3 x ~62 > 160)
+    assert len(ratios) > 2                        # the estimate decayed and was re-estimated
+    alloc = mr.token_to_kv_pool_allocator
+    assert alloc.available_size() + sch.tree_cache.evictable_size() == mr.max_total_num_tokens
+    assert sch.tree_cache.protected_size() == 0
+    assert mr.req_to_token_pool.available_size() == mr.req_to_token_pool.size
+    oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
+    for r, (n, m) in zip(reqs, spec):
+        ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
+        assert r.output_ids == ref_toks[0].tolist(), (r.rid, r.output_ids, ref_toks[0].tolist())
 
 
 def test_radix_cache_tree_semantics():
