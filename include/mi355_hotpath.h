@@ -417,6 +417,13 @@ int mi355_ar_all_reduce(void* comm, void* out, const void* in, int64_t count, in
  * replaces: GroupCoordinator.all_gather on the logits (distributed/parallel_state.py:528-597) at
  *           decode sizes; the reference has no custom kernel for it and goes through RCCL. */
 int mi355_ar_all_gather(void* comm, void* out, const void* in, int64_t bytes, void* stream);
+/* In place: x[rows, hidden] holds this rank's partial sums on entry and
+ * RMSNorm(sum over ranks + residual) * weight on return; residual becomes sum + residual.  Bit-identical
+ * to mi355_ar_all_reduce(x) followed by mi355_fused_add_rmsnorm(x, residual, weight).
+ * hidden * element size a multiple of 16, at most 2048 16-byte vectors per row; rows * hidden within max_bytes.
+ * replaces: RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:166-190). */
+int mi355_ar_fused_add_rmsnorm(void* comm, void* x, void* residual, const void* weight, int64_t rows,
+                               int64_t hidden, float eps, int dtype, void* stream);
 /* waits for `stream`, then MI355_OK, or MI355_ERR_LAUNCH if any barrier wait has timed out so far */
 int mi355_ar_status(void* comm, void* stream);
 

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "mi355_ar_choose_algo": (I, [I, L]),
     "mi355_ar_all_reduce": (I, [P, P, P, L, I, I, P]),
     "mi355_ar_all_gather": (I, [P, P, P, L, P]),
+    "mi355_ar_fused_add_rmsnorm": (I, [P, P, P, P, L, L, F, I, P]),
     "mi355_ar_status": (I, [P, P]),
     "mi355_fused_add_rmsnorm_partials": (I, [P, P, P, P, I, L, L, F, I, P]),
     "mi355_per_token_quant_fp8": (I, [P, P, P, L, L, L, I, P]),

@@ -218,6 +218,89 @@ __global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, co
   ar_store_epoch(p, rank, epoch);
 }
 
+// All-reduce + residual add + RMSNorm in one launch, for the row-parallel projections of a tensor-
+// parallel decoder layer: x (this rank's partial sums) -> sum over ranks, rounded to T exactly as
+// the plain all-reduce rounds it -> + residual (kept in fp32 for the norm, stored rounded) ->
+// RMSNorm * weight.  The arithmetic after the sum repeats the fused add+RMSNorm kernel's statement
+// by statement (256 lanes, same per-lane accumulation and block reduction), so the result equals
+// all-reduce followed by that kernel bit for bit.  A workgroup owns whole rows: b, b + grid, ...
+// replaces: RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:166-190) and the deferred
+//           all-reduce of LayerCommunicator.prepare_mlp / prepare_attn (layers/communicator.py).
+template <typename T, int NR, int CHUNKS>
+__global__ __launch_bounds__(256) void ar_fused_add_rmsnorm_kernel(ArPeers p, T* x, T* residual, const T* __restrict__ w,
+                                                                   int rows, int64_t hidden, float eps, int rank,
+                                                                   uint32_t* status) {
+  constexpr int VE = 16 / sizeof(T);
+  constexpr int BT = 256;
+  __shared__ float red[16];
+  const int nvec = (int)(hidden / VE);
+  ArVec* mine = reinterpret_cast<ArVec*>(ar_staging(p.base[rank]));
+  uint32_t epoch = ar_load_epoch(p, rank);
+  Vec<T, VE> wv[CHUNKS];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int vi = threadIdx.x + c * BT;
+    wv[c] = ldvec<T, VE>(w + (int64_t)(vi < nvec ? vi : 0) * VE);
+  }
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const ArVec* xin = reinterpret_cast<const ArVec*>(x + (int64_t)row * hidden);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int vi = threadIdx.x + c * BT;
+      if (vi < nvec) mine[(int64_t)row * nvec + vi] = xin[vi];
+    }
+  }
+  ar_barrier<NR>(p, rank, epoch, status);
+  const ArVec* src[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]));
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    T* xr = x + (int64_t)row * hidden;
+    T* rr = residual + (int64_t)row * hidden;
+    Vec<T, VE> a[CHUNKS], b[CHUNKS];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int vi = threadIdx.x + c * BT;
+      const int64_t v0 = vi < nvec ? vi : 0;
+      b[c] = ldvec<T, VE>(rr + v0 * VE);
+      const ArVec summed = ar_reduce<T, NR>(src, (int64_t)row * nvec + v0);
+      a[c] = *reinterpret_cast<const Vec<T, VE>*>(&summed);
+    }
+    float vals[CHUNKS][VE];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int vi = threadIdx.x + c * BT;
+      if (vi < nvec) {
+        Vec<T, VE> s;
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          float f = to_f32(a[c].v[j]) + to_f32(b[c].v[j]);
+          vals[c][j] = f;
+          s.v[j] = from_f32<T>(f);
+        }
+        stvec<T, VE>(rr + (int64_t)vi * VE, s);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) ss += vals[c][j] * vals[c][j];
+      }
+    }
+    ss = block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int vi = threadIdx.x + c * BT;
+      if (vi < nvec) {
+        Vec<T, VE> ov;
+#pragma unroll
+        for (int j = 0; j < VE; ++j) ov.v[j] = from_f32<T>((vals[c][j] * inv) * to_f32(wv[c].v[j]));
+        stvec<T, VE>(xr + (int64_t)vi * VE, ov);
+      }
+    }
+  }
+  ar_barrier<NR>(p, rank, epoch, status);
+  ar_store_epoch(p, rank, epoch);
+}
+
 template <typename T, int NR>
 static void ar_launch(const ArComm* c, void* out, const void* in, int64_t nvec, int algo, hipStream_t st) {
   const int grid = (int)std::min<int64_t>(AR_MAX_BLOCKS, std::max<int64_t>(1, (nvec + AR_THREADS - 1) / AR_THREADS));
@@ -238,6 +321,34 @@ static int ar_dispatch_world(const ArComm* c, void* out, const void* in, int64_t
     default: set_error("mi355_ar_all_reduce: world size %d (2, 4, 6 or 8)", c->world); return MI355_ERR_UNSUPPORTED;
   }
   return MI355_OK;
+}
+
+template <typename T, int NR>
+static int ar_fused_norm_launch(const ArComm* c, T* x, T* residual, const T* w, int rows, int64_t hidden, float eps,
+                                hipStream_t st) {
+  const int nvec = (int)(hidden / (16 / sizeof(T)));
+  const int chunks = (nvec + 255) / 256;
+  const int grid = std::min(AR_MAX_BLOCKS, rows);
+#define AR_NORM(C) \
+  ar_fused_add_rmsnorm_kernel<T, NR, C><<<grid, 256, 0, st>>>(c->peers, x, residual, w, rows, hidden, eps, c->rank, c->status)
+  if (chunks <= 1) AR_NORM(1);
+  else if (chunks <= 2) AR_NORM(2);
+  else if (chunks <= 4) AR_NORM(4);
+  else AR_NORM(8);
+#undef AR_NORM
+  return MI355_OK;
+}
+
+template <typename T>
+static int ar_fused_norm_world(const ArComm* c, void* x, void* residual, const void* w, int rows, int64_t hidden,
+                               float eps, hipStream_t st) {
+  switch (c->world) {
+    case 2: return ar_fused_norm_launch<T, 2>(c, (T*)x, (T*)residual, (const T*)w, rows, hidden, eps, st);
+    case 4: return ar_fused_norm_launch<T, 4>(c, (T*)x, (T*)residual, (const T*)w, rows, hidden, eps, st);
+    case 6: return ar_fused_norm_launch<T, 6>(c, (T*)x, (T*)residual, (const T*)w, rows, hidden, eps, st);
+    case 8: return ar_fused_norm_launch<T, 8>(c, (T*)x, (T*)residual, (const T*)w, rows, hidden, eps, st);
+    default: set_error("mi355_ar_fused_add_rmsnorm: world size %d (2, 4, 6 or 8)", c->world); return MI355_ERR_UNSUPPORTED;
+  }
 }
 
 }  // namespace mi355
@@ -392,6 +503,29 @@ int mi355_ar_all_gather(void* comm, void* out, const void* in, int64_t bytes, vo
   }
 #undef AR_GATHER
   MI355_CHECK_LAUNCH("mi355_ar_all_gather");
+  return MI355_OK;
+}
+
+int mi355_ar_fused_add_rmsnorm(void* comm, void* x, void* residual, const void* weight, int64_t rows, int64_t hidden,
+                               float eps, int dtype, void* stream) {
+  MI355_REQUIRE(comm && x && residual && weight, MI355_ERR_INVALID, "mi355_ar_fused_add_rmsnorm: null argument");
+  const ArComm* c = static_cast<const ArComm*>(comm);
+  const int64_t esize = dtype == MI355_F32 ? 4 : 2;
+  const int64_t ve = 16 / esize;
+  MI355_REQUIRE(rows > 0 && rows <= (1 << 24) && hidden > 0 && hidden % ve == 0 && hidden / ve <= 256 * 8,
+                MI355_ERR_UNSUPPORTED, "mi355_ar_fused_add_rmsnorm: rows %lld, hidden %lld (hidden a multiple of %lld, at most %lld)",
+                (long long)rows, (long long)hidden, (long long)ve, (long long)(256 * 8 * ve));
+  MI355_REQUIRE(rows * hidden * esize <= c->max_bytes, MI355_ERR_INVALID,
+                "mi355_ar_fused_add_rmsnorm: %lld bytes exceed the region's %lld", (long long)(rows * hidden * esize),
+                (long long)c->max_bytes);
+  MI355_REQUIRE(aligned16(x) && aligned16(residual) && aligned16(weight), MI355_ERR_INVALID,
+                "mi355_ar_fused_add_rmsnorm: buffers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = MI355_OK;
+  MI355_DISPATCH_DTYPE(dtype, "mi355_ar_fused_add_rmsnorm",
+                       rc = ar_fused_norm_world<T>(c, x, residual, weight, (int)rows, hidden, eps, st));
+  if (rc != MI355_OK) return rc;
+  MI355_CHECK_LAUNCH("mi355_ar_fused_add_rmsnorm");
   return MI355_OK;
 }
 

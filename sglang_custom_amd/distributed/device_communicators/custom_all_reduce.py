@@ -41,6 +41,7 @@ class CustomAllreduce:
         self._region = None
         self._opened: List[int] = []
         self._IS_CAPTURING = False
+        self.calls = {"all_reduce": 0, "all_gather": 0, "fused_add_rmsnorm": 0}   # launches issued (incl. captured)
         self.group = group
         assert dist.get_backend(group) != dist.Backend.NCCL, \
             "CustomAllreduce exchanges IPC handles as Python objects: attach it to a non-NCCL group"
@@ -115,6 +116,7 @@ class CustomAllreduce:
         if out is None:
             out = torch.empty_like(inp)
         stream = torch.cuda.current_stream(inp.device).cuda_stream
+        self.calls["all_reduce"] += 1
         _lib.check(self._lib.mi355_ar_all_reduce(self._comm, out.data_ptr(), inp.data_ptr(), inp.numel(),
                                                  _DT[inp.dtype], algo, stream), "mi355_ar_all_reduce")
         return out
@@ -134,9 +136,25 @@ class CustomAllreduce:
         """[world, *inp.shape]: every rank's tensor, rank-major (one launch, any dtype)."""
         out = torch.empty((self.world_size,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
         stream = torch.cuda.current_stream(inp.device).cuda_stream
+        self.calls["all_gather"] += 1
         _lib.check(self._lib.mi355_ar_all_gather(self._comm, out.data_ptr(), inp.data_ptr(),
                                                  inp.numel() * inp.element_size(), stream), "mi355_ar_all_gather")
         return out
+
+    def should_fuse_norm(self, x: torch.Tensor, hidden: int) -> bool:
+        ve = 16 // x.element_size()
+        return (self.should_custom_ar(x) and x.dim() == 2 and x.is_contiguous() and x.shape[1] == hidden
+                and hidden % ve == 0 and hidden // ve <= 2048)
+
+    def fused_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+        """In place: x (this rank's partial sums) -> RMSNorm(sum over ranks + residual) * weight,
+        residual -> sum + residual; same bits as all_reduce followed by the fused add+RMSNorm."""
+        assert residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self.calls["fused_add_rmsnorm"] += 1
+        _lib.check(self._lib.mi355_ar_fused_add_rmsnorm(self._comm, x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                                        x.shape[0], x.shape[1], float(eps), _DT[x.dtype], stream),
+                   "mi355_ar_fused_add_rmsnorm")
 
     def check_status(self) -> None:
         """Synchronises the current stream; raises if any barrier wait has timed out."""

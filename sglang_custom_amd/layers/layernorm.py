@@ -9,7 +9,8 @@ from torch import nn
 
 from ..custom_op import CustomOp
 from ..ops_backend import get_ops
-from .quantization.unquant import QuantizedAct, SplitKPartials
+from ..distributed.parallel_state import get_custom_all_reduce, tensor_model_parallel_all_reduce
+from .quantization.unquant import PendingAllReduce, QuantizedAct, SplitKPartials
 
 
 class RMSNorm(CustomOp):
@@ -25,6 +26,13 @@ class RMSNorm(CustomOp):
         quant_fp8: also quantise the normalised rows per token for an fp8 GEMM -- the result is then
         a QuantizedAct (decode-sized inputs only; callers check the ops backend supports it)."""
         ops = get_ops()
+        if isinstance(x, PendingAllReduce):
+            # partial sums of a row-parallel projection (layernorm.py:166-190 forward_with_allreduce_fusion)
+            ca = get_custom_all_reduce()
+            if residual is not None and not quant_fp8 and ca is not None:
+                ca.fused_add_rmsnorm(x.partial, residual, self.weight.data, self.variance_epsilon)
+                return x.partial, residual
+            x = tensor_model_parallel_all_reduce(x.partial)
         if isinstance(x, SplitKPartials) or quant_fp8:
             part = x if isinstance(x, SplitKPartials) else None
             assert part is None or residual is not None

@@ -9,11 +9,12 @@ import torch
 from torch import nn
 
 from ..distributed.parallel_state import (
+    get_custom_all_reduce,
     get_tensor_model_parallel_rank,
     get_tensor_model_parallel_world_size,
     tensor_model_parallel_all_reduce,
 )
-from .quantization.unquant import UnquantizedLinearMethod
+from .quantization.unquant import PendingAllReduce, UnquantizedLinearMethod
 
 
 class LinearBase(nn.Module):
@@ -95,8 +96,14 @@ class RowParallelLinear(LinearBase):
         per = w.shape[1] // self.tp_size
         return w[:, self.tp_rank * per:(self.tp_rank + 1) * per].contiguous()
 
-    def forward(self, x):
+    def forward(self, x, defer_all_reduce: bool = False):
+        """defer_all_reduce: the caller hands the result to an RMSNorm with a residual; when the
+        one-launch collectives are on and the output qualifies, the partial sums come back as a
+        PendingAllReduce for that norm to sum (all-reduce + add + norm in one launch)."""
         y = self.quant_method.apply(self, x)
         if self.reduce_results and self.tp_size > 1:
+            ca = get_custom_all_reduce() if defer_all_reduce else None
+            if ca is not None and y.is_cuda and ca.should_fuse_norm(y, y.shape[-1]):
+                return PendingAllReduce(y), None
             y = tensor_model_parallel_all_reduce(y)
         return y, None

@@ -88,6 +88,23 @@ class QuantizedAct:
         self.shape = xq.shape
 
 
+class PendingAllReduce:
+    """This rank's partial sums of a row-parallel projection whose sum over the TP group has been
+    left to the consumer: the RMSNorm behind it does all-reduce + residual add + norm in one launch
+    (the reference defers the same all-reduce through LayerCommunicator, layers/communicator.py)."""
+
+    def __init__(self, partial: torch.Tensor):
+        self.partial = partial
+
+    @property
+    def shape(self):
+        return self.partial.shape
+
+    @property
+    def dtype(self):
+        return self.partial.dtype
+
+
 def decode_linear_deferred(layer, x, needs_all_reduce: bool = True):
     """layer(x) on the decode path, leaving the split-K reduction to the kernel that consumes it; None
     when the layer, the shape or the ops backend does not support it.  A row-parallel layer

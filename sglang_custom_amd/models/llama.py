@@ -57,7 +57,7 @@ class LlamaMLP(nn.Module):
         deferred = decode_linear_deferred(self.down_proj, x)   # summed by the next layer's norm
         if deferred is not None:
             return deferred
-        x, _ = self.down_proj(x)
+        x, _ = self.down_proj(x, defer_all_reduce=True)   # TP: the next norm may take the sum over ranks too
         return x
 
 
@@ -117,7 +117,7 @@ class LlamaAttention(nn.Module):
             deferred = decode_linear_deferred(self.o_proj, attn_output)
             if deferred is not None:
                 return deferred
-            return self.o_proj(attn_output)[0]
+            return self.o_proj(attn_output, defer_all_reduce=True)[0]
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         pool = forward_batch.token_to_kv_pool
@@ -131,7 +131,7 @@ class LlamaAttention(nn.Module):
         deferred = decode_linear_deferred(self.o_proj, attn_output)   # summed by post_attention_layernorm
         if deferred is not None:
             return deferred
-        output, _ = self.o_proj(attn_output)
+        output, _ = self.o_proj(attn_output, defer_all_reduce=True)
         return output
 
 

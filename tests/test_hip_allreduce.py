@@ -76,6 +76,27 @@ def _rank_main(rank, world, port, queue):
         ca.check_status()
         for x, want in pending:
             assert torch.equal(x.cpu(), want)
+        # all-reduce + residual add + RMSNorm in one launch == the two launches it replaces, bit for bit
+        from sglang_custom_amd import ops
+
+        for i, (dtn, rows, hidden) in enumerate((("bfloat16", 64, 4096), ("float16", 3, 512), ("float32", 5, 1024),
+                                                 ("bfloat16", 70, 8192), ("bfloat16", 1, 4096))):
+            dtype = getattr(torch, dtn)
+            ins = _inputs(700 + i, world, rows * hidden, dtype)
+            g = torch.Generator().manual_seed(7000 + i)
+            res = torch.randn(rows, hidden, generator=g).to(dtype)
+            wt = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).cuda()
+            x, r1 = ins[rank].cuda().view(rows, hidden), res.cuda()
+            assert ca.should_fuse_norm(x, hidden)
+            ca.fused_add_rmsnorm(x, r1, wt, 1e-5)
+            y, r2 = ca.all_reduce(ins[rank].cuda()).view(rows, hidden), res.cuda()
+            ops.fused_add_rmsnorm(y, r2, wt, 1e-5)
+            ca.check_status()
+            assert torch.equal(x, y) and torch.equal(r1, r2), (dtn, rows, hidden)
+            s64 = ops_ref.custom_all_reduce(ins).view(rows, hidden).double() + res.double()
+            want = s64 * torch.rsqrt((s64 * s64).mean(-1, keepdim=True) + 1e-5) * wt.cpu().double()
+            tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+            assert (x.cpu().double() - want).abs().max().item() <= tol * want.abs().max().item()
         # the reference's entry point: a new tensor, or None for what does not qualify
         ins = _inputs(900, world, 4096, torch.bfloat16)
         got = ca.custom_all_reduce(ins[rank].cuda())
@@ -151,6 +172,9 @@ def _tp_rank_main(rank, world, port, queue, preset, dtn):
             toks.append(nxt.cpu())
             lgs.append(logits.float().cpu())
         ca.check_status()
+        # every row-parallel sum went through the fused all-reduce + norm launch (2 per layer per
+        # forward, eager prefill + graph capture), the logits through the gather, none through gloo
+        assert ca.calls["fused_add_rmsnorm"] >= 2 * cfg["num_hidden_layers"] * 2 and ca.calls["all_gather"] >= 2
         toks = torch.stack(toks, 1)
         if dt == torch.float32:
             ref_toks, ref_logits = OracleLlama(cfg, w, dt, max_total_tokens=512).generate_greedy(prompts, 4)
