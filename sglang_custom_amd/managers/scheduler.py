@@ -43,8 +43,9 @@ CLIP_MAX_NEW_TOKENS = 4096
 class Scheduler:
     def __init__(self, model_runner, eos_token_id: Optional[int] = None, enable_radix_cache: bool = False):
         self.mr = model_runner
+        self.page_size = getattr(model_runner.token_to_kv_pool_allocator, "page_size", 1)
         self.tree_cache = RadixCache(model_runner.req_to_token_pool, model_runner.token_to_kv_pool_allocator,
-                                     disable=not enable_radix_cache)
+                                     disable=not enable_radix_cache, page_size=self.page_size)
         self.cached_prefix_tokens = 0
         sa = model_runner.server_args
         self.eos_token_id = eos_token_id
@@ -52,9 +53,6 @@ class Scheduler:
         cps = sa.chunked_prefill_size
         self.chunked_prefill_size = cps if cps is not None and cps > 0 else None
         self.max_prefill_tokens = sa.max_prefill_tokens
-        self.page_size = getattr(model_runner.token_to_kv_pool_allocator, "page_size", 1)
-        if self.page_size > 1 and enable_radix_cache:
-            raise NotImplementedError("the prefix tree matches token by token: use page_size 1 with enable_radix_cache")
         self.waiting_queue: List[Req] = []
         self.running_batch: ScheduleBatch = self._new_batch([])
         self.chunked_req: Optional[Req] = None
@@ -141,14 +139,16 @@ class Scheduler:
                 return refuse()
             n = req.extend_input_len
             truncate = rem_chunk is not None and n > rem_chunk
-            if (truncate and rem_chunk <= 0) or (not truncate and n > rem_input and can_run):
+            # chunks end on page boundaries (PrefillAdder trunc_len, schedule_policy.py)
+            chunk = rem_chunk // self.page_size * self.page_size if truncate else 0
+            if (truncate and chunk <= 0) or (not truncate and n > rem_input and can_run):
                 return refuse()
             if matched_node is not None:
                 req.last_node = matched_node
                 self.cached_prefix_tokens += len(prefix)
             if truncate:
                 # truncate to the chunk budget (add_chunked_req / add_one_req trunc_len)
-                n = rem_chunk
+                n = chunk
                 req.fill_ids = req.fill_ids[: len(req.prefix_indices) + n]
                 req.extend_input_len = n
                 req.is_chunked += 1
@@ -240,7 +240,7 @@ class Scheduler:
             req = reqs[idx]
             retracted.append(req)
             # what the prefix tree holds stays there (unlocked); the rest goes back to the allocator
-            own_from = len(req.prefix_indices)
+            own_from = 0 if self.tree_cache.disable else len(req.prefix_indices) // self.page_size * self.page_size
             slots = pool.req_to_token[req.req_pool_idx, own_from:batch.seq_lens_cpu_list[idx]].to(torch.int64)
             alloc.free(slots)
             pool.free(req.req_pool_idx)

@@ -1,7 +1,10 @@
 """Radix tree over token ids whose values are KV-cache slots: the prefix cache behind
 "RadixAttention" (python/sglang/srt/mem_cache/radix_cache.py: TreeNode :40-80, match_prefix
 :134-178, insert :180-186, cache_finished_req :188-222, cache_unfinished_req :224-270, evict
-:283-306, inc/dec_lock_ref :308-338, _split_node :380-398).  page_size = 1.
+:283-306, inc/dec_lock_ref :308-338, _split_node :380-398).  With page_size > 1 keys match in
+whole pages (_key_match_paged :111-120, children keyed by their first page :149): lookups and
+insertions are truncated to a multiple of the page size and a request's partly filled last page
+never enters the tree.
 
 A cached prefix costs nothing on the GPU: its slots are handed to prepare_for_extend as
 prefix_indices, the extend kernel reads them through kv_indices, and only the new tokens are
@@ -31,19 +34,24 @@ class TreeNode:
         return self.last_access_time < other.last_access_time
 
 
-def _match_len(a: List[int], b: List[int]) -> int:
+def _match_len(a: List[int], b: List[int], page_size: int = 1) -> int:
     n = min(len(a), len(b))
     i = 0
-    while i < n and a[i] == b[i]:
-        i += 1
+    if page_size == 1:
+        while i < n and a[i] == b[i]:
+            i += 1
+        return i
+    while i + page_size <= n and a[i:i + page_size] == b[i:i + page_size]:
+        i += page_size
     return i
 
 
 class RadixCache:
-    def __init__(self, req_to_token_pool, token_to_kv_pool_allocator, disable: bool = False):
+    def __init__(self, req_to_token_pool, token_to_kv_pool_allocator, disable: bool = False, page_size: int = 1):
         self.req_to_token_pool = req_to_token_pool
         self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
         self.disable = disable
+        self.page_size = page_size
         self.device = token_to_kv_pool_allocator.device
         self.reset()
 
@@ -55,19 +63,26 @@ class RadixCache:
         self.evictable_size_ = 0
         self.protected_size_ = 0
 
+    def _child_key(self, key: List[int]):
+        return key[0] if self.page_size == 1 else tuple(key[:self.page_size])
+
+    def _aligned(self, n: int) -> int:
+        return n // self.page_size * self.page_size
+
     # ---- lookup ----
     def match_prefix(self, key: List[int]) -> Tuple[torch.Tensor, TreeNode]:
         """Longest cached prefix of `key`: (its slots, the node it ends in).  A node that matches
         only partly is split so that the returned node ends exactly at the match (:134-178)."""
         if self.disable or len(key) == 0:
             return torch.empty((0,), dtype=torch.int64, device=self.device), self.root_node
+        key = key[:self._aligned(len(key))]
         values, node = [], self.root_node
         now = time.monotonic()
         node.last_access_time = now
-        while len(key) > 0 and key[0] in node.children:
-            child = node.children[key[0]]
+        while len(key) > 0 and self._child_key(key) in node.children:
+            child = node.children[self._child_key(key)]
             child.last_access_time = now
-            n = _match_len(child.key, key)
+            n = _match_len(child.key, key, self.page_size)
             if n < len(child.key):
                 child = self._split_node(child, n)
                 values.append(child.value)
@@ -82,7 +97,7 @@ class RadixCache:
     def _split_node(self, child: TreeNode, split_len: int) -> TreeNode:
         """child = [first split_len tokens] -> new parent node, rest stays in child (:380-398)."""
         new_node = TreeNode()
-        new_node.children = {child.key[split_len]: child}
+        new_node.children = {self._child_key(child.key[split_len:]): child}
         new_node.parent = child.parent
         new_node.lock_ref = child.lock_ref
         new_node.key = child.key[:split_len]
@@ -91,7 +106,7 @@ class RadixCache:
         child.parent = new_node
         child.key = child.key[split_len:]
         child.value = child.value[split_len:]
-        new_node.parent.children[new_node.key[0]] = new_node
+        new_node.parent.children[self._child_key(new_node.key)] = new_node
         return new_node
 
     # ---- insertion ----
@@ -104,10 +119,11 @@ class RadixCache:
         now = time.monotonic()
         node.last_access_time = now
         total_prefix = 0
-        while len(key) > 0 and key[0] in node.children:
-            child = node.children[key[0]]
+        assert len(key) % self.page_size == 0, "insert whole pages"
+        while len(key) > 0 and self._child_key(key) in node.children:
+            child = node.children[self._child_key(key)]
             child.last_access_time = now
-            n = _match_len(child.key, key)
+            n = _match_len(child.key, key, self.page_size)
             total_prefix += n
             key, value = key[n:], value[n:]
             if n < len(child.key):
@@ -118,7 +134,7 @@ class RadixCache:
             new_node.parent = node
             new_node.key = list(key)
             new_node.value = value.clone()
-            node.children[key[0]] = new_node
+            node.children[self._child_key(key)] = new_node
             self.evictable_size_ += len(key)
         return total_prefix
 
@@ -133,7 +149,10 @@ class RadixCache:
             self.token_to_kv_pool_allocator.free(kv_indices)
             pool.free(req.req_pool_idx)
             return
-        new_prefix_len = self.insert(token_ids, kv_indices.clone())
+        aligned = self._aligned(len(token_ids))
+        if aligned < len(token_ids):
+            self.token_to_kv_pool_allocator.free(kv_indices[aligned:])   # the partly filled last page
+        new_prefix_len = self.insert(token_ids[:aligned], kv_indices[:aligned].clone())
         self.token_to_kv_pool_allocator.free(kv_indices[len(req.prefix_indices): new_prefix_len])
         pool.free(req.req_pool_idx)
         self.dec_lock_ref(req.last_node)
@@ -146,15 +165,18 @@ class RadixCache:
         token_ids = req.fill_ids
         pool = self.req_to_token_pool
         kv_indices = pool.req_to_token[req.req_pool_idx, : len(token_ids)].to(torch.int64)
-        new_prefix_len = self.insert(token_ids, kv_indices.clone())
+        aligned = self._aligned(len(token_ids))
+        new_prefix_len = self.insert(token_ids[:aligned], kv_indices[:aligned].clone())
         self.token_to_kv_pool_allocator.free(kv_indices[len(req.prefix_indices): new_prefix_len])
-        new_indices, new_last_node = self.match_prefix(token_ids)
-        assert len(new_indices) == len(token_ids)
-        pool.write((req.req_pool_idx, slice(len(req.prefix_indices), len(new_indices))),
-                   new_indices[len(req.prefix_indices):].to(torch.int32))
+        new_indices, new_last_node = self.match_prefix(token_ids[:aligned])
+        assert len(new_indices) == aligned
+        if len(new_indices) > len(req.prefix_indices):
+            pool.write((req.req_pool_idx, slice(len(req.prefix_indices), len(new_indices))),
+                       new_indices[len(req.prefix_indices):].to(torch.int32))
         self.dec_lock_ref(req.last_node)
         self.inc_lock_ref(new_last_node)
-        req.prefix_indices = new_indices
+        # the tree's slots for the whole pages, the request's own for the page still filling (:281-285)
+        req.prefix_indices = torch.cat([new_indices, kv_indices[len(new_indices):]]) if aligned < len(token_ids) else new_indices
         req.last_node = new_last_node
 
     # ---- eviction / locking ----
@@ -178,7 +200,7 @@ class RadixCache:
             self.token_to_kv_pool_allocator.free(x.value)
             freed += len(x.value)
             self.evictable_size_ -= len(x.value)
-            del x.parent.children[x.key[0]]
+            del x.parent.children[self._child_key(x.key)]
             if len(x.parent.children) == 0 and x.parent.lock_ref == 0 and x.parent is not self.root_node:
                 heapq.heappush(leaves, x.parent)
         return freed

@@ -79,16 +79,23 @@ class _Alloc:
         self.freed.append(sorted(int(v) for v in idx.tolist()))
 
 
-def radix_trace():
-    rng = random.Random(11)
+def radix_trace(page_size=1):
+    """page_size > 1: stems and tails are longer (whole pages must repeat for anything to match), the
+    alphabet is smaller, and inserted keys are cut to whole pages as cache_finished_req does."""
+    rng = random.Random(11 if page_size == 1 else 29)
     alloc = _Alloc()
-    tree = RadixCache(req_to_token_pool=None, token_to_kv_pool_allocator=alloc, page_size=1)
-    ops, next_slot, locked = [], 1, []
-    stems = [[rng.randint(0, 5) for _ in range(rng.randint(3, 12))] for _ in range(5)]
+    tree = RadixCache(req_to_token_pool=None, token_to_kv_pool_allocator=alloc, page_size=page_size)
+    ops, next_slot, locked = [], 1 if page_size == 1 else page_size, []
+    hi, stem_len, tail = (5, 12, 6) if page_size == 1 else (2, 12 * page_size, 3 * page_size)
+    stems = [[rng.randint(0, hi) for _ in range(rng.randint(3, stem_len))] for _ in range(5)]
     for step in range(160):
         kind = rng.choice(["insert", "insert", "match", "match", "lock", "unlock", "evict"])
-        key = list(rng.choice(stems))[: rng.randint(1, 12)] + [rng.randint(0, 5) for _ in range(rng.randint(0, 6))]
+        key = list(rng.choice(stems))[: rng.randint(1, stem_len)] + [rng.randint(0, hi) for _ in range(rng.randint(0, tail))]
         rec = dict(op=kind)
+        if kind == "insert" and page_size > 1:
+            key = key[: len(key) // page_size * page_size]
+            if not key:
+                continue
         if kind == "insert":
             val = list(range(next_slot, next_slot + len(key)))
             next_slot += len(key)
@@ -119,7 +126,7 @@ def radix_trace():
 
 
 def main():
-    out = dict(paged=paged_cases(), radix=radix_trace())
+    out = dict(paged=paged_cases(), radix=radix_trace(), radix_page4=radix_trace(4))
     path = os.path.join(HERE, "cache.json")
     with open(path, "w") as f:
         json.dump(out, f)

@@ -91,7 +91,8 @@ def test_paged_allocation_kernels_match_oracle():
             assert used2_gpu == used2 and torch.equal(out2.cpu(), ref2)
 
 
-def test_radix_tree_replays_reference_trace():
+@pytest.mark.parametrize("name,page_size", [("radix", 1), ("radix_page4", 4)])
+def test_radix_tree_replays_reference_trace(name, page_size):
     from sglang_custom_amd.mem_cache.radix_cache import RadixCache
 
     class Alloc:
@@ -104,8 +105,8 @@ def test_radix_tree_replays_reference_trace():
             self.freed.extend(int(v) for v in idx.tolist())
 
     alloc = Alloc()
-    tree = RadixCache(req_to_token_pool=None, token_to_kv_pool_allocator=alloc)
-    for i, rec in enumerate(GOLD["radix"]):
+    tree = RadixCache(req_to_token_pool=None, token_to_kv_pool_allocator=alloc, page_size=page_size)
+    for i, rec in enumerate(GOLD[name]):
         op = rec["op"]
         if op == "insert":
             assert tree.insert(rec["key"], torch.tensor(rec["value"], dtype=torch.int64)) == rec["ret"], (i, rec)
@@ -123,7 +124,7 @@ def test_radix_tree_replays_reference_trace():
             (rec["total"], rec["evictable"], rec["protected"]), (i, rec)
 
 
-def _scheduler_run(ops_backend_module, device, page, dtype="float32", weights_to=None, graphs=False):
+def _scheduler_run(ops_backend_module, device, page, dtype="float32", weights_to=None, graphs=False, radix=False):
     from oracle.llama_ref import OracleLlama
     from sglang_custom_amd.configs.model_config import ModelConfig
     from sglang_custom_amd.managers.schedule_batch import Req
@@ -144,7 +145,13 @@ def _scheduler_run(ops_backend_module, device, page, dtype="float32", weights_to
     spec = [(5, 6), (41, 3), (17, 9), (33, 2), (70, 4), (9, 12), (24, 5)]
     reqs = [Req(i, rng.randint(0, cfg["vocab_size"], n).tolist(), SamplingParams(max_new_tokens=m, temperature=0))
             for i, (n, m) in enumerate(spec)]
-    sch = Scheduler(mr)
+    if radix:   # prompts that share whole pages with earlier ones (and a few tokens past a page boundary)
+        stem = rng.randint(0, cfg["vocab_size"], 2 * page + 3).tolist()
+        for r in reqs[1:]:
+            if len(r.origin_input_ids) > len(stem):
+                r.origin_input_ids[: len(stem)] = stem
+                r.fill_ids = r.origin_input_ids
+    sch = Scheduler(mr, enable_radix_cache=radix)
     for r in reqs[:3]:
         sch.add_request(r)
     arrivals = {2: reqs[3], 4: reqs[4], 5: reqs[5], 9: reqs[6]}
@@ -161,12 +168,20 @@ def _scheduler_run(ops_backend_module, device, page, dtype="float32", weights_to
             row = table[r.req_pool_idx, :n].tolist()
             assert all(s % page == t % page for t, s in enumerate(row)), (r.rid, row)
             pages = {s // page for s in row}
+            if radix:   # whole pages of a cached prefix are shared; the page being filled never is
+                pages = {row[-1] // page} if n % page else set()
             assert not (pages & seen)
             seen |= pages
         it += 1
         assert it < 500
     assert len(sch.finished) == len(reqs)
-    assert mr.token_to_kv_pool_allocator.available_size() == mr.max_total_num_tokens
+    alloc = mr.token_to_kv_pool_allocator
+    assert alloc.available_size() + sch.tree_cache.evictable_size() == mr.max_total_num_tokens
+    if radix:
+        assert sch.cached_prefix_tokens >= 2 * page and sch.cached_prefix_tokens % page == 0   # whole pages were reused
+        assert sch.tree_cache.protected_size() == 0 and sch.tree_cache.total_size() % page == 0
+        sch.tree_cache.evict(1 << 30)
+        assert alloc.available_size() == mr.max_total_num_tokens
     oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
     for r, (n, m) in zip(reqs, spec):
         ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
@@ -182,10 +197,19 @@ def test_scheduler_with_paged_allocator_on_cpu(page):
     _scheduler_run(cpu_ops, "cpu", page)
 
 
+@pytest.mark.parametrize("page", [4, 16])
+def test_scheduler_with_prefix_tree_over_pages_on_cpu(page):
+    import cpu_ops
+    from sglang_custom_amd import ops_backend
+
+    ops_backend.set_ops_backend(cpu_ops)
+    _scheduler_run(cpu_ops, "cpu", page, radix=True)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("page,graphs", [(16, False), (4, True)])
-def test_scheduler_with_paged_allocator_on_gpu(page, graphs):
+@pytest.mark.parametrize("page,graphs,radix", [(16, False, False), (4, True, False), (16, True, True), (4, False, True)])
+def test_scheduler_with_paged_allocator_on_gpu(page, graphs, radix):
     from sglang_custom_amd import ops, ops_backend
 
     ops_backend.set_ops_backend(ops)
-    _scheduler_run(ops, "cuda", page, weights_to="cuda", graphs=graphs)
+    _scheduler_run(ops, "cuda", page, weights_to="cuda", graphs=graphs, radix=radix)

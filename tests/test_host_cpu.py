@@ -180,8 +180,8 @@ def test_continuous_batching_scheduler_matches_isolated_generation(mixed):
         assert sch.num_decode_steps < 30
 
 
-@pytest.mark.parametrize("radix", [False, True])
-def test_scheduler_retracts_decoding_requests_when_the_pool_runs_out(radix):
+@pytest.mark.parametrize("radix,page", [(False, 1), (True, 1), (True, 4), (False, 4)])
+def test_scheduler_retracts_decoding_requests_when_the_pool_runs_out(radix, page):
     """Admission reserves only a fraction of what running requests may still generate, so a pool
     that cannot hold every admitted request to its end runs short mid-decode: requests are
     retracted (slots back, outputs kept), re-prefilled over prompt + outputs later, and still
@@ -200,16 +200,21 @@ def test_scheduler_retracts_decoding_requests_when_the_pool_runs_out(radix):
     ops_backend.set_ops_backend(cpu_ops)
     cfg = hf_config_dict("tiny-llama-d64", "float32")
     w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
-    sa = ServerArgs(dtype="float32", device="cpu", max_total_tokens=160, max_running_requests=6,
-                    disable_cuda_graph=True, max_prefill_tokens=128)
+    # pages: requests are admitted against whole pages plus one, so over-committing the pool takes
+    # longer outputs and a bolder estimate
+    sa = ServerArgs(dtype="float32", device="cpu", max_total_tokens=160 if page == 1 else 256, max_running_requests=6,
+                    disable_cuda_graph=True, max_prefill_tokens=128, page_size=page,
+                    schedule_conservativeness=1.0 if page == 1 else 0.1)
     mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights=w)
     rng = np.random.RandomState(11)
     spec = [(20, 40), (24, 40), (18, 44), (22, 36), (10, 30)]
+    if page > 1:
+        spec = [(n, 2 * m) for n, m in spec]
     shared = rng.randint(0, cfg["vocab_size"], 8).tolist()
     reqs = [Req(i, shared + rng.randint(0, cfg["vocab_size"], n - 8).tolist(),
                 SamplingParams(max_new_tokens=m, temperature=0)) for i, (n, m) in enumerate(spec)]
     sch = Scheduler(mr, enable_radix_cache=radix)
-    assert sch.new_token_ratio == pytest.approx(0.7)
+    assert sch.new_token_ratio == pytest.approx(0.7 if page == 1 else 0.07)
     for r in reqs:
         sch.add_request(r)
     peak_running, ratios = 0, set()
