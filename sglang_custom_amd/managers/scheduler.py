@@ -333,6 +333,96 @@ class Scheduler:
         self.process_batch_result(batch, self.run_batch(batch))
         return True
 
+    # ---- overlap mode: the next step is launched before the last one's tokens are read ----
+    # (scheduler.py event_loop_overlap :749-789, tp_worker_overlap_thread.py:53-292.  The reference
+    # needs a worker thread and a map of "future" token ids because its sampled tokens pass through
+    # the host; here a step's token ids stay on the device and are the next step's input as they
+    # are, so one thread that launches first and reads results one step late gives the same overlap.)
+    def _launch(self, batch: ScheduleBatch):
+        """Launch `batch`, start the copy of its token ids to the host, and bring the batches to the
+        state the next launch needs, none of which depends on the ids' values."""
+        ids = self.run_batch(batch)
+        host = torch.empty(ids.shape, dtype=ids.dtype, device="cpu", pin_memory=ids.is_cuda)
+        host.copy_(ids, non_blocking=True)
+        done = None
+        if ids.is_cuda:
+            done = torch.cuda.Event()
+            done.record()
+        mid_prompt = self.chunked_req if batch.forward_mode.is_extend() else None
+        launched = dict(reqs=list(batch.reqs), ids=host, done=done, extend=batch.forward_mode.is_extend(),
+                        mid_prompt=mid_prompt)
+        batch.output_ids = ids.to(torch.int64)
+        if batch.forward_mode.is_extend():
+            self.num_prefill_batches += 1
+            keep = []
+            for i, req in enumerate(batch.reqs):
+                if req.is_chunked > 0 and req is mid_prompt:
+                    self.tree_cache.cache_unfinished_req(req)
+                    continue
+                req.is_chunked = 0
+                keep.append(i)
+            batch.filter_batch(keep_indices=keep)
+            if not batch.is_empty():
+                self.running_batch.merge_batch(batch)
+        else:
+            self.num_decode_steps += 1
+        return launched
+
+    def _release_late(self, req: Req) -> None:
+        """A request whose end became known one step late: it may already sit in a launched decode
+        step, whose slot goes back with the rest."""
+        if req.req_pool_idx is None:            # retracted meanwhile: it holds nothing
+            self.waiting_queue = [r for r in self.waiting_queue if r is not req]
+            self.finished[req.rid] = req
+            return
+        rb = self.running_batch
+        i = next(k for k, r in enumerate(rb.reqs) if r is req)
+        held = rb.seq_lens_cpu_list[i]
+        cached = len(req.origin_input_ids) + len(req.output_ids) - 1
+        if not self.tree_cache.disable:
+            self.tree_cache.cache_finished_req(req, num_extra_slots=held - cached)
+        else:
+            pool = self.mr.req_to_token_pool
+            self.mr.token_to_kv_pool_allocator.free(pool.req_to_token[req.req_pool_idx, :held].to(torch.int64))
+            pool.free(req.req_pool_idx)
+        req.req_pool_idx = None
+        req.last_node = None
+        self.finished[req.rid] = req
+
+    def _collect(self, launched) -> None:
+        if launched["done"] is not None:
+            launched["done"].synchronize()
+        for req, tok in zip(launched["reqs"], launched["ids"].tolist()):
+            if req is launched["mid_prompt"] or req.finished:
+                continue                        # mid-prompt sample, or a step past the request's end
+            req.output_ids.append(tok)
+            self._check_finished(req)
+            if req.finished:
+                self._release_late(req)
+
+    def run_until_done_overlap(self, max_iters: int = 1 << 30, arrivals=None) -> Dict[object, Req]:
+        """arrivals: {iteration: [requests that arrive before it]} (a stand-in for the request socket)."""
+        assert not self.enable_mixed_chunk, "overlap mode and mixed batches are not combined"
+        arrivals = dict(arrivals or {})
+        in_flight = None
+        it = 0
+        while (self.waiting_queue or self.chunked_req is not None or not self.running_batch.is_empty()
+               or in_flight is not None or arrivals) and it < max_iters:
+            for req in arrivals.pop(it, []):
+                self.add_request(req)
+            rb = self.running_batch
+            if any(r.finished for r in rb.reqs):
+                rb.filter_batch(keep_indices=[i for i, r in enumerate(rb.reqs) if not r.finished])
+            batch = self.get_next_batch_to_run()
+            launched = self._launch(batch) if batch is not None else None
+            if in_flight is not None:
+                self._collect(in_flight)        # the host reads step N while the device runs step N+1
+            elif launched is None and not arrivals:
+                raise RuntimeError("scheduler stalled: a waiting request does not fit the KV pool")
+            in_flight = launched
+            it += 1
+        return self.finished
+
     def run_until_done(self, max_iters: int = 1 << 30) -> Dict[object, Req]:
         it = 0
         while (self.waiting_queue or self.chunked_req is not None or not self.running_batch.is_empty()) and it < max_iters:

@@ -139,19 +139,22 @@ class RadixCache:
         return total_prefix
 
     # ---- request life cycle ----
-    def cache_finished_req(self, req) -> None:
+    def cache_finished_req(self, req, num_extra_slots: int = 0) -> None:
         """All but the last token of a finished request have KV: give them to the tree, free the
-        duplicates and the request row, unlock its path (:188-222)."""
+        duplicates and the request row, unlock its path (:188-222).  num_extra_slots: slots the
+        request holds past those (a decode step launched before its end was known)."""
         token_ids = (req.origin_input_ids + req.output_ids)[:-1]
         pool = self.req_to_token_pool
-        kv_indices = pool.req_to_token[req.req_pool_idx, : len(token_ids)].to(torch.int64)
+        kv_indices = pool.req_to_token[req.req_pool_idx, : len(token_ids) + num_extra_slots].to(torch.int64)
         if self.disable:
             self.token_to_kv_pool_allocator.free(kv_indices)
             pool.free(req.req_pool_idx)
             return
         aligned = self._aligned(len(token_ids))
-        if aligned < len(token_ids):
-            self.token_to_kv_pool_allocator.free(kv_indices[aligned:])   # the partly filled last page
+        if aligned < len(kv_indices):
+            # the partly filled last page and the extra slots, in ONE call: a paged allocator takes
+            # back whole pages and must not see the same page twice
+            self.token_to_kv_pool_allocator.free(kv_indices[aligned:])
         new_prefix_len = self.insert(token_ids[:aligned], kv_indices[:aligned].clone())
         self.token_to_kv_pool_allocator.free(kv_indices[len(req.prefix_indices): new_prefix_len])
         pool.free(req.req_pool_idx)

@@ -203,6 +203,48 @@ def test_continuous_batching_on_gpu_matches_isolated_generation(graphs, mixed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("radix,page", [(False, 1), (True, 1), (True, 16)])
+def test_overlap_scheduling_on_gpu_matches_isolated_generation(radix, page):
+    """Step N+1 (HIP-graph decode or a prefill chunk) is launched before step N's token ids are read
+    back; finished requests run one step past their end and give that slot back too.  Tokens equal
+    the oracle's for each prompt alone."""
+    from oracle.llama_ref import OracleLlama
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.managers.scheduler import Scheduler
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.sampling.sampling_params import SamplingParams
+    from sglang_custom_amd.server_args import ServerArgs
+
+    cfg = hf_config_dict("tiny-llama-d64", "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    sa = ServerArgs(dtype="float32", max_total_tokens=320, max_running_requests=6, cuda_graph_bs=[1, 2, 4, 8],
+                    chunked_prefill_size=32, max_prefill_tokens=128, page_size=page)
+    mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights={k: v.cuda() for k, v in w.items()})
+    rng = np.random.RandomState(5)
+    spec = [(5, 6), (41, 3), (17, 9), (33, 1), (70, 4), (9, 12), (24, 5), (30, 2)]
+    stem = rng.randint(0, cfg["vocab_size"], 2 * page + 3).tolist()
+    reqs = []
+    for i, (n, m) in enumerate(spec):
+        ids = rng.randint(0, cfg["vocab_size"], n).tolist()
+        if radix and n > len(stem):
+            ids[: len(stem)] = stem
+        reqs.append(Req(i, ids, SamplingParams(max_new_tokens=m, temperature=0)))
+    sch = Scheduler(mr, enable_radix_cache=radix)
+    for r in reqs[:3]:
+        sch.add_request(r)
+    sch.run_until_done_overlap(max_iters=3000, arrivals={2: [reqs[3]], 4: [reqs[4]], 5: [reqs[5]], 9: reqs[6:]})
+    assert len(sch.finished) == len(reqs)
+    alloc = mr.token_to_kv_pool_allocator
+    assert alloc.available_size() + sch.tree_cache.evictable_size() == mr.max_total_num_tokens
+    assert sch.tree_cache.protected_size() == 0
+    oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
+    for r, (n, m) in zip(reqs, spec):
+        ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
+        assert r.output_ids == ref_toks[0].tolist(), r.rid
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("page_size", [1, 16])
 def test_retraction_on_gpu_matches_isolated_generation(page_size):
     """A KV pool too small for the admitted requests to finish together: decode retracts requests

@@ -239,6 +239,58 @@ def test_scheduler_retracts_decoding_requests_when_the_pool_runs_out(radix, page
         assert r.output_ids == ref_toks[0].tolist(), (r.rid, r.output_ids, ref_toks[0].tolist())
 
 
+@pytest.mark.parametrize("radix,page,tight", [(False, 1, False), (True, 1, False), (True, 4, False), (False, 1, True)])
+def test_overlap_scheduling_matches_isolated_generation(radix, page, tight):
+    """The loop that launches step N+1 before reading step N's tokens: requests finish one step
+    late (their extra step's slot is returned too), chunked prompts, staggered arrivals, the prefix
+    tree with and without pages, and (tight) a pool small enough to force retraction while results
+    are in flight -- every request still gets exactly the oracle's tokens for its prompt alone."""
+    import cpu_ops
+    from oracle.llama_ref import OracleLlama
+    from sglang_custom_amd import ops_backend
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.managers.scheduler import Scheduler
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+    from sglang_custom_amd.sampling.sampling_params import SamplingParams
+    from sglang_custom_amd.server_args import ServerArgs
+
+    ops_backend.set_ops_backend(cpu_ops)
+    cfg = hf_config_dict("tiny-llama-d64", "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    sa = ServerArgs(dtype="float32", device="cpu", max_total_tokens=176 if tight else 320, max_running_requests=6,
+                    disable_cuda_graph=True, chunked_prefill_size=None if tight else 24, max_prefill_tokens=128,
+                    page_size=page)
+    mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights=w)
+    rng = np.random.RandomState(5)
+    spec = ([(20, 40), (24, 40), (18, 44), (22, 36), (10, 30)] if tight else
+            [(5, 6), (41, 3), (17, 9), (33, 1), (70, 4), (9, 12), (24, 5), (30, 2)])
+    stem = rng.randint(0, cfg["vocab_size"], 2 * page + 3).tolist()
+    reqs = []
+    for i, (n, m) in enumerate(spec):
+        ids = rng.randint(0, cfg["vocab_size"], n).tolist()
+        if radix and n > len(stem):
+            ids[: len(stem)] = stem
+        reqs.append(Req(i, ids, SamplingParams(max_new_tokens=m, temperature=0)))
+    sch = Scheduler(mr, enable_radix_cache=radix)
+    for r in (reqs if tight else reqs[:3]):
+        sch.add_request(r)
+    arrivals = {} if tight else {2: [reqs[3]], 4: [reqs[4]], 5: [reqs[5]], 9: reqs[6:]}
+    sch.run_until_done_overlap(max_iters=3000, arrivals=arrivals)
+    assert len(sch.finished) == len(reqs)
+    if tight:
+        assert sch.total_retracted_reqs > 0
+    alloc = mr.token_to_kv_pool_allocator
+    assert alloc.available_size() + sch.tree_cache.evictable_size() == mr.max_total_num_tokens
+    assert sch.tree_cache.protected_size() == 0
+    assert mr.req_to_token_pool.available_size() == mr.req_to_token_pool.size
+    oracle = OracleLlama(cfg, w, torch.float32, max_total_tokens=512)
+    for r, (n, m) in zip(reqs, spec):
+        ref_toks, _ = oracle.generate_greedy([r.origin_input_ids], m)
+        assert r.output_ids == ref_toks[0].tolist(), (r.rid, r.output_ids, ref_toks[0].tolist())
+
+
 def test_radix_cache_tree_semantics():
     """match / insert / split / lock / LRU eviction of the prefix tree, on a fake allocator."""
     from sglang_custom_amd.mem_cache.radix_cache import RadixCache
