@@ -118,6 +118,16 @@ class Mi355AttnBackend(AttentionBackend):
         if save_kv_cache:
             pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
         md = self.forward_metadata
+        if hasattr(pool, "kv_lora_rank"):
+            # MLA: one latent row per token serves as key (rank + rope) and value (rank) of every
+            # head (deepseek_v2.py:866-875 attn_mqa, num_kv_heads = 1)
+            ops.decode_attention_mla(
+                q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), pool.get_key_buffer(layer.layer_id),
+                o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+                forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
+                forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, pool.kv_lora_rank,
+                layer.scaling, layer.logit_cap)
+            return o
         ops.decode_attention_paged(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
             pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
@@ -162,10 +172,15 @@ class Mi355AttnBackend(AttentionBackend):
         if save_kv_cache:
             pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
         md = self.forward_metadata
+        if hasattr(pool, "kv_lora_rank") and sum(forward_batch.extend_prefix_lens_cpu) > 0:
+            raise NotImplementedError("MLA prefill over a cached prefix (absorbed extend, head_dim 576) is not built: "
+                                      "prefill MLA layers without a prefix (the MHA path)")
         ops.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k, v,
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
-            pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
+            pool.get_key_buffer(layer.layer_id),
+            # (an MLA pool has no separate value rows; without a prefix neither buffer is read)
+            pool.get_key_buffer(layer.layer_id) if hasattr(pool, "kv_lora_rank") else pool.get_value_buffer(layer.layer_id),
             md.qo_indptr, md.kv_indptr, md.kv_indices, None, True, None, md.max_extend_len,
             layer.scaling, layer.logit_cap, sliding_window_size=layer.sliding_window_size)
         return o

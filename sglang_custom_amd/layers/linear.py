@@ -28,6 +28,16 @@ class LinearBase(nn.Module):
         self.tp_size = get_tensor_model_parallel_world_size()
 
 
+class ReplicatedLinear(LinearBase):
+    """Unsharded projection (linear.py ReplicatedLinear): every rank holds the whole weight."""
+
+    def __init__(self, input_size: int, output_size: int, dtype, device, quant_method=None):
+        super().__init__(input_size, output_size, dtype, device, quant_method)
+
+    def forward(self, x):
+        return self.quant_method.apply(self, x), None
+
+
 class QKVParallelLinear(LinearBase):
     """Fused q|k|v projection, column-parallel over heads.  Per rank the rows are
     [q heads | k heads | v heads] (linear.py:784-794); with fewer kv heads than ranks each kv head

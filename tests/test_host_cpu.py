@@ -382,3 +382,26 @@ def test_scheduler_with_radix_prefix_cache_matches_isolated_generation():
     held = tree.total_size()
     assert tree.evict(10 ** 9) == held
     assert alloc.available_size() == mr.max_total_num_tokens and tree.total_size() == 0
+
+
+@pytest.mark.parametrize("q_lora_rank", [None, 48])
+def test_mla_oracle_absorbed_equals_expanded(q_lora_rank):
+    """The two restatements of multi-head latent attention (latent expanded per head vs. kv_b_proj
+    folded into query and output) are one function: equal to float64 rounding."""
+    from oracle import mla_ref
+
+    g = torch.Generator().manual_seed(2)
+    hidden, H, nope, rope, vd, kr = 64, 4, 16, 8, 12, 32
+    w = {"kv_a_layernorm": 1 + 0.1 * torch.randn(kr, generator=g), "kv_b_proj": torch.randn(H * (nope + vd), kr, generator=g) * 0.2,
+         "o_proj": torch.randn(hidden, H * vd, generator=g) * 0.2}
+    if q_lora_rank is None:
+        w["q_proj"] = torch.randn(H * (nope + rope), hidden, generator=g) * 0.2
+        w["kv_a_proj_with_mqa"] = torch.randn(kr + rope, hidden, generator=g) * 0.2
+    else:
+        w["fused_qkv_a_proj_with_mqa"] = torch.randn(q_lora_rank + kr + rope, hidden, generator=g) * 0.2
+        w["q_a_layernorm"] = 1 + 0.1 * torch.randn(q_lora_rank, generator=g)
+        w["q_b_proj"] = torch.randn(H * (nope + rope), q_lora_rank, generator=g) * 0.2
+    x = torch.randn(11, hidden, generator=g)
+    a = mla_ref.mla_attention(x, w, H, nope, rope, vd, q_lora_rank, kr)
+    b = mla_ref.mla_attention_absorbed(x, w, H, nope, rope, vd, q_lora_rank, kr)
+    assert a.shape == (11, hidden) and (a - b).abs().max().item() < 1e-10 * a.abs().max().item()
