@@ -13,8 +13,12 @@ SOURCES = ["elementwise.hip", "index_ops.hip", "attn_decode.hip", "attn_extend.h
            "sampling.hip", "quant_fp8.hip", "debug_bw.hip", "allreduce.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"),
            os.path.join(os.path.dirname(HERE), "include", "mi355_hotpath.h")]
+# -amdgpu-mfma-vgpr-form: matrix-core accumulators stay in ordinary vector registers.  The kernels
+# here run softmax / rescale / epilogue arithmetic on them between MFMAs; with the default AGPR
+# form every such use costs a v_accvgpr_read/_write pair (hundreds per loop body in the attention
+# kernels), and no kernel needs more than the 256 registers the VGPR form can address.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _stale(target, deps):

@@ -104,7 +104,9 @@ __device__ __forceinline__ void ar_store_epoch(const ArPeers& p, int rank, uint3
   if (threadIdx.x == 0) ar_signal(p.base[rank])->epoch[blockIdx.x] = epoch;
 }
 
-using ArVec = uint4;   // 16 bytes: 8 16-bit values or 4 floats
+// 16 bytes: 8 16-bit values or 4 floats.  A plain aggregate (not HIP's uint4 class): arrays of it
+// are split into registers by the compiler at every rank count.
+struct alignas(16) ArVec { uint32_t x, y, z, w; };
 
 template <typename T> struct ArAcc {
   static constexpr int N = 16 / sizeof(T);
@@ -158,6 +160,10 @@ __global__ __launch_bounds__(AR_THREADS) void ar_one_shot_kernel(ArPeers p, cons
   ar_store_epoch(p, rank, epoch);
 }
 
+template <int NR>
+__device__ __forceinline__ void gather_slices(const ArVec* const* red, ArVec* __restrict__ out, int64_t tid,
+                                              int64_t stride, int64_t part, int64_t last);
+
 template <typename T, int NR>
 __global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArPeers p, const ArVec* in, ArVec* out,
                                                                  int64_t nvec, int rank, int64_t max_bytes,
@@ -183,23 +189,41 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArPeers p, cons
   const int64_t my_len = rank == NR - 1 ? last : part;
   for (int64_t i = tid; i < my_len; i += stride) reduced[i] = ar_reduce<T, NR>(src, i);
   ar_barrier<NR>(p, rank, epoch, status);
-  for (int64_t i = tid; i < last; i += stride) {
-    ArVec raw[NR];
+  const ArVec* red[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
-      if (r == NR - 1 || i < part) raw[r] = reinterpret_cast<const ArVec*>(ar_scatter(p.base[r], max_bytes))[i];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-      if (r == NR - 1 || i < part) out[r * part + i] = raw[r];
-  }
+  for (int r = 0; r < NR; ++r) red[r] = reinterpret_cast<const ArVec*>(ar_scatter(p.base[r], max_bytes));
+  gather_slices<NR>(red, out, tid, stride, part, last);
   ar_barrier<NR>(p, rank, epoch, status);
   ar_store_epoch(p, rank, epoch);
+}
+
+// Stage 2 of the two-shot kernel.  `out` never overlaps a scatter area; saying so lets the compiler
+// keep all loads of an index in registers ahead of its stores.
+template <int NR>
+__device__ __forceinline__ void gather_slices(const ArVec* const* red, ArVec* __restrict__ out, int64_t tid,
+                                              int64_t stride, int64_t part, int64_t last) {
+  for (int64_t i = tid; i < last; i += stride) {
+    // loads are unconditional (index clamped into the slice) so that all of them are in flight together
+    const int64_t ic = i < part ? i : (part > 0 ? part - 1 : 0);
+    constexpr int H = NR / 2;   // (two half-size register arrays, see the all-gather below)
+    ArVec lo[H], hi[NR - H];
+#pragma unroll
+    for (int r = 0; r < H; ++r) lo[r] = red[r][ic];
+#pragma unroll
+    for (int r = H; r < NR; ++r) hi[r - H] = red[r][r == NR - 1 ? i : ic];
+#pragma unroll
+    for (int r = 0; r < H; ++r)
+      if (i < part) out[r * part + i] = lo[r];
+#pragma unroll
+    for (int r = H; r < NR; ++r)
+      if (r == NR - 1 || i < part) out[r * part + i] = hi[r - H];
+  }
 }
 
 // out[r] = rank r's input, r = 0..n-1: the concatenating all-gather of vocab-sharded logits, with
 // the same copy-in / barrier / pull structure (no arithmetic, so no element type).
 template <int NR>
-__global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, const ArVec* in, ArVec* out, int64_t nvec,
+__global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, const ArVec* __restrict__ in, ArVec* __restrict__ out, int64_t nvec,
                                                                    int rank, uint32_t* status) {
   const int64_t tid = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
@@ -207,12 +231,22 @@ __global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, co
   uint32_t epoch = ar_load_epoch(p, rank);
   for (int64_t i = tid; i < nvec; i += stride) mine[i] = in[i];
   ar_barrier<NR>(p, rank, epoch, status);
+  const ArVec* src[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]));
   for (int64_t i = tid; i < nvec; i += stride) {
-    ArVec raw[NR];
+    // two half-size register arrays: the compiler keeps arrays of up to four vectors in registers
+    // and sends longer ones through private memory
+    constexpr int H = NR / 2;
+    ArVec lo[H], hi[NR - H];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) raw[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]))[i];
+    for (int r = 0; r < H; ++r) lo[r] = src[r][i];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) out[r * nvec + i] = raw[r];
+    for (int r = H; r < NR; ++r) hi[r - H] = src[r][i];
+#pragma unroll
+    for (int r = 0; r < H; ++r) out[r * nvec + i] = lo[r];
+#pragma unroll
+    for (int r = H; r < NR; ++r) out[r * nvec + i] = hi[r - H];
   }
   ar_barrier<NR>(p, rank, epoch, status);
   ar_store_epoch(p, rank, epoch);

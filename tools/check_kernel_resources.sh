@@ -8,7 +8,7 @@ cd "$tmp"
 bad=0
 for f in "$root"/sglang_custom_amd/csrc/*.hip; do
   b=$(basename "$f" .hip)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I"$root/include" -c "$f" -o "$b.o" -save-temps 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I"$root/include" -c "$f" -o "$b.o" -save-temps 2>/dev/null
   s="$b-hip-amdgcn-amd-amdhsa-gfx950.s"
   n=$(grep -E "^\s+\.(name|private_segment_fixed_size|vgpr_spill_count):" "$s" | paste - - - | awk '$4 != 0 || $6 != 0' | wc -l)
   echo "$b: $(grep -c '^\s*\.name:' "$s") kernels, $n with private memory or spills"
