@@ -317,6 +317,11 @@ constexpr int XV_ROW = 128 + 16;   // V tile row: 288 B -> conflict-free transpo
 
 // KV8: the prefix lives in an e4m3fn cache (kbuf / vbuf are byte buffers); its rows are widened to T
 // while they are staged.  The extend part (k_ext / v_ext) is always T.
+// v_exp_f32 as is: the library exp2f wraps it in range scaling so that results below 2^-126 come out
+// as denormals instead of zero (five instructions per call, and this kernel is bound by instruction
+// issue).  A softmax weight that small contributes nothing at 16-bit output precision.
+__device__ __forceinline__ float raw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <typename T, bool KV8 = false>
 __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restrict__ q_ext,
                                                                const T* __restrict__ k_ext,
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restri
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mnew = fmaxf(m, mloc);
     const float ms = mnew == -INFINITY ? 0.f : mnew;
-    const float alpha = exp2f(m - ms);
+    const float alpha = raw_exp2(m - ms);
     m = mnew;
     float psum = 0.f;
     frag pb[2];
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256) void extend_attn_mfma_kernel(const T* __restri
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pe = exp2f(st[t][r] - ms);
+        const float pe = raw_exp2(st[t][r] - ms);
         const T pt = (T)pe;                 // probabilities enter P.V in the value dtype
         psum += (float)pt;
         pb[t >> 1][(t & 1) * 4 + r] = pt;
