@@ -317,8 +317,8 @@ constexpr int XV_ROW = 128 + 16;   // V tile row: 288 B -> conflict-free transpo
 
 // Three waves per SIMD (168 registers): the phases of a tile (LDS reads, MFMAs, softmax arithmetic,
 // transposed reads, MFMAs) run back to back within a wave, so it is the number of resident waves that
-// overlaps them: 2.17 -> 1.81 ms per layer against two waves, although eight values of the
-// page-table path (tiles that reach into the cached prefix) then live in private memory.
+// overlaps them: 2.17 -> 1.75 ms per layer against two waves.  To fit, the K fragments of a k-step
+// are read right before their MFMAs (no second fragment buffer: the other waves cover that latency).
 // KV8: the prefix lives in an e4m3fn cache (kbuf / vbuf are byte buffers); its rows are widened to T
 // while they are staged.  The extend part (k_ext / v_ext) is always T.
 // v_exp_f32 as is: the library exp2f wraps it in range scaling so that results below 2^-126 come out
@@ -437,28 +437,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     if (kt + 1 < n_tiles) load_tile(kt + 1);
 
-    // S^T tile: st[t][r] = score of key 64 kt + 16 t + 4 c + r for this lane's query
-    // k-step major with the four key sub-tiles as independent accumulators; the K fragments of step
-    // s + 1 are requested before the MFMAs of step s issue (the scheduler would otherwise sink every
-    // LDS read next to its MFMA and the product would run at LDS latency)
+    // S^T tile: st[t][r] = score of key 64 kt + 16 t + 4 c + r for this lane's query;
+    // k-step major with the four key sub-tiles as independent accumulators
     f32x4 st[4];
-    frag kf[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      kf[0][t] = *reinterpret_cast<const frag*>(k_rd + (16 * t) * XK_ROW);
-    }
+    for (int t = 0; t < 4; ++t) st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) {
+      frag kf[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          kf[(s + 1) & 1][t] = *reinterpret_cast<const frag*>(k_rd + (16 * t) * XK_ROW + 32 * (s + 1));
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const frag*>(k_rd + (16 * t) * XK_ROW + 32 * s);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) st[t] = Mfma<T>::run(kf[s & 1][t], qf[s], st[t]);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < 4; ++t) st[t] = Mfma<T>::run(kf[t], qf[s], st[t]);
     }
     const bool need_mask = kt * 64 + 63 > wave_min_limit;   // wave-uniform
     float mloc = -INFINITY;
