@@ -172,9 +172,22 @@ class Mi355AttnBackend(AttentionBackend):
         if save_kv_cache:
             pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
         md = self.forward_metadata
+        if hasattr(pool, "kv_lora_rank") and layer.qk_head_dim == pool.head_dim:
+            # MLA in the absorbed form (attn_mqa) over a cached prefix: the new latent rows are in
+            # the cache by now (written above), so token t of a request is a decode query over the
+            # request's first position(t) + 1 rows -- the multi-query kernel of the decode path
+            # serves it with per-token table rows and lengths.  Causal by construction.
+            assert save_kv_cache, "the absorbed MLA extend reads the new tokens from the cache"
+            tok_req = torch.repeat_interleave(forward_batch.req_pool_indices, forward_batch.extend_seq_lens.to(torch.int64))
+            tok_len = (forward_batch.positions + 1).to(torch.int64)
+            ops.decode_attention_mla(
+                q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), pool.get_key_buffer(layer.layer_id),
+                o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+                forward_batch.req_to_token_pool.req_to_token, tok_req, tok_len, None, None, 1, pool.kv_lora_rank,
+                layer.scaling, layer.logit_cap)
+            return o
         if hasattr(pool, "kv_lora_rank") and sum(forward_batch.extend_prefix_lens_cpu) > 0:
-            raise NotImplementedError("MLA prefill over a cached prefix (absorbed extend, head_dim 576) is not built: "
-                                      "prefill MLA layers without a prefix (the MHA path)")
+            raise NotImplementedError("MLA multi-head prefill cannot read a cached prefix: use the absorbed form (attn_mqa)")
         ops.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k, v,
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),

@@ -10,8 +10,8 @@ with the reference's two forward methods (python/sglang/srt/models/deepseek_v2.p
                   512-wide values, one KV "head" shared by all heads (mi355_decode_attention_mla).
 
 dispatch_attn_forward_method (:969-1039) picks between them as the reference's Triton backend does:
-extend without prefix -> normal, decode -> absorb; extend over a cached prefix (the absorbed extend,
-head_dim 576) is not built and raises.  YaRN scaling of the rotary table and of the softmax scale is
+extend without prefix -> normal; decode and extend over a cached prefix -> absorb (the latter as one
+decode-style multi-query pass per new token over the rows cached so far: exact, O(new x cached) reads).  YaRN scaling of the rotary table and of the softmax scale is
 left to the caller (rope_scaling=None here); the rotation is the interleaved (GPT-J) layout.
 """
 from typing import Optional
@@ -121,8 +121,8 @@ class DeepseekV2AttentionMLA(nn.Module):
         return self.o_proj(out.contiguous())[0]
 
     def forward(self, positions, hidden_states, forward_batch):
-        if forward_batch.forward_mode.is_decode():
+        # dispatch_attn_forward_method (:969-1039) for the Triton backend: multi-head form for a
+        # prefill without prefix, absorbed form otherwise (decode, or extend over cached latent rows)
+        if forward_batch.forward_mode.is_decode() or sum(forward_batch.extend_prefix_lens_cpu) > 0:
             return self.forward_absorb(positions, hidden_states, forward_batch)
-        if sum(forward_batch.extend_prefix_lens_cpu) > 0:
-            raise NotImplementedError("MLA prefill over a cached prefix is not built")
         return self.forward_normal(positions, hidden_states, forward_batch)

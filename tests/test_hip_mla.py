@@ -83,3 +83,70 @@ def test_mla_module_prefill_then_absorbed_decode(dtn, H, qr, tol):
         ref = torch.stack([r[n + t] for r, n in zip(want, lens)]).float()
         assert fb.positions.tolist() == [n + t for n in lens]
         assert (out - ref).abs().max().item() <= tol * scale, f"decode step {t}"
+
+
+def test_mla_module_chunked_prefill_over_cached_latent_rows():
+    """A prompt prefilled in two chunks: the first through the multi-head path, the second as an
+    extend over the cached latent rows in the absorbed form; then one decode step.  Every position
+    equals the oracle's causal attention over the whole sequence."""
+    from oracle import mla_ref
+    from sglang_custom_amd.layers.attention.mi355_backend import Mi355AttnBackend
+    from sglang_custom_amd.managers.schedule_batch import Req, ScheduleBatch
+    from sglang_custom_amd.mem_cache.allocator import TokenToKVPoolAllocator
+    from sglang_custom_amd.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardBatch
+    from sglang_custom_amd.models.deepseek_v2 import DeepseekV2AttentionMLA
+
+    dt, H, qr, tol = torch.bfloat16, 16, None, 4e-2
+    hidden, nope, rope, vd, kr = 1024, 128, 64, 128, 512
+    w = {k: v.to(dt) for k, v in _weights(hidden, H, nope, rope, vd, qr, kr, 5).items()}
+    kvpool = MLATokenToKVPool(1024, 1, dt, kr, rope, 1, DEV)
+    runner = SimpleNamespace(device=DEV, req_to_token_pool=ReqToTokenPool(8, 256, DEV), token_to_kv_pool=kvpool,
+                             model_config=SimpleNamespace(num_attention_heads=H, num_key_value_heads=1, vocab_size=32),
+                             tp_size=1, attn_backend=None)
+    runner.attn_backend = Mi355AttnBackend(runner)
+    alloc = TokenToKVPoolAllocator(1024, dt, DEV, kvpool)
+    attn = DeepseekV2AttentionMLA(hidden, H, nope, rope, vd, qr, kr, 0, dt, DEV, max_position_embeddings=512)
+    with torch.no_grad():
+        for name, val in w.items():
+            getattr(attn, name).weight.data.copy_(val.to(DEV))
+    attn.post_load_weights()
+
+    first, lens = (20, 3, 48), (45, 30, 49)            # tokens in chunk 1, prompt lengths
+    g = torch.Generator().manual_seed(12)
+    seqs = [torch.randn(n + 1, hidden, generator=g).to(dt) for n in lens]
+    want = [mla_ref.mla_attention(s, w, H, nope, rope, vd, qr, kr).float() for s in seqs]
+    scale = max(r.abs().max().item() for r in want)
+    reqs = [Req(i, [1] * n) for i, n in enumerate(lens)]
+
+    def run(batch, rows):
+        fb = ForwardBatch.init_new(batch.get_model_worker_batch(), runner)
+        runner.attn_backend.init_forward_metadata(fb)
+        with torch.no_grad():
+            return attn(fb.positions, rows.to(DEV), fb).float().cpu(), fb
+
+    # chunk 1: no prefix -> multi-head path
+    for r, f in zip(reqs, first):
+        r.fill_ids = r.origin_input_ids[:f]
+        r.extend_input_len = f
+    batch = ScheduleBatch.init_new(reqs, runner.req_to_token_pool, alloc, model_config=runner.model_config)
+    batch.prepare_for_extend()
+    out, _ = run(batch, torch.cat([s[:f] for s, f in zip(seqs, first)]))
+    assert (out - torch.cat([r[:f] for r, f in zip(want, first)])).abs().max().item() <= tol * scale
+    # chunk 2: the rows of chunk 1 are the prefix -> absorbed extend over the cache
+    table = runner.req_to_token_pool.req_to_token
+    for r, f in zip(reqs, first):
+        prefix = table[r.req_pool_idx, :f].clone()
+        runner.req_to_token_pool.free(r.req_pool_idx)
+        r.req_pool_idx = None
+        r.init_next_round_input(prefix)
+    batch = ScheduleBatch.init_new(reqs, runner.req_to_token_pool, alloc, model_config=runner.model_config)
+    batch.prepare_for_extend()
+    out, fb = run(batch, torch.cat([s[f:n] for s, f, n in zip(seqs, first, lens)]))
+    assert fb.extend_prefix_lens_cpu == list(first)
+    assert (out - torch.cat([r[f:n] for r, f, n in zip(want, first, lens)])).abs().max().item() <= tol * scale
+    # one decode step on top
+    batch.output_ids = torch.ones(len(lens), dtype=torch.int64, device=DEV)
+    batch.prepare_for_decode()
+    out, _ = run(batch, torch.stack([s[n] for s, n in zip(seqs, lens)]))
+    assert (out - torch.stack([r[n] for r, n in zip(want, lens)])).abs().max().item() <= tol * scale
