@@ -405,3 +405,22 @@ def test_mla_oracle_absorbed_equals_expanded(q_lora_rank):
     a = mla_ref.mla_attention(x, w, H, nope, rope, vd, q_lora_rank, kr)
     b = mla_ref.mla_attention_absorbed(x, w, H, nope, rope, vd, q_lora_rank, kr)
     assert a.shape == (11, hidden) and (a - b).abs().max().item() < 1e-10 * a.abs().max().item()
+
+
+def test_mla_oracle_rotation_is_the_pinned_interleaved_rope():
+    """oracle/mla_ref.py rotates with its own float64 helper; it must be the rotation of
+    ops_ref.apply_rope(is_neox=False), which the reference's golden vectors pin."""
+    from oracle import mla_ref, ops_ref
+
+    g = torch.Generator().manual_seed(4)
+    T, H, R, theta = 9, 3, 64, 10000.0
+    x = torch.randn(T, H, R, generator=g, dtype=torch.float64)
+    pos = torch.tensor([0, 1, 2, 5, 17, 100, 511, 3, 64])
+    cache = ops_ref.cos_sin_cache(R, 512, theta, None, torch.float64)
+    ang = pos.double()[:, None] * (1.0 / theta ** (torch.arange(0, R, 2, dtype=torch.float64) / R))[None]
+    cache64 = torch.cat([ang.cos(), ang.sin()], -1)                      # exact angles for the rows in use
+    assert (cache[pos] - cache64).abs().max().item() < 1e-4              # same table up to its float32 construction
+    table = torch.zeros(512, R, dtype=torch.float64)
+    table[pos] = cache64
+    q, _ = ops_ref.apply_rope(pos, x.reshape(T, H * R), x[:, :1].reshape(T, R), R, table, False)
+    assert (q.view(T, H, R) - mla_ref._rope_gptj(x, pos, theta)).abs().max().item() < 1e-12
