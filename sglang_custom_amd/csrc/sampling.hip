@@ -21,8 +21,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restric
   const bool vec = (row_stride % 4 == 0) && aligned16(logits);
   if (vec) {
     const int64_t nv = vocab / 4;
-    for (int64_t i = threadIdx.x; i < nv; i += SAMP_THREADS) {
-      const float4 v = *reinterpret_cast<const float4*>(row + i * 4);
+    auto take = [&](const float4& v, int64_t i) {
       const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -30,7 +29,18 @@ __global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restric
           best = a[j];
           bidx = (int)(i * 4 + j);
         }
+    };
+    // four loads in flight per lane before the first comparison: 64 rows are 64 workgroups, so the
+    // row is read at the latency of its loads unless each lane keeps several outstanding
+    int64_t i = threadIdx.x;
+    for (; i + 3 * SAMP_THREADS < nv; i += 4 * SAMP_THREADS) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(row + (i + u * SAMP_THREADS) * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) take(v[u], i + u * SAMP_THREADS);
     }
+    for (; i < nv; i += SAMP_THREADS) take(*reinterpret_cast<const float4*>(row + i * 4), i);
     for (int64_t i = nv * 4 + threadIdx.x; i < vocab; i += SAMP_THREADS)
       if (row[i] > best || (row[i] == best && (int)i < bidx)) {
         best = row[i];
