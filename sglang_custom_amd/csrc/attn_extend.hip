@@ -474,9 +474,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pe = raw_exp2(st[t][r] - ms);
-        const T pt = (T)pe;                 // probabilities enter P.V in the value dtype
-        psum += (float)pt;
-        pb[t >> 1][(t & 1) * 4 + r] = pt;
+        // the denominator sums the fp32 weights; only the P.V operand is rounded to the value dtype
+        // (as the reference's kernel: deno += sum(p), acc += dot(p.to(v.dtype), v),
+        // triton_ops/extend_attention.py:190,200-201 and 271,281-282)
+        psum += pe;
+        pb[t >> 1][(t & 1) * 4 + r] = (T)pe;
       }
     lsum = lsum * alpha + psum;
     // multiplying by exactly 1 changes nothing: rescale only when some lane's maximum moved
