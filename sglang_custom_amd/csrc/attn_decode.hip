@@ -981,7 +981,7 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
 constexpr int MLA_RANK = 512, MLA_ROPE = 64, MLA_D = MLA_RANK + MLA_ROPE;
 constexpr int MLA_ROW = MLA_RANK + 16;   // LDS row (elements): 1056 B, same bank residue as DV_ROW
 
-constexpr int MLA_QROW = MLA_D + 8;                   // query tile row in LDS: 1168 B, conflict-free b128 reads
+constexpr int MLA_QROW = MLA_D + 16;                  // query tile row in LDS: 1184 B (bank = 8 * row residue class, as DV_ROW)
 constexpr int MLA_V_BYTES = 4 * 16 * MLA_ROW * 2;     // four waves' value tiles (16-bit elements)
 constexpr int MLA_LDS_BYTES = MLA_V_BYTES + 16 * MLA_QROW * 2;
 static_assert(MLA_V_BYTES >= 16 * MLA_RANK * 4, "the merge buffer reuses the value tiles");

@@ -22,7 +22,7 @@ template <typename T, typename OUT> __device__ __forceinline__ OUT finish(float 
 }
 
 constexpr int SK_BK = 256;            // K elements per chunk
-constexpr int SK_LDS_ROW = SK_BK + 8; // padded LDS row (elements): 528 B rows spread banks
+constexpr int SK_LDS_ROW = SK_BK + 16; // padded LDS row (elements): 544 B rows (bank = 8 * row: no ds_read_b128 conflicts)
 
 // grid: (ceil(N / (64*NT)), splits).  block: 256.
 template <typename T, int MT, int NT, typename OUT, bool PACKED = false>
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
   constexpr int KSTEP = 4 * VE;               // k covered by one fragment row (4 lane groups)
   constexpr int BK = 8 * KSTEP / NT;          // k elements per chunk (256 / NT; fp8: 512 / NT)
   constexpr int S = BK / KSTEP;               // fragment steps per chunk
-  constexpr int ROW = BK + VE;                // padded LDS row (+16 B): bank = 4 * row (mod 64)
+  constexpr int ROW = BK + 2 * VE;            // padded LDS row (+32 B): bank = 8 * row (mod 64)
   constexpr int KMUL = PACKED ? 64 : 1;
   constexpr int R = 16 * MT;
   constexpr int THREADS = 64 * WAVES;
@@ -680,7 +680,7 @@ static void launch_ring(const T* x, const T* w, const void* bias, OUT* y, float*
                         int M, int N, int K, int64_t x_stride, const SkinnyPlan& p, hipStream_t st,
                         const float* x_scale = nullptr, const float* w_scale = nullptr) {
   const dim3 grid((unsigned)p.nblocks, (unsigned)p.splits);
-  const size_t lds = 2 * (16 * MT) * (512 / NT + 16);   // bytes: same tile geometry for 16-bit and fp8
+  const size_t lds = 2 * (16 * MT) * (512 / NT + 32);   // bytes: same tile geometry for 16-bit and fp8
   auto kern = gemm_ring_kernel<T, MT, NT, OUT, PACKED, WAVES, ACT>;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
