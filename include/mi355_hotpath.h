@@ -8,7 +8,8 @@
  *     last error on the calling thread is available from mi355_last_error();
  *   - validates shapes/dtypes/alignment on the host BEFORE launching anything;
  *   - is asynchronous: no hipMalloc/hipFree, no host synchronisation, safe under HIP graph
- *     capture; all scratch memory is passed in by the caller.
+ *     capture; all scratch memory is passed in by the caller (the one exception,
+ *     mi355_decode_attention_static, says so).
  *
  * "file:line" citations name the reference interface (under the reference checkout's root)
  * that each entry point replaces.
@@ -211,6 +212,27 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
                            int v_head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                            int64_t num_slots, float sm_scale, float logit_cap,
                            int sliding_window_size, int dtype, void* stream);
+
+/* mi355_decode_attention for callers that cannot allocate device memory or pass a workspace (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the split-KV
+ * scratch (attn_logits / attn_lse of the call above) is a fixed array inside the library,
+ * MI355_DECODE_STATIC_SCRATCH_BYTES per GPU, held from the first call on that GPU until the process
+ * ends.  Everything else -- arguments, kernels, results bit for bit -- is mi355_decode_attention.
+ * The call itself allocates nothing (no hipMalloc / hipFree); the first call on a device looks the
+ * array's device address up (hipGetSymbolAddress), so make one call per device before capturing.
+ * bs * hq * num_splits * (v_head_dim + 1) * 4 bytes (partials rounded up to 256 B) beyond the limit
+ * -> MI355_ERR_UNSUPPORTED.  All calls on one GPU share the array: calls that may overlap on a GPU
+ * (different streams, different threads) race on it; order them or use mi355_decode_attention.
+ * The array keeps the previous call's contents; no cell is read before this call has written it.
+ * No counterpart in the reference (its backends allocate attn_logits / attn_lse per forward,
+ * layers/attention/triton_backend.py:210-219). */
+#define MI355_DECODE_STATIC_SCRATCH_BYTES (16 << 20)
+int mi355_decode_attention_static(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                  const int32_t* page_table, int mode, const int64_t* req_pool_indices,
+                                  const int64_t* seq_lens, const int32_t* kv_indptr, int64_t table_stride,
+                                  int num_splits, int64_t bs, int hq, int hkv, int head_dim, int v_head_dim,
+                                  int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap,
+                                  int dtype, void* stream);
 
 /* Decode attention fused with everything between the qkv GEMM and the attention kernel.
  * qkv_part: the fp32 split-K partials [nsplit][bs][(hq + 2 hkv) * 128] of the qkv projection

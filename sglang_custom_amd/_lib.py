@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mi355_linear": (I, [P, P, P, P, L, L, L, L, P, L, I, I, P]),
     "mi355_packed_weight_elems": (L, [L, L]),
     "mi355_pack_weight": (I, [P, P, L, L, I, P]),
+    "mi355_decode_attention_static": (I, [P, P, P, P, P, I, P, P, P, L, I, L, I, I, I, I, L, L, F, F, I, P]),
     "mi355_decode_attention_mla": (I, [P, P, P, P, I, P, P, P, L, P, P, I, L, I, I, I, L, L, F, F, I, P]),
     "mi355_linear_packed": (I, [P, P, P, P, L, L, L, L, P, L, I, I, P]),
     "mi355_linear_packed_silu_mul": (I, [P, P, P, L, L, L, L, P, L, I, P]),

@@ -12,6 +12,7 @@
 #include "common.cuh"
 #include <math.h>
 #include <type_traits>
+#include <mutex>
 
 namespace mi355 {
 
@@ -1384,6 +1385,71 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("decode_attention");
   return MI355_OK;
+}
+
+// ---- split-KV decode attention for callers that cannot allocate -----------------------------
+// The partial outputs and log-sum-exps of the KV splits live in a file-scope device array instead
+// of caller memory.  `g_static_scratch` is only a host-side stand-in for the symbol: the device
+// address comes from hipGetSymbolAddress, once per device (every GPU holds its own copy of the
+// array at its own address), and that address is what the kernels receive.
+static constexpr int64_t kStaticScratchFloats = MI355_DECODE_STATIC_SCRATCH_BYTES / 4;
+static __device__ __align__(256) float g_static_scratch[kStaticScratchFloats];
+
+static constexpr int kMaxDevices = 64;
+static std::mutex g_static_mu;
+static float* g_static_ptr[kMaxDevices];   // per device; null until that device's first call
+
+static int static_scratch_ptr(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    set_error("decode_attention_static: hipGetDevice failed or device %d outside 0..%d: %s", dev, kMaxDevices - 1,
+              hipGetErrorString(e));
+    return MI355_ERR_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lk(g_static_mu);
+  if (!g_static_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch));
+    if (e != hipSuccess || !ptr) {
+      set_error("decode_attention_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return MI355_ERR_LAUNCH;
+    }
+    g_static_ptr[dev] = (float*)ptr;
+  }
+  *out = g_static_ptr[dev];
+  return MI355_OK;
+}
+
+int mi355_decode_attention_static(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                  const int32_t* page_table, int mode, const int64_t* req_pool_indices,
+                                  const int64_t* seq_lens, const int32_t* kv_indptr, int64_t table_stride,
+                                  int num_splits, int64_t bs, int hq, int hkv, int head_dim, int v_head_dim,
+                                  int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap, int dtype,
+                                  void* stream) {
+  MI355_REQUIRE(bs >= 0 && hq > 0 && v_head_dim > 0 && num_splits >= 1, MI355_ERR_INVALID,
+                "decode_attention_static: bad shape bs=%lld hq=%d Dv=%d splits=%d", (long long)bs, hq, v_head_dim,
+                num_splits);
+  // partial outputs [bs, hq, splits, Dv] followed by log-sum-exps [bs, hq, splits], the latter
+  // starting on a 256-byte boundary
+  const int64_t n_o = bs * hq * (int64_t)num_splits * v_head_dim;
+  const int64_t n_o_pad = (n_o + 63) / 64 * 64;
+  const int64_t n_lse = bs * hq * (int64_t)num_splits;
+  MI355_REQUIRE(num_splits == 1 || n_o_pad + n_lse <= kStaticScratchFloats, MI355_ERR_UNSUPPORTED,
+                "decode_attention_static: bs %lld x hq %d x splits %d x (Dv %d + 1) floats = %lld bytes of split "
+                "scratch exceed the built-in %lld bytes; use fewer splits or mi355_decode_attention",
+                (long long)bs, hq, num_splits, v_head_dim, (long long)((n_o_pad + n_lse) * 4),
+                (long long)MI355_DECODE_STATIC_SCRATCH_BYTES);
+  float* base = nullptr;
+  if (num_splits > 1) {
+    const int rc = static_scratch_ptr(&base);
+    if (rc != MI355_OK) return rc;
+  }
+  // Every (sequence, head, split) cell is written by stage 1 before stage 2 reads it (an empty
+  // split stores lse = -inf), so nothing in the array has to start at zero.
+  return mi355_decode_attention(q, k_buffer, v_buffer, o, page_table, mode, req_pool_indices, seq_lens, kv_indptr,
+                                table_stride, base, base ? base + n_o_pad : nullptr, num_splits, bs, hq, hkv,
+                                head_dim, v_head_dim, q_stride, num_slots, sm_scale, logit_cap, dtype, stream);
 }
 
 int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const float* part_x_scale,

@@ -322,6 +322,26 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
         "decode_attention")
 
 
+def decode_attention_paged_static(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
+                                  num_kv_splits: int, sm_scale: float, logit_cap: float = 0.0) -> None:
+    """decode_attention_paged without caller scratch: the split partials live in the library's own
+    fixed device array (mi355_decode_attention_static), so the call allocates nothing.  Calls that
+    may overlap on one GPU race on that array."""
+    _gpu(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous()
+    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    check(_lib_().mi355_decode_attention_static(
+        q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
+        req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
+        req_to_token.stride(0), num_kv_splits, B, Hq, Hkv, D, Dv,
+        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer), _stream(q)),
+        "decode_attention_static")
+
+
 def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache, k_buffer, v_buffer, o, req_to_token,
                                req_pool_indices, seq_lens, attn_logits, attn_lse, num_kv_splits: int,
                                sm_scale: float, part_x_scale=None, part_w_scale=None) -> None:
