@@ -43,6 +43,33 @@ def build_cos_sin_cache(rotary_dim: int, max_position: int, base: float,
     return torch.cat((freqs.cos(), freqs.sin()), dim=-1)
 
 
+def yarn_get_mscale(scale: float = 1, mscale: float = 1) -> float:
+    """Magnitude correction of YaRN-interpolated attention (rotary_embedding.py:635-638)."""
+    return 1.0 if scale <= 1 else 0.1 * mscale * math.log(scale) + 1.0
+
+
+def yarn_inverse_frequencies(rotary_dim: int, base: float, factor: float, original_max_position: int,
+                             beta_fast: float = 32, beta_slow: float = 1,
+                             extrapolation_factor: float = 1) -> torch.Tensor:
+    """YaRN: feature pairs that turn more than beta_fast times over the original context keep their
+    frequency, those that turn fewer than beta_slow times are interpolated (divided by `factor`), the
+    pairs in between blend linearly (DeepseekScalingRotaryEmbedding._compute_inv_freq,
+    rotary_embedding.py:382-418, 685-711)."""
+    half = rotary_dim // 2
+    wavelength_base = base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim)
+
+    def pair_index_for(rotations):   # the (fractional) pair whose wave turns `rotations` times in the original context
+        return rotary_dim * math.log(original_max_position / (rotations * 2 * math.pi)) / (2 * math.log(base))
+
+    lo = max(math.floor(pair_index_for(beta_fast)), 0)
+    hi = min(math.ceil(pair_index_for(beta_slow)), rotary_dim - 1)
+    if lo == hi:
+        hi += 0.001
+    ramp = torch.clamp((torch.arange(half, dtype=torch.float) - lo) / (hi - lo), 0, 1)
+    keep = (1 - ramp) * extrapolation_factor
+    return (1.0 / (factor * wavelength_base)) * (1 - keep) + (1.0 / wavelength_base) * keep
+
+
 class RotaryEmbedding(CustomOp):
     def __init__(self, head_size: int, rotary_dim: int, max_position_embeddings: int, base: float,
                  is_neox_style: bool, dtype: torch.dtype,
@@ -54,8 +81,11 @@ class RotaryEmbedding(CustomOp):
         self.base = base
         self.is_neox_style = is_neox_style
         self.dtype = dtype
-        cache = build_cos_sin_cache(rotary_dim, max_position_embeddings, base, llama3_scaling)
+        cache = self._compute_cos_sin_cache(llama3_scaling)
         self.register_buffer("cos_sin_cache", cache.to(dtype), persistent=False)
+
+    def _compute_cos_sin_cache(self, llama3_scaling=None) -> torch.Tensor:
+        return build_cos_sin_cache(self.rotary_dim, self.max_position_embeddings, self.base, llama3_scaling)
 
     def forward_hip(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
                     offsets: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -83,6 +113,31 @@ class Llama3RotaryEmbedding(RotaryEmbedding):
                                              original_max_position_embeddings=orig_max_position))
 
 
+class DeepseekScalingRotaryEmbedding(RotaryEmbedding):
+    """YaRN-scaled table for DeepSeek-V2/V3 (rotary_embedding.py:641-765): interpolated inverse
+    frequencies, original_max_position * factor rows, cos / sin multiplied by
+    mscale(factor, mscale) / mscale(factor, mscale_all_dim) * attn_factor before the cast to the model
+    dtype.  The rotation itself is the ordinary one (the kernel reads whatever the table holds); the
+    attention module multiplies its softmax scale by mscale(factor, mscale_all_dim)^2."""
+
+    def __init__(self, head_size, rotary_dim, max_position_embeddings, base, is_neox_style, scaling_factor, dtype, *,
+                 extrapolation_factor: float = 1, attn_factor: float = 1, beta_fast: float = 32, beta_slow: float = 1,
+                 mscale: float = 1, mscale_all_dim: float = 0) -> None:
+        self.scaling_factor = scaling_factor
+        self.extrapolation_factor, self.attn_factor = extrapolation_factor, attn_factor
+        self.beta_fast, self.beta_slow = beta_fast, beta_slow
+        self.mscale = float(yarn_get_mscale(scaling_factor, float(mscale))
+                            / yarn_get_mscale(scaling_factor, float(mscale_all_dim)) * attn_factor)
+        super().__init__(head_size, rotary_dim, max_position_embeddings, base, is_neox_style, dtype)
+
+    def _compute_cos_sin_cache(self, llama3_scaling=None) -> torch.Tensor:
+        inv_freq = yarn_inverse_frequencies(self.rotary_dim, self.base, self.scaling_factor, self.max_position_embeddings,
+                                            self.beta_fast, self.beta_slow, self.extrapolation_factor)
+        t = torch.arange(self.max_position_embeddings * self.scaling_factor, dtype=torch.float32)
+        freqs = torch.einsum("i,j -> ij", t, inv_freq)
+        return torch.cat((freqs.cos() * self.mscale, freqs.sin() * self.mscale), dim=-1)
+
+
 _ROPE_DICT: Dict[Tuple, RotaryEmbedding] = {}
 
 
@@ -90,8 +145,8 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float,
              is_neox_style: bool = True, rope_scaling: Optional[Dict[str, Any]] = None,
              dtype: Optional[torch.dtype] = None, partial_rotary_factor: float = 1.0) -> RotaryEmbedding:
     """Same arguments and caching behaviour as the reference's get_rope
-    (rotary_embedding.py:1178-1395); scaling types beyond None / "default" / "llama3" belong to
-    model families outside this package."""
+    (rotary_embedding.py:1178-1395); scaling types beyond None / "default" / "llama3" /
+    "deepseek_yarn" belong to model families outside this package."""
     if dtype is None:
         dtype = torch.get_default_dtype()
     if partial_rotary_factor < 1.0:
@@ -115,6 +170,12 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float,
             head_size, rotary_dim, max_position, base, is_neox_style, dtype,
             rope_scaling["factor"], rope_scaling["low_freq_factor"],
             rope_scaling["high_freq_factor"], rope_scaling["original_max_position_embeddings"])
+    elif kind == "deepseek_yarn":
+        extra = {k: v for k, v in rope_scaling.items()
+                 if k in ("extrapolation_factor", "attn_factor", "beta_fast", "beta_slow", "mscale", "mscale_all_dim")}
+        rope = DeepseekScalingRotaryEmbedding(
+            head_size, rotary_dim, rope_scaling["original_max_position_embeddings"], base, is_neox_style,
+            rope_scaling["factor"], dtype, **extra)
     else:
         raise ValueError(f"RoPE scaling type {kind!r} is not supported by this backend")
     _ROPE_DICT[key] = rope

@@ -11,8 +11,10 @@ with the reference's two forward methods (python/sglang/srt/models/deepseek_v2.p
 
 dispatch_attn_forward_method (:969-1039) picks between them as the reference's Triton backend does:
 extend without prefix -> normal; decode and extend over a cached prefix -> absorb (the latter as one
-decode-style multi-query pass per new token over the rows cached so far: exact, O(new x cached) reads).  YaRN scaling of the rotary table and of the softmax scale is
-left to the caller (rope_scaling=None here); the rotation is the interleaved (GPT-J) layout.
+decode-style multi-query pass per new token over the rows cached so far: exact, O(new x cached) reads).
+With rope_scaling (DeepSeek's YaRN) the rotary table is the interpolated, magnitude-scaled one and the
+softmax scale is multiplied by mscale(factor, mscale_all_dim)^2 (:845-862); the rotation is the
+interleaved (GPT-J) layout.
 """
 from typing import Optional
 
@@ -22,13 +24,14 @@ from torch import nn
 from ..layers.layernorm import RMSNorm
 from ..layers.linear import ReplicatedLinear
 from ..layers.radix_attention import RadixAttention
-from ..layers.rotary_embedding import get_rope
+from ..layers.rotary_embedding import get_rope, yarn_get_mscale
 
 
 class DeepseekV2AttentionMLA(nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, qk_nope_head_dim: int, qk_rope_head_dim: int,
                  v_head_dim: int, q_lora_rank: Optional[int], kv_lora_rank: int, layer_id: int, dtype, device,
-                 rope_theta: float = 10000.0, max_position_embeddings: int = 8192, rms_norm_eps: float = 1e-6):
+                 rope_theta: float = 10000.0, max_position_embeddings: int = 8192, rms_norm_eps: float = 1e-6,
+                 rope_scaling: Optional[dict] = None):
         super().__init__()
         self.hidden_size = hidden_size
         self.num_local_heads = num_heads
@@ -49,8 +52,12 @@ class DeepseekV2AttentionMLA(nn.Module):
         self.kv_a_layernorm = RMSNorm(kv_lora_rank, eps=rms_norm_eps)
         self.kv_b_proj = ReplicatedLinear(kv_lora_rank, num_heads * (qk_nope_head_dim + v_head_dim), dtype, device)
         self.o_proj = ReplicatedLinear(num_heads * v_head_dim, hidden_size, dtype, device)
+        if rope_scaling:
+            rope_scaling = dict(rope_scaling, rope_type="deepseek_yarn")
+            mscale = yarn_get_mscale(rope_scaling["factor"], float(rope_scaling.get("mscale_all_dim", False)))
+            self.scaling = self.scaling * mscale * mscale
         self.rotary_emb = get_rope(qk_rope_head_dim, qk_rope_head_dim, max_position_embeddings, rope_theta,
-                                   is_neox_style=False, rope_scaling=None, dtype=dtype)
+                                   is_neox_style=False, rope_scaling=rope_scaling, dtype=dtype)
         # the two RadixAttention views of one layer (:866-886)
         self.attn_mqa = RadixAttention(num_heads, kv_lora_rank + qk_rope_head_dim, self.scaling, num_kv_heads=1,
                                        layer_id=layer_id, v_head_dim=kv_lora_rank)

@@ -111,3 +111,66 @@ E2E_PREFIX_CUT = 4   # second scenario: first cache prompt[:4], then extend with
 def e2e_prompts(preset_vocab, lens, seed=0):
     rng = np.random.RandomState(seed)
     return [rng.randint(0, preset_vocab, n).tolist() for n in lens]
+
+
+# ---- DeepSeek multi-head latent attention (compressed KV: 512-wide latent + 64 rope features) ----
+# decode over a latent cache [slots, 1, 576] whose value is the row's first 512 features:
+# (B, Hq, max_len); the MLA shapes of the reference's kernel tests (test/srt/cpu/test_decode.py:62-163,
+# test/srt/test_triton_attention_kernels.py:293-388) plus the TP=8 head count of DeepSeek-V3
+MLA_DECODE_CASES = [(2, 16, 100), (3, 128, 257), (1, 22, 1024), (4, 16, 33)]
+MLA_RANK, MLA_ROPE = 512, 64
+
+
+def mla_decode_inputs(i, dt):
+    B, Hq, max_len = MLA_DECODE_CASES[i]
+    g = _g(1300 + i)
+    lens = torch.randint(max(1, max_len // 2), max_len + 1, (B,), generator=g)
+    lens[0] = max_len
+    kv_cache, _, r2t, pool = paged_inputs(1310 + 10 * i, dt, B, 1, MLA_RANK + MLA_ROPE, lens.tolist())
+    q = randn((B, Hq, MLA_RANK + MLA_ROPE), 1305 + i, dt)
+    return q, kv_cache, r2t, pool, lens.to(torch.int64)
+
+
+# the attention MODULE: (name, dtype, q_lora_rank, rope_scaling)
+YARN_V3 = dict(type="yarn", factor=40.0, original_max_position_embeddings=4096, beta_fast=32, beta_slow=1,
+               mscale=1.0, mscale_all_dim=1.0)              # DeepSeek-V3's published rope_scaling
+YARN_ALT = dict(type="yarn", factor=8.0, original_max_position_embeddings=512, beta_fast=32, beta_slow=1,
+                mscale=1.0, mscale_all_dim=0.5)             # cos/sin magnitude scale != 1
+MLA_MODULE_CASES = [("f32_plain", "f32", None, None), ("bf16_qlora", "bf16", 192, None),
+                    ("f32_qlora_yarn", "f32", 192, YARN_V3), ("bf16_yarn_alt", "bf16", None, YARN_ALT)]
+MLA_DIMS = dict(hidden=512, heads=16, nope=128, rope=64, v=128, kv_lora=512)
+MLA_THETA, MLA_EPS = 10000.0, 1e-6
+MLA_LENS, MLA_STEPS = (37, 5, 64), 3          # prompt lengths, decode steps
+MLA_CHUNK_FIRST, MLA_CHUNK_LENS = (20, 3, 48), (45, 30, 49)   # tokens in chunk 1, prompt lengths
+
+
+def mla_weights(q_lora_rank, seed=3):
+    """fp32 master weights of one attention module (rounded to the case dtype by the caller)."""
+    d = MLA_DIMS
+    hidden, H, nope, rope, vd, kr = d["hidden"], d["heads"], d["nope"], d["rope"], d["v"], d["kv_lora"]
+    g = _g(seed)
+
+    def r(*shape, scale):
+        return torch.randn(*shape, generator=g) * scale
+
+    w = {"kv_a_layernorm": 1 + 0.1 * r(kr, scale=1.0), "kv_b_proj": r(H * (nope + vd), kr, scale=kr ** -0.5),
+         "o_proj": r(hidden, H * vd, scale=(H * vd) ** -0.5)}
+    if q_lora_rank is not None:
+        w["fused_qkv_a_proj_with_mqa"] = r(q_lora_rank + kr + rope, hidden, scale=hidden ** -0.5)
+        w["q_a_layernorm"] = 1 + 0.1 * r(q_lora_rank, scale=1.0)
+        w["q_b_proj"] = r(H * (nope + rope), q_lora_rank, scale=q_lora_rank ** -0.5)
+    else:
+        w["q_proj"] = r(H * (nope + rope), hidden, scale=hidden ** -0.5)
+        w["kv_a_proj_with_mqa"] = r(kr + rope, hidden, scale=hidden ** -0.5)
+    return w
+
+
+def mla_hidden_states(lens, extra, seed, dt):
+    """Hidden states of every position of every sequence (prompt + `extra` decode positions)."""
+    g = _g(seed)
+    return [torch.randn(n + extra, MLA_DIMS["hidden"], generator=g).to(dt) for n in lens]
+
+
+def mla_slots(total, seed):
+    """A scrambled assignment of KV slots 1..total (slot 0 is the padding sink)."""
+    return torch.randperm(total, generator=_g(seed)) + 1

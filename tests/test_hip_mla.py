@@ -7,6 +7,8 @@ from types import SimpleNamespace
 import pytest
 import torch
 
+import cases as _CASES
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -150,3 +152,133 @@ def test_mla_module_chunked_prefill_over_cached_latent_rows():
     batch.prepare_for_decode()
     out, _ = run(batch, torch.stack([s[n] for s, n in zip(seqs, lens)]))
     assert (out - torch.stack([r[n] for r, n in zip(want, lens)])).abs().max().item() <= tol * scale
+
+
+# ---- against vectors produced by the reference's own module and kernels (tests/golden/mla.npz) --------
+@pytest.fixture(scope="module")
+def golden_mla():
+    import os
+
+    import numpy as np
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mla.npz"))
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16", "f16"])
+def test_mla_decode_kernel_matches_reference_vectors(golden_mla, dtn):
+    """mi355_decode_attention_mla on the latent-cache decode cases the reference's torch-native
+    backend was run on (16 / 22 / 128 heads, up to 1024 keys); within one output rounding."""
+    import cases
+    from sglang_custom_amd import ops
+
+    tol = {"f32": 2e-5, "bf16": 1.6e-2, "f16": 2e-3}[dtn]
+    R, P = cases.MLA_RANK, cases.MLA_ROPE
+    for i, (B, Hq, _) in enumerate(cases.MLA_DECODE_CASES):
+        q, kv, r2t, pool, lens = (x.to(DEV) for x in cases.mla_decode_inputs(i, cases.DTYPES[dtn]))
+        want = torch.from_numpy(golden_mla[f"mla_decode/{dtn}/{i}"])
+        for splits in (1, 4):
+            o = torch.empty((B, Hq, R), dtype=q.dtype, device=DEV)
+            al = torch.empty((B, Hq, splits, R), dtype=torch.float32, device=DEV)
+            ll = torch.empty((B, Hq, splits), dtype=torch.float32, device=DEV)
+            ops.decode_attention_mla(q, kv, o, r2t, pool, lens, al, ll, splits, R, (R + P) ** -0.5)
+            err = (o.float().cpu() - want).abs().max().item()
+            assert err <= tol, (i, splits, err)
+
+
+def _mla_world(dt, H, slots=1024):
+    from sglang_custom_amd.layers.attention.mi355_backend import Mi355AttnBackend
+    from sglang_custom_amd.mem_cache.allocator import TokenToKVPoolAllocator
+    from sglang_custom_amd.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+
+    kvpool = MLATokenToKVPool(slots, 1, dt, 512, 64, 1, DEV)
+    runner = SimpleNamespace(device=DEV, req_to_token_pool=ReqToTokenPool(8, 256, DEV), token_to_kv_pool=kvpool,
+                             model_config=SimpleNamespace(num_attention_heads=H, num_key_value_heads=1, vocab_size=32),
+                             tp_size=1, attn_backend=None)
+    runner.attn_backend = Mi355AttnBackend(runner)
+    return runner, kvpool, TokenToKVPoolAllocator(slots, dt, DEV, kvpool)
+
+
+@pytest.mark.parametrize("name,dtn,qr,scaling", _CASES.MLA_MODULE_CASES)
+def test_mla_module_matches_reference_vectors(golden_mla, name, dtn, qr, scaling):
+    """The attention module on the GPU against the outputs of the reference's DeepseekV2AttentionMLA on
+    the same weights and hidden states: prefill (multi-head form and absorbed form), the latent rows
+    written to the cache, three decode steps, and a two-chunk prefill; with and without q_lora, with
+    and without YaRN scaling (table magnitude and softmax scale)."""
+    import cases
+    from sglang_custom_amd.managers.schedule_batch import Req, ScheduleBatch
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardBatch
+    from sglang_custom_amd.models.deepseek_v2 import DeepseekV2AttentionMLA
+
+    dt, d = cases.DTYPES[dtn], cases.MLA_DIMS
+    g = lambda k: torch.from_numpy(golden_mla[f"mla_module/{name}/{k}"])   # noqa: E731
+    tol = 2e-4 if dtn == "f32" else 4e-2          # of the output range: fp32 accumulation order / bf16 rounding chains
+    H = d["heads"]
+    attn = DeepseekV2AttentionMLA(d["hidden"], H, d["nope"], d["rope"], d["v"], qr, d["kv_lora"], 0, dt, DEV,
+                                  rope_theta=cases.MLA_THETA, max_position_embeddings=4096, rms_norm_eps=cases.MLA_EPS,
+                                  rope_scaling=scaling)
+    with torch.no_grad():
+        for wname, val in cases.mla_weights(qr).items():
+            getattr(attn, wname).weight.data.copy_(val.to(dt).to(DEV))
+    attn.post_load_weights()
+    assert abs(attn.scaling - float(golden_mla[f"mla_module/{name}/softmax_scale"])) < 1e-12
+    assert torch.equal(attn.rotary_emb.cos_sin_cache[:128].float().cpu(), g("cos_sin_cache_head"))
+    scale = g("absorb_prefill").abs().max().item()
+
+    def close(out, key):
+        err = (out.float().cpu() - g(key)).abs().max().item()
+        assert err <= tol * scale, (key, err, scale)
+
+    def run(runner, batch, rows, method=None):
+        fb = ForwardBatch.init_new(batch.get_model_worker_batch(), runner)
+        runner.attn_backend.init_forward_metadata(fb)
+        with torch.no_grad():
+            return (method or attn)(fb.positions, rows.to(DEV), fb), fb
+
+    lens, steps = cases.MLA_LENS, cases.MLA_STEPS
+    seqs = cases.mla_hidden_states(lens, steps, 9, dt)
+    x0 = torch.cat([s[:n] for s, n in zip(seqs, lens)])
+    # prefill in the absorbed form (what the reference's backend ran), on its own pool
+    runner, kvpool, alloc = _mla_world(dt, H)
+    batch = ScheduleBatch.init_new([Req(i, [1] * n) for i, n in enumerate(lens)], runner.req_to_token_pool, alloc,
+                                   model_config=runner.model_config)
+    batch.prepare_for_extend()
+    out, fb = run(runner, batch, x0, attn.forward_absorb)
+    close(out, "absorb_prefill")
+    # prefill through the module's own dispatch (multi-head form), then decode steps
+    runner, kvpool, alloc = _mla_world(dt, H)
+    batch = ScheduleBatch.init_new([Req(i, [1] * n) for i, n in enumerate(lens)], runner.req_to_token_pool, alloc,
+                                   model_config=runner.model_config)
+    batch.prepare_for_extend()
+    out, fb = run(runner, batch, x0)
+    close(out, "normal_prefill")
+    rows_written = kvpool.get_key_buffer(0)[fb.out_cache_loc, 0].float().cpu()
+    lat = g("normal_latent_cache")
+    assert (rows_written - lat).abs().max().item() <= (1e-4 if dtn == "f32" else 3.2e-2) * lat.abs().max().item()
+    for step in range(steps):
+        batch.output_ids = torch.ones(len(lens), dtype=torch.int64, device=DEV)
+        batch.prepare_for_decode()
+        out, _ = run(runner, batch, torch.stack([s[n + step] for s, n in zip(seqs, lens)]))
+        close(out, f"decode_{step}")
+    # two chunks: the second extends over the cached latent rows
+    first, clens = cases.MLA_CHUNK_FIRST, cases.MLA_CHUNK_LENS
+    cseqs = cases.mla_hidden_states(clens, 1, 12, dt)
+    runner, kvpool, alloc = _mla_world(dt, H)
+    reqs = [Req(i, [1] * n) for i, n in enumerate(clens)]
+    for r, f in zip(reqs, first):
+        r.fill_ids = r.origin_input_ids[:f]
+        r.extend_input_len = f
+    batch = ScheduleBatch.init_new(reqs, runner.req_to_token_pool, alloc, model_config=runner.model_config)
+    batch.prepare_for_extend()
+    out, _ = run(runner, batch, torch.cat([s[:f] for s, f in zip(cseqs, first)]))
+    close(out, "chunk1")
+    table = runner.req_to_token_pool.req_to_token
+    for r, f in zip(reqs, first):
+        prefix = table[r.req_pool_idx, :f].clone()
+        runner.req_to_token_pool.free(r.req_pool_idx)
+        r.req_pool_idx = None
+        r.init_next_round_input(prefix)
+    batch = ScheduleBatch.init_new(reqs, runner.req_to_token_pool, alloc, model_config=runner.model_config)
+    batch.prepare_for_extend()
+    out, fb = run(runner, batch, torch.cat([s[f:n] for s, f, n in zip(cseqs, first, clens)]))
+    assert fb.extend_prefix_lens_cpu == list(first)
+    close(out, "chunk2")

@@ -147,3 +147,119 @@ def test_e2e_matches_reference(name, preset, dtn, lens, steps):
         logits, loc = m.extend(prompts, prefix_lens=[cut] * len(prompts))
         assert torch.equal(loc, t(g[f"e2e/{name}/prefix_extend_out_cache_loc"]))
         assert (logits - t(g[f"e2e/{name}/prefix_extend_logits"])).abs().max() <= tol
+
+
+# ---- DeepSeek multi-head latent attention: tests/golden/mla.npz (gen_mla_golden.py) ------------------
+@pytest.fixture(scope="module")
+def golden_mla():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mla.npz"))
+
+
+@pytest.mark.parametrize("dtn", list(DT))
+def test_mla_decode_kernel_matches_reference(golden_mla, dtn):
+    """Multi-query attention over a 576-wide latent cache whose value is the row's first 512 features:
+    the oracle's decode routine == the reference's torch-native routine bit for bit; the reference's
+    C++ kernel (MLA branch, decode.cpp:1197) is held to its own test's cosine bar."""
+    R, P = cases.MLA_RANK, cases.MLA_ROPE
+    for i, (B, Hq, _) in enumerate(cases.MLA_DECODE_CASES):
+        q, kv, r2t, pool, lens = cases.mla_decode_inputs(i, DT[dtn])
+        o = ops_ref.decode_attention(q, kv, kv[..., :R], r2t, pool, lens, (R + P) ** -0.5, True)
+        assert torch.equal(o.float(), t(golden_mla[f"mla_decode/{dtn}/{i}"]))
+        for b in range(B):
+            toks = r2t[pool[b], : lens[b]].long()
+            ref = ops_ref.attention_fp64(q[b][:, None], kv[toks].transpose(0, 1), kv[toks][..., :R].transpose(0, 1),
+                                         (R + P) ** -0.5)[:, 0]
+            assert (o[b].double() - ref).abs().max() < (1e-5 if dtn == "f32" else 2e-2)
+        if dtn == "bf16":
+            ck = t(golden_mla[f"mla_decode_cpu_kernel/{dtn}/{i}"])
+            assert torch.nn.functional.cosine_similarity(ck.flatten(), o.float().flatten(), dim=0) > 0.99
+
+
+@pytest.mark.parametrize("name,dtn,qr,scaling", cases.MLA_MODULE_CASES)
+def test_mla_module_matches_reference(golden_mla, name, dtn, qr, scaling):
+    """The module oracle replays the generator's scenario: absorbed prefill + decode steps, the
+    multi-head form of the same prefill, and a two-chunk prefill whose second chunk extends over the
+    cached latent rows.  Same torch build, same op sequence -> the reference's bits."""
+    from oracle import mla_ref
+
+    dt, d = DT[dtn], cases.MLA_DIMS
+    g = lambda k: t(golden_mla[f"mla_module/{name}/{k}"])   # noqa: E731
+    w = cases.mla_weights(qr)
+
+    def new():
+        return mla_ref.OracleMLA(w, dt, d["hidden"], d["heads"], d["nope"], d["rope"], d["v"], d["kv_lora"], qr,
+                                 cases.MLA_THETA, cases.MLA_EPS, scaling)
+
+    m = new()
+    assert abs(m.scaling - float(golden_mla[f"mla_module/{name}/softmax_scale"])) < 1e-15
+    assert torch.equal(m.cache[:128].float(), g("cos_sin_cache_head"))
+    lens, steps, rows = cases.MLA_LENS, cases.MLA_STEPS, torch.tensor([2, 0, 5])
+    seqs = cases.mla_hidden_states(lens, steps, 9, dt)
+    slots = cases.mla_slots(sum(lens) + steps * len(lens), 21)
+    per, p = [], 0
+    for n in lens:
+        per.append(slots[p: p + n])
+        p += n
+    zeros, lt = torch.zeros(3, dtype=torch.int64), torch.tensor(lens)
+    tol = 0.0 if dtn != "f32" else 1e-6     # fp32 GEMMs may block differently run to run; 16-bit outputs round it away
+
+    def close(a, key):
+        assert (a.float() - g(key)).abs().max().item() <= tol * max(1.0, g(key).abs().max().item()), key
+
+    with torch.no_grad():
+        for r, sl in zip(rows, per):
+            m.req_to_token[r, : len(sl)] = sl.int()
+        loc = torch.cat(per)
+        pos, _ = ops_ref.compute_position(zeros, lt)
+        x = torch.cat([s[:n] for s, n in zip(seqs, lens)])
+        close(m.absorb("extend", pos, x, rows, lt, zeros, lt, loc), "absorb_prefill")
+        close(m.kv[loc, 0], "latent_cache")
+        for step in range(steps):
+            new_slots = slots[p: p + len(lens)]
+            p += len(lens)
+            m.req_to_token[rows, lt + step] = new_slots.int()
+            x = torch.stack([s[n + step] for s, n in zip(seqs, lens)])
+            sl = lt + step + 1
+            close(m.absorb("decode", sl - 1, x, rows, sl, None, None, new_slots), f"decode_{step}")
+        # multi-head form of the same prefill
+        m = new()
+        for r, sl in zip(rows, per):
+            m.req_to_token[r, : len(sl)] = sl.int()
+        x = torch.cat([s[:n] for s, n in zip(seqs, lens)])
+        q, k, v = m.normal_prepare(pos, x, loc)
+        close(m.kv[loc, 0], "normal_latent_cache")
+        close(m.normal_core(q, k, v, rows, lt, zeros, lt, loc), "normal_prefill")
+        # two chunks
+        first, clens = torch.tensor(cases.MLA_CHUNK_FIRST), torch.tensor(cases.MLA_CHUNK_LENS)
+        cseqs = cases.mla_hidden_states(cases.MLA_CHUNK_LENS, 1, 12, dt)
+        m = new()
+        slots = cases.mla_slots(int(clens.sum()), 22)
+        per1, per2, p = [], [], 0
+        for f, n in zip(first.tolist(), clens.tolist()):
+            per1.append(slots[p: p + f])
+            per2.append(slots[p + f: p + n])
+            p += n
+        for r, a, b in zip(rows, per1, per2):
+            m.req_to_token[r, : len(a)] = a.int()
+            m.req_to_token[r, len(a): len(a) + len(b)] = b.int()
+        pos1, _ = ops_ref.compute_position(zeros, first)
+        x = torch.cat([s[:f] for s, f in zip(cseqs, first.tolist())])
+        close(m.absorb("extend", pos1, x, rows, first, zeros, first, torch.cat(per1)), "chunk1")
+        pos2, _ = ops_ref.compute_position(first, clens - first)
+        x = torch.cat([s[f:n] for s, f, n in zip(cseqs, first.tolist(), clens.tolist())])
+        close(m.absorb("extend", pos2, x, rows, clens, first, clens - first, torch.cat(per2)), "chunk2")
+
+    # the float64 functions (expanded and absorbed) agree with the reference's outputs to the dtype's noise
+    tol64 = 2e-5 if dtn == "f32" else 4e-2
+    wd = {k: v.to(dt) for k, v in w.items()}
+    for fn in (mla_ref.mla_attention, mla_ref.mla_attention_absorbed):
+        want = [fn(s, wd, d["heads"], d["nope"], d["rope"], d["v"], qr, d["kv_lora"], cases.MLA_THETA, cases.MLA_EPS, scaling)
+                for s in seqs]
+        ref = torch.cat([r[:n] for r, n in zip(want, lens)]).float()
+        for key in ("absorb_prefill", "normal_prefill"):
+            assert (ref - g(key)).abs().max().item() <= tol64 * g(key).abs().max().item(), (fn.__name__, key)
+        for step in range(steps):
+            ref = torch.stack([r[n + step] for r, n in zip(want, lens)]).float()
+            assert (ref - g(f"decode_{step}")).abs().max().item() <= tol64 * g("absorb_prefill").abs().max().item()
