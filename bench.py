@@ -1,4 +1,4 @@
-"""Headline benchmark: decode output tokens/s (+ TTFT) of Llama-3-8B bf16 TP=1, static batch of 64
+"""Headline benchmark: decode output tokens/s (+ TTFT) of Llama-3-8B bf16, static batch of 64
 requests, 1024-token prompts, on MI355X -- BASELINE.json configs[1] -- measured with the
 semantics of the reference's bench_one_batch.py (synthetic fixed-length prompts, greedy).
 
@@ -7,16 +7,21 @@ semantics of the reference's bench_one_batch.py (synthetic fixed-length prompts,
 
 One "step" = one decode forward of the whole batch (bs new tokens).  W untimed warm-up steps,
 then exactly K timed steps between barrier + synchronize; rank 0 prints ONE JSON line.
-N > 1 (default): N independent TP=1 replicas, one per GPU, no data-path collective ("weak"
-scaling: per-GPU work fixed); `--parallelism tp` shards one model over the N GPUs with RCCL
-all-reduce instead (strong scaling).
+N > 1: one process per GPU.  Started under torchrun the ranks are torchrun's; started as a plain
+`python bench.py --gpus N`, N fresh child processes are spawned BEFORE anything touches the GPU
+(as the reference starts one process per tensor-parallel rank, bench_one_batch.py:524-544), and the
+run fails if fewer than N ranks come up.  Default `--parallelism tp`: ONE model sharded over the N
+GPUs (heads / MLP columns / vocabulary, two sum-all-reduces per layer over RCCL, or the one-launch
+xGMI kernels with --custom-all-reduce), the global batch fixed ("strong" scaling); `--parallelism dp`
+runs N independent TP=1 replicas instead ("weak").  `n_gpus` in the line is the number of ranks that
+actually ran.
 
 The same line carries
-  roofline      -- the dominant kernel (weight-streaming skinny GEMM): algorithmic bytes per launch
-                   / its average duration measured here with HIP events on the launch stream,
-                   against the 8 TB/s HBM3E peak;
+  roofline      -- the dominant kernel (weight-streaming skinny GEMM) on rank 0's shard: algorithmic
+                   bytes per launch / its average duration measured here with HIP events on the
+                   launch stream, against the 8 TB/s HBM3E peak;
   cpu_baseline  -- the CPU restatement (oracle/) of the same decode step timed on this host's cores
-                   on a bounded sample (a few of the 32 layers + the LM head, scaled).
+                   on a bounded sample (a few of the layers + the LM head, scaled), N = 1 only.
 """
 import argparse
 import json
@@ -45,7 +50,7 @@ def parse_args():
     ap.add_argument("--quantization", default=None, choices=[None, "w8a8_fp8"])
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
                     help="fp8_e4m3: optional reduced-precision KV cache (NOT the headline configuration)")
-    ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--parallelism", default="tp", choices=["dp", "tp"])
     ap.add_argument("--custom-all-reduce", action="store_true",
                     help="with --parallelism tp: row-parallel sums and the logits gather through the "
                          "one-launch xGMI collectives instead of RCCL")
@@ -56,7 +61,42 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ttft-repeats", type=int, default=3)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous rehearsal without a GPU: every rank joins a gloo group, meets at the "
+                         "barriers and rank 0 prints the line's bookkeeping fields (value null)")
     return ap.parse_args()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh interpreters, one per GPU, with the
+    rendezvous variables torchrun would set.  This process never touches the GPU; it relays the
+    children's output and returns non-zero if any rank failed (the others are then stopped)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def weight_bytes_per_step(cfg, tp, dtype_bytes, quant):
@@ -198,13 +238,27 @@ def cpu_baseline(cfg, bs, ctx, dtype):
                        f"{threads} threads, scaled to {cfg['num_hidden_layers']} layers")
 
 
+def metric_name(args, tp, simulated):
+    if simulated:
+        return "per-GPU kernel time of one simulated TP shard (diagnostic)"
+    names = {"llama-3-8b": "Llama-3-8B", "llama-3-70b": "Llama-3-70B", "llama-3.2-1b": "Llama-3.2-1B"}
+    dt = {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype] + (" fp8-W8A8" if args.quantization else "")
+    return (f"decode output tok/s ({names.get(args.model, args.model)} {dt} TP={tp}, bs={args.batch_size}, "
+            f"{args.input_len}-in) + p50 TTFT")
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    assert world in (1, n_gpus), f"WORLD_SIZE={world} but --gpus {n_gpus}"
+    if world != args.gpus:
+        print(f"[bench] {world} rank(s) running (WORLD_SIZE) but --gpus {args.gpus}: refusing to mislabel the run",
+              file=sys.stderr)
+        sys.exit(2)
+    n_gpus = world
     import torch.distributed as dist
 
     from sglang_custom_amd import bench_one_batch as bob
@@ -213,6 +267,21 @@ def main():
     from sglang_custom_amd.model_loader.synthetic import hf_config_dict
     from sglang_custom_amd.server_args import ServerArgs
 
+    if args.dry_run:
+        dist.init_process_group("gloo", world_size=world, rank=rank)
+        dist.barrier()
+        alive = torch.ones(1)
+        dist.all_reduce(alive)
+        dist.barrier()
+        if rank == 0:
+            tp = world if args.parallelism == "tp" else 1
+            print(json.dumps({"metric": metric_name(args, tp, False), "value": None, "unit": "tok/s", "n_gpus": n_gpus,
+                              "ranks_alive": int(alive.item()), "steps": args.steps, "warmup": args.warmup,
+                              "scaling": "strong" if tp > 1 else "weak", "dry_run": True,
+                              "config": {"parallelism": f"tp{tp}" if tp > 1 else (f"dp{world}" if world > 1 else "tp1")}}),
+                  flush=True)
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     tp = world if (args.parallelism == "tp" and world > 1) else 1
     sim = args.simulate_tp if (args.simulate_tp > 1 and world == 1) else 0
@@ -291,8 +360,7 @@ def main():
     step_gbs = bytes_step / (ms_per_step * 1e-3) / 1e9
 
     out = {
-        "metric": ("per-GPU kernel time of one simulated TP shard (diagnostic)" if sim else
-                   "decode output tok/s (Llama-3-8B bf16 TP=1, bs=64, 1024-in) + p50 TTFT"),
+        "metric": metric_name(args, tp, bool(sim)),
         "value": round(value, 1), "unit": "tok/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None,
@@ -311,9 +379,18 @@ def main():
         "step_hbm_gbs": round(step_gbs, 1),
         "step_hbm_frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
     }
-    if rank == 0 and not args.no_roofline and args.quantization is None and tp == 1:
+    if tp > 1 and not sim:
+        # exchange steps of one decode step on every rank: 2 per layer (o_proj, down_proj) + the
+        # embedding, each a sum over ranks of a [bs, hidden] tensor; + the all-gather of the logits shards
+        n_ar = 2 * cfg["num_hidden_layers"] + 1
+        out["collectives"] = {"backend": "custom one-launch xGMI kernels" if args.custom_all_reduce else "rccl",
+                              "ranks": world, "all_reduces_per_step": n_ar,
+                              "all_reduce_message_bytes": bs * cfg["hidden_size"] * dtype_bytes,
+                              "all_gather_bytes_per_rank": bs * (cfg["vocab_size"] // tp) * dtype_bytes}
+    if rank == 0 and not args.no_roofline and args.quantization is None:
+        # rank 0's shard: the projection kernels launch no collective, so measuring on one rank is safe
         k = measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes)
-        traffic, traffic_src = committed_pmc_traffic(k["kernel"])
+        traffic, traffic_src = committed_pmc_traffic(k["kernel"]) if tp == 1 else (None, None)
         out["roofline"] = {"bound": "hbm", "achieved": round(k["achieved_gbs"], 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(k["achieved_gbs"] / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_source": traffic_src, "kernel": k["kernel"],

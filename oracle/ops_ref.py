@@ -135,6 +135,41 @@ def attention_fp64(q, k, v, scaling, causal_offset: Optional[int] = None, logit_
 
 
 # ---- layers/attention/utils.py:5-41, managers/schedule_batch.py:1287-1294,1571-1573 ----------
+def window_of(length: int, sliding_window_size: int):
+    """(start, count) of the cached tokens a sliding-window layer is shown: the last
+    min(length, window + 1) (update_sliding_window_buffer, layers/attention/triton_backend.py:927-955)."""
+    n = min(int(length), sliding_window_size + 1)
+    return int(length) - n, n
+
+
+def extend_attention_kernel_rules_fp64(q, k_prefix, v_prefix, k_ext, v_ext, scaling, causal=True,
+                                       logit_cap: float = 0.0, sliding_window_size: int = -1):
+    """The masking rules of the reference's extend kernel (triton_ops/extend_attention.py:41-303) for
+    ONE sequence in float64: q [E, Hq, D]; k_prefix / v_prefix [P, Hkv, *] are the cached keys as the
+    kernel is handed them (for a sliding-window layer: already cut to window_of(prefix)); k_ext / v_ext
+    [E, Hkv, *] the new tokens.  Phase 1 (prefix) keeps key k for query row i iff i <= k + window when a
+    window is set (:179-184; i counts new tokens, k counts the handed prefix keys); phase 2 (new
+    tokens) is causal and has no window term (:247-262).  logit_cap * tanh(s / logit_cap) on both.
+    Parity unpinned: the reference's kernel is Triton (no CPU execution) and its torch-native backend
+    ignores windows; this follows the kernel's source."""
+    E, Hq, _ = q.shape
+    P = k_prefix.shape[0]
+    g = Hq // k_ext.shape[1]
+    k = torch.cat([k_prefix, k_ext]).repeat_interleave(g, 1).double()      # [P + E, Hq, D]
+    v = torch.cat([v_prefix, v_ext]).repeat_interleave(g, 1).double()
+    s = torch.einsum("ehd,khd->hek", q.double(), k) * scaling
+    if logit_cap > 0:
+        s = logit_cap * torch.tanh(s / logit_cap)
+    keep = torch.ones(E, P + E, dtype=torch.bool)
+    i = torch.arange(E)[:, None]
+    if sliding_window_size > 0 and P:
+        keep[:, :P] = i <= torch.arange(P)[None, :] + sliding_window_size
+    if causal:
+        keep[:, P:] = i >= torch.arange(E)[None, :]
+    s = s.masked_fill(~keep[None], float("-inf"))
+    return torch.einsum("hek,khd->ehd", torch.softmax(s, -1), v)
+
+
 def create_kv_indices(req_to_token, req_pool_indices, lens, kv_start=None) -> torch.Tensor:
     parts = []
     for i in range(len(req_pool_indices)):

@@ -6,7 +6,12 @@ forward_decode :687-732) with two deliberate differences:
   * decode reads the req_to_token page table directly (as the reference's CPU kernel does,
     sgl-kernel/csrc/cpu/decode.cpp:913-916), so no kv_indices gather and no per-forward
     allocation or device->host read is needed: metadata is a split count chosen on the host;
-  * the per-forward scratch (split partials) lives in grow-only buffers owned by the backend.
+  * the per-forward scratch (split partials) lives in grow-only buffers owned by the backend
+    (outgrown buffers are kept alive: captured graphs hold their addresses).
+Sliding-window layers follow the reference's scheme (triton_backend.py:188-205, 302-310, 656-663,
+711-716, 927-973): the keys handed to the kernels are the LAST min(len, window + 1) cached tokens,
+gathered into window_kv_indptr / window_kv_indices (prefix tokens for an extend, all tokens for a
+decode); the extend kernel additionally masks the prefix phase with q_index <= k_index + window.
 Called once per layer; the backend owns the KV write when save_kv_cache is set.
 """
 import dataclasses
@@ -29,6 +34,9 @@ class ForwardMetadata:
     kv_indptr: Optional[torch.Tensor] = None
     kv_indices: Optional[torch.Tensor] = None
     max_extend_len: int = 0
+    window_kv_indptr: Optional[torch.Tensor] = None
+    window_kv_indices: Optional[torch.Tensor] = None
+    window_num_kv_splits: int = 1
 
 
 class Mi355AttnBackend(AttentionBackend):
@@ -40,20 +48,45 @@ class Mi355AttnBackend(AttentionBackend):
         tp = model_runner.tp_size
         self.num_head = cfg.num_attention_heads // tp
         self.num_kv_head = max(1, cfg.num_key_value_heads // tp)
-        self.v_head_dim = model_runner.token_to_kv_pool.v_head_dim
+        # value width as the pool stores it (an MLA pool's value is the first kv_lora_rank features of
+        # its rows); read from the buffer so that any pool with the reference's accessors works
+        self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
+        self.max_context_len = int(getattr(cfg, "context_len", 0) or self.req_to_token.shape[1])
+        sw = getattr(model_runner, "sliding_window_size", None)
+        self.sliding_window_size = sw if sw is not None and sw > 0 else None
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._logits = None
         self._lse = None
+        self._retired = []      # outgrown scratch: captured graphs may still point into it
         self._dummy_idx = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.graph_num_splits = {}
+        self.graph_window_indptr = None
+        self.graph_window_indices = None
 
     # ---- scratch ----
     def _scratch(self, bs: int, splits: int):
         need = bs * self.num_head * splits
         if self._lse is None or self._lse.numel() < need:
+            if self._lse is not None:
+                self._retired.append((self._logits, self._lse))
             self._logits = torch.empty(need * self.v_head_dim, dtype=torch.float32, device=self.device)
             self._lse = torch.empty(need, dtype=torch.float32, device=self.device)
         return self._logits, self._lse
+
+    def _window(self, lens: torch.Tensor, lens_cpu, req_pool_indices, bs: int, indptr=None, indices=None):
+        """The last min(len, window + 1) tokens of every request as (indptr, indices, longest)."""
+        w1 = self.sliding_window_size + 1
+        wl = torch.clamp(lens, max=w1)
+        if indptr is None:
+            indptr = torch.zeros(bs + 1, dtype=torch.int32, device=self.device)
+        indptr[1: bs + 1] = torch.cumsum(wl, dim=0)
+        if indices is None:
+            total = sum(min(int(n), w1) for n in lens_cpu) if lens_cpu is not None else int(indptr[bs].item())
+            indices = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
+        if bs > 0:
+            get_ops().create_kv_indices(self.req_to_token, req_pool_indices, wl, indptr[: bs + 1],
+                                        (lens - wl).to(torch.int32), indices)
+        return indptr[: bs + 1], indices
 
     def _plan_splits(self, bs: int, max_seq_len: int) -> int:
         return get_ops().decode_num_splits(bs, self.num_kv_head, max_seq_len, MAX_KV_SPLITS)
@@ -68,8 +101,14 @@ class Mi355AttnBackend(AttentionBackend):
             else:
                 max_len = max(1, forward_batch.seq_lens_sum // max(bs, 1))
             splits = self._plan_splits(bs, max_len)
-            logits, lse = self._scratch(bs, splits) if splits > 1 else (None, None)
-            self.forward_metadata = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse)
+            wsplits = self._plan_splits(bs, min(max_len, self.sliding_window_size + 1)) if self.sliding_window_size else 1
+            logits, lse = self._scratch(bs, max(splits, wsplits)) if max(splits, wsplits) > 1 else (None, None)
+            md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits)
+            if self.sliding_window_size:
+                cpu = forward_batch.seq_lens_cpu.tolist() if forward_batch.seq_lens_cpu is not None else None
+                md.window_kv_indptr, md.window_kv_indices = self._window(
+                    forward_batch.seq_lens, cpu, forward_batch.req_pool_indices, bs)
+            self.forward_metadata = md
             return
         # extend: prefix indices gathered once for all layers (triton_backend.py:283-320)
         dev = self.device
@@ -84,27 +123,41 @@ class Mi355AttnBackend(AttentionBackend):
                                   forward_batch.extend_prefix_lens, kv_indptr, None, kv_indices)
         else:
             kv_indices = self._dummy_idx
-        self.forward_metadata = ForwardMetadata(
-            qo_indptr=qo_indptr, kv_indptr=kv_indptr, kv_indices=kv_indices,
-            max_extend_len=max(forward_batch.extend_seq_lens_cpu))
+        md = ForwardMetadata(qo_indptr=qo_indptr, kv_indptr=kv_indptr, kv_indices=kv_indices,
+                             max_extend_len=max(forward_batch.extend_seq_lens_cpu))
+        if self.sliding_window_size:
+            md.window_kv_indptr, md.window_kv_indices = self._window(
+                forward_batch.extend_prefix_lens, forward_batch.extend_prefix_lens_cpu, forward_batch.req_pool_indices, bs)
+        self.forward_metadata = md
 
     # ---- HIP-graph capture / replay (static shapes; nothing to refresh per replay) ----
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
         self._scratch(max_bs, MAX_KV_SPLITS)
+        if self.sliding_window_size:
+            self.graph_window_indptr = torch.zeros(max_bs + 1, dtype=torch.int32, device=self.device)
+            self.graph_window_indices = torch.zeros(max_num_tokens * (self.sliding_window_size + 1), dtype=torch.int32,
+                                                    device=self.device)
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens,
-                                                 encoder_lens, forward_mode, spec_info,
-                                                 max_seq_len: int = 4096):
+                                                 encoder_lens, forward_mode, spec_info):
         assert forward_mode.is_decode_or_idle(), "only decode is captured"
-        splits = self._plan_splits(bs, max_seq_len)
+        # one graph serves every step: split for the longest context the model can reach
+        splits = self._plan_splits(bs, self.max_context_len)
         self.graph_num_splits[bs] = splits
-        logits, lse = self._scratch(bs, splits) if splits > 1 else (None, None)
-        self.forward_metadata = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse)
+        wsplits = self._plan_splits(bs, self.sliding_window_size + 1) if self.sliding_window_size else 1
+        logits, lse = self._scratch(bs, max(splits, wsplits)) if max(splits, wsplits) > 1 else (None, None)
+        md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits)
+        if self.sliding_window_size:
+            md.window_kv_indptr, md.window_kv_indices = self._window(
+                seq_lens[:bs], None, req_pool_indices[:bs], bs, self.graph_window_indptr, self.graph_window_indices)
+        self.forward_metadata = md
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum,
                                                 encoder_lens, forward_mode, spec_info, seq_lens_cpu):
-        # the captured kernels read req_to_token / seq_lens from the static buffers directly
-        return
+        # the captured kernels read req_to_token / seq_lens from the static buffers directly; only the
+        # window gather of sliding-window models is refreshed (into the buffers the graph captured)
+        if self.sliding_window_size:
+            self._window(seq_lens[:bs], None, req_pool_indices[:bs], bs, self.graph_window_indptr, self.graph_window_indices)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
@@ -128,6 +181,13 @@ class Mi355AttnBackend(AttentionBackend):
                 forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, pool.kv_lora_rank,
                 layer.scaling, layer.logit_cap)
             return o
+        if self._windowed(layer):
+            ops.decode_attention_fwd(
+                q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
+                o.view(-1, layer.tp_q_head_num, layer.v_head_dim), md.window_kv_indptr, md.window_kv_indices,
+                md.attn_logits, md.attn_lse, md.window_num_kv_splits, MAX_KV_SPLITS, layer.scaling, layer.logit_cap)
+            return o
         ops.decode_attention_paged(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
             pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
@@ -136,6 +196,17 @@ class Mi355AttnBackend(AttentionBackend):
             forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits,
             layer.scaling, layer.logit_cap)
         return o
+
+    def _windowed(self, layer) -> bool:
+        """triton_backend.py:656, 711: a layer with sliding_window_size > -1 attends the window lists."""
+        sw = layer.sliding_window_size
+        if sw is None or sw <= -1:
+            return False
+        if self.forward_metadata.window_kv_indptr is None or sw != self.sliding_window_size:
+            raise NotImplementedError(
+                f"layer {layer.layer_id} has sliding_window_size {sw} but the backend was built for "
+                f"model_runner.sliding_window_size = {self.sliding_window_size}")
+        return True
 
     def forward_decode_fused_qkv(self, qkv_part, positions, cos_sin_cache, layer, forward_batch,
                                  part_x_scale=None, part_w_scale=None, out_dtype=None):
@@ -188,12 +259,14 @@ class Mi355AttnBackend(AttentionBackend):
             return o
         if hasattr(pool, "kv_lora_rank") and sum(forward_batch.extend_prefix_lens_cpu) > 0:
             raise NotImplementedError("MLA multi-head prefill cannot read a cached prefix: use the absorbed form (attn_mqa)")
+        windowed = self._windowed(layer)
         ops.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k, v,
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             pool.get_key_buffer(layer.layer_id),
             # (an MLA pool has no separate value rows; without a prefix neither buffer is read)
             pool.get_key_buffer(layer.layer_id) if hasattr(pool, "kv_lora_rank") else pool.get_value_buffer(layer.layer_id),
-            md.qo_indptr, md.kv_indptr, md.kv_indices, None, True, None, md.max_extend_len,
-            layer.scaling, layer.logit_cap, sliding_window_size=layer.sliding_window_size)
+            md.qo_indptr, md.window_kv_indptr if windowed else md.kv_indptr,
+            md.window_kv_indices if windowed else md.kv_indices, None, True, None, md.max_extend_len,
+            layer.scaling, layer.logit_cap, sliding_window_size=layer.sliding_window_size if windowed else -1)
         return o

@@ -61,8 +61,7 @@ class HipGraphRunner:
             for bs in reversed(self.capture_bs):  # largest first: it sizes the shared pool
                 fb = self._static_batch(bs)
                 mr.attn_backend.init_forward_metadata_capture_cuda_graph(
-                    bs, bs, fb.req_pool_indices, fb.seq_lens, None, ForwardMode.DECODE, None,
-                    max_seq_len=mr.model_config.context_len)
+                    bs, bs, fb.req_pool_indices, fb.seq_lens, None, ForwardMode.DECODE, None)
                 run = lambda: mr.model.forward(fb.input_ids, fb.positions, fb).next_token_logits
                 for _ in range(2):  # warm-up: grow every workspace before capture
                     run()

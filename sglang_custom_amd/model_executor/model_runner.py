@@ -50,6 +50,8 @@ class ModelRunner:
         else:
             self.model.init_random_weights(seed=server_args.random_seed)
         self.sampler = Sampler()
+        # model_runner.py:287-290: the window of sliding-window models (None for Llama / DeepSeek)
+        self.sliding_window_size = getattr(self.model, "get_attention_sliding_window_size", lambda: None)()
         self.init_memory_pool()
         self.attn_backend = (attn_backend_cls or Mi355AttnBackend)(self)
         self.graph_runner = None

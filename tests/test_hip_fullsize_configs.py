@@ -1,0 +1,237 @@
+"""Full-size shapes of the configurations beyond the single-GPU headline, checked through the C ABI
+with size-independent properties and float64 samples computed on the GPU:
+
+  Llama-3-70B, one tensor-parallel rank of 8: projections N x K in {1280 x 8192 (qkv), 8192 x 1024 (o),
+      7168 x 8192 (gate_up with fused SiLU-mul), 8192 x 3584 (down)}; decode attention with 8 query
+      heads on ONE kv head, batch 16 / 64, context ~4224; the fused decode launch bit-identical to the
+      unfused sequence at that shape.
+  prefill at length: extend attention on 1 x 4096 and 4 x 1024 tokens with 32/8 and 8/1 heads, and a
+      4096-token prompt prefilled as 2048 + 2048 with the second chunk reading the first through
+      kv_indices (chunked prefill) -- sampled rows against float64, chunked == unchunked to one rounding.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D = 128
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_custom_amd import ops as _ops
+    from sglang_custom_amd import _lib
+
+    _lib.load()
+    return _ops
+
+
+def _w(n, k, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(n, k, device=DEV, generator=g) * 0.02).bfloat16()
+
+
+def _ordered_sum(part):
+    acc = torch.zeros_like(part[0])
+    for s in range(part.shape[0]):
+        acc = acc + part[s]
+    return acc
+
+
+# ---- Llama-3-70B / TP = 8: hidden 8192, 8 q heads + 1 kv head per rank, intermediate 28672 / 8 --------
+H70, HQ70, HKV70, INTER70 = 8192, 8, 1, 3584
+
+
+@pytest.mark.parametrize("bs", [16, 64])
+@pytest.mark.parametrize("n,k", [((HQ70 + 2 * HKV70) * D, H70), (H70, HQ70 * D), (H70, INTER70)])
+def test_70b_shard_projections(ops, n, k, bs):
+    w = _w(n, k, 11)
+    wp = ops.pack_weight(w)
+    x = torch.randn(bs, k, device=DEV).bfloat16()
+    y = ops.linear_packed(x, wp, n)
+    assert torch.equal(ops.linear_packed(x * 2, wp, n), y * 2)                # exact under power-of-two scaling
+    for rows in ([0], [bs - 1], list(range(min(bs, 7))), list(range(bs - 1, -1, -1))):
+        idx = torch.tensor(rows, device=DEV)
+        assert torch.equal(ops.linear_packed(x[idx].contiguous(), wp, n), y[idx]), rows
+    part = ops.linear_packed_partials(x, wp, n)
+    assert part is not None and part.shape[0] >= 1
+    assert torch.equal(_ordered_sum(part).bfloat16(), y)          # deferred split-K == in-kernel combine
+    cols = torch.randint(0, n, (64,), device=DEV)
+    ref = x.double() @ w[cols].double().t()
+    assert (y[:, cols].double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-3
+    # the row-major entry point (other K split, other summation order): same values to one rounding
+    yr = ops.linear(x, w)
+    assert (yr[:, cols].double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("bs", [16, 64])
+def test_70b_shard_gate_up_with_fused_activation(ops, bs):
+    w = _w(2 * INTER70, H70, 12)
+    x = torch.randn(bs, H70, device=DEV).bfloat16()
+    fused = ops.linear_packed_silu_mul(x, ops.pack_weight_gate_up(w), 2 * INTER70)
+    plain = ops.silu_and_mul(ops.linear_packed(x, ops.pack_weight(w), 2 * INTER70))
+    assert torch.equal(fused, plain)
+    g, u = (x.double() @ w.double().t()).split(INTER70, dim=-1)
+    ref = torch.nn.functional.silu(g) * u
+    assert (fused.double() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item() + 1e-3
+
+
+def _kv_setup(bs, ctx, hq, hkv, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    lens = torch.randint(ctx - 128, ctx + 1, (bs,), device=DEV, generator=g, dtype=torch.int64)
+    lens[0] = ctx
+    total = int(lens.sum())
+    kb = torch.randn(total + 1, hkv, D, device=DEV, generator=g).bfloat16()
+    vb = torch.randn(total + 1, hkv, D, device=DEV, generator=g).bfloat16()
+    perm = (torch.randperm(total, device=DEV, generator=g) + 1).int()
+    r2t = torch.zeros(bs, ctx + 4, dtype=torch.int32, device=DEV)
+    off = 0
+    for b in range(bs):
+        n = int(lens[b])
+        r2t[b, :n] = perm[off:off + n]
+        off += n
+    q = torch.randn(bs, hq, D, device=DEV, generator=g).bfloat16()
+    return q, kb, vb, r2t, lens
+
+
+def _attend(ops, q, kb, vb, r2t, lens, splits):
+    bs, hq = q.shape[0], q.shape[1]
+    o = torch.empty(bs, hq, D, device=DEV, dtype=q.dtype)
+    lg = torch.empty(bs, hq, splits, D, dtype=torch.float32, device=DEV)
+    ls = torch.empty(bs, hq, splits, dtype=torch.float32, device=DEV)
+    ops.decode_attention_paged(q, kb, vb, o, r2t, torch.arange(bs, device=DEV), lens, lg, ls, splits, D ** -0.5)
+    return o
+
+
+@pytest.mark.parametrize("bs", [16, 64])
+def test_70b_shard_decode_attention(ops, bs):
+    ctx = 4224
+    q, kb, vb, r2t, lens = _kv_setup(bs, ctx, HQ70, HKV70, 13)
+    planned = ops.decode_num_splits(bs, HKV70, ctx, 64)
+    assert planned > 1                                        # bs x 1 kv head cannot fill 256 CUs without splitting
+    o = _attend(ops, q, kb, vb, r2t, lens, planned)
+    o1 = _attend(ops, q, kb, vb, r2t, lens, 1)
+    assert (o.float() - o1.float()).abs().max().item() <= 2e-2
+    # slot permutation: same tokens in other cache rows, same bits
+    slots = kb.shape[0]
+    sigma = torch.cat([torch.zeros(1, device=DEV, dtype=torch.long), torch.randperm(slots - 1, device=DEV) + 1])
+    kb2, vb2 = torch.empty_like(kb), torch.empty_like(vb)
+    kb2[sigma], vb2[sigma] = kb, vb
+    r2t2 = sigma[r2t.long()].int()
+    r2t2[r2t == 0] = 0
+    assert torch.equal(_attend(ops, q, kb2, vb2, r2t2, lens, planned), o)
+    for b in (0, bs // 2, bs - 1):
+        n = int(lens[b])
+        idx = r2t[b, :n].long()
+        s = torch.einsum("gd,nd->gn", q[b].double(), kb[idx, 0].double()) * D ** -0.5
+        ref = s.softmax(-1) @ vb[idx, 0].double()
+        assert (o[b].double() - ref).abs().max().item() <= 1.6e-2
+        assert (o1[b].double() - ref).abs().max().item() <= 1.6e-2
+
+
+@pytest.mark.parametrize("bs", [16, 64])
+def test_70b_shard_fused_decode_launch_is_bit_identical(ops, bs):
+    ctx = 4224
+    _, kb0, vb0, r2t, lens = _kv_setup(bs, ctx, HQ70, HKV70, 14)
+    n = (HQ70 + 2 * HKV70) * D
+    w = _w(n, H70, 15)
+    wp = ops.pack_weight(w)
+    x = torch.randn(bs, H70, device=DEV).bfloat16()
+    positions = lens - 1
+    loc = torch.stack([r2t[b, int(lens[b]) - 1] for b in range(bs)]).to(torch.int64)
+    cache = torch.cat([torch.randn(ctx + 8, D // 2, device=DEV).cos(), torch.randn(ctx + 8, D // 2, device=DEV).sin()], 1).contiguous()
+    splits = ops.decode_num_splits(bs, HKV70, ctx, 64)
+    lg = torch.empty(bs, HQ70, splits, D, dtype=torch.float32, device=DEV)
+    ls = torch.empty(bs, HQ70, splits, dtype=torch.float32, device=DEV)
+    rpi = torch.arange(bs, device=DEV)
+    kb, vb = kb0.clone(), vb0.clone()
+    qkv = ops.linear_packed(x, wp, n)
+    q, k, v = qkv.split([HQ70 * D, HKV70 * D, HKV70 * D], dim=-1)
+    ops.rope_inplace(positions, q, k, D, cache, True, v=v, k_buffer=kb, v_buffer=vb, loc=loc)
+    o_ref = torch.empty(bs, HQ70, D, device=DEV, dtype=torch.bfloat16)
+    ops.decode_attention_paged(q.reshape(bs, HQ70 * D).contiguous().view(bs, HQ70, D), kb, vb, o_ref, r2t, rpi, lens, lg, ls,
+                               splits, D ** -0.5)
+    kb2, vb2 = kb0.clone(), vb0.clone()
+    o = torch.empty_like(o_ref)
+    part = ops.linear_packed_partials(x, wp, n)
+    ops.decode_attention_fused_qkv(part, positions, loc, cache, kb2, vb2, o, r2t, rpi, lens, lg, ls, splits, D ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(kb, kb2) and torch.equal(vb, vb2) and torch.equal(o, o_ref)
+
+
+# ---- prefill / chunked prefill at length -----------------------------------------------------------------
+def _extend(ops, q, k_new, v_new, kb, vb, qo, kvp, kvi, max_ext):
+    o = torch.empty_like(q)
+    ops.extend_attention_fwd(q, k_new, v_new, o, kb, vb, qo, kvp, kvi, None, True, None, max_ext, D ** -0.5)
+    return o
+
+
+def _ref_rows(q, K, V, rows, hq, hkv):
+    """float64 causal attention of query rows `rows` (absolute positions) of one sequence:
+    q [S, hq, D] (only `rows` are read), K / V [S, hkv, D]."""
+    g = hq // hkv
+    out = []
+    for p in rows:
+        s = torch.einsum("hgd,nhd->hgn", q[p].double().view(hkv, g, D), K[: p + 1].double()) * D ** -0.5
+        out.append(torch.einsum("hgn,nhd->hgd", s.softmax(-1), V[: p + 1].double()).reshape(hq, D))
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("hq,hkv", [(32, 8), (8, 1)])
+@pytest.mark.parametrize("lens", [(4096,), (1024, 1024, 1000, 1024)])
+def test_prefill_attention_at_length(ops, hq, hkv, lens):
+    g = torch.Generator(device=DEV).manual_seed(21)
+    T = sum(lens)
+    q = torch.randn(T, hq, D, device=DEV, generator=g).bfloat16()
+    k = torch.randn(T, hkv, D, device=DEV, generator=g).bfloat16()
+    v = torch.randn(T, hkv, D, device=DEV, generator=g).bfloat16()
+    qo = torch.zeros(len(lens) + 1, dtype=torch.int32, device=DEV)
+    qo[1:] = torch.cumsum(torch.tensor(lens, device=DEV), 0)
+    kvp = torch.zeros(len(lens) + 1, dtype=torch.int32, device=DEV)
+    dummy_cache = torch.zeros(2, hkv, D, device=DEV, dtype=torch.bfloat16)
+    o = _extend(ops, q, k, v, dummy_cache, dummy_cache, qo, kvp, torch.zeros(1, dtype=torch.int32, device=DEV), max(lens))
+    start = 0
+    for n in lens:
+        rows = [0, 1, 63, 64, 65, n // 2, n - 2, n - 1]
+        ref = _ref_rows(q[start: start + n], k[start: start + n], v[start: start + n], rows, hq, hkv)
+        got = o[start: start + n][rows].double()
+        assert (got - ref).abs().max().item() <= 1.6e-2, (hq, hkv, n)
+        start += n
+    # a sequence's rows do not depend on what else is in the batch
+    if len(lens) > 1:
+        n0 = lens[0]
+        qo1 = torch.tensor([0, n0], dtype=torch.int32, device=DEV)
+        o1 = _extend(ops, q[:n0].contiguous(), k[:n0].contiguous(), v[:n0].contiguous(), dummy_cache, dummy_cache, qo1,
+                     kvp[:2].contiguous(), torch.zeros(1, dtype=torch.int32, device=DEV), n0)
+        assert torch.equal(o1, o[:n0])
+
+
+@pytest.mark.parametrize("hq,hkv", [(32, 8), (8, 1)])
+def test_chunked_prefill_2048_plus_2048_equals_one_pass(ops, hq, hkv):
+    """A 4096-token prompt in two chunks: chunk 2's queries read chunk 1 from scrambled cache slots
+    through kv_indices (phase 1 of the kernel) and themselves from k_extend (phase 2)."""
+    g = torch.Generator(device=DEV).manual_seed(22)
+    S, C = 4096, 2048
+    q = torch.randn(S, hq, D, device=DEV, generator=g).bfloat16()
+    k = torch.randn(S, hkv, D, device=DEV, generator=g).bfloat16()
+    v = torch.randn(S, hkv, D, device=DEV, generator=g).bfloat16()
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+    dummy_cache = torch.zeros(2, hkv, D, device=DEV, dtype=torch.bfloat16)
+    whole = _extend(ops, q, k, v, dummy_cache, dummy_cache, torch.tensor([0, S], dtype=torch.int32, device=DEV),
+                    torch.zeros(2, dtype=torch.int32, device=DEV), zero, S)
+    # chunk 1 into the cache at scrambled slots
+    slots = (torch.randperm(C + 100, device=DEV, generator=g)[:C] + 1)
+    kb = torch.randn(C + 101, hkv, D, device=DEV, generator=g).bfloat16()
+    vb = torch.randn(C + 101, hkv, D, device=DEV, generator=g).bfloat16()
+    kb[slots], vb[slots] = k[:C], v[:C]
+    first = _extend(ops, q[:C].contiguous(), k[:C].contiguous(), v[:C].contiguous(), dummy_cache, dummy_cache,
+                    torch.tensor([0, C], dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV), zero, C)
+    second = _extend(ops, q[C:].contiguous(), k[C:].contiguous(), v[C:].contiguous(), kb, vb,
+                     torch.tensor([0, S - C], dtype=torch.int32, device=DEV), torch.tensor([0, C], dtype=torch.int32, device=DEV),
+                     slots.int().contiguous(), S - C)
+    assert torch.equal(first, whole[:C])
+    # different tile order over the same keys: equal to one output rounding (bf16 ulp at |o| < 0.5 is 2^-9..2^-8)
+    assert (second.float() - whole[C:].float()).abs().max().item() <= 2 ** -7
+    rows = [C, C + 1, C + 63, C + 64, 3000, S - 1]
+    ref = _ref_rows(q, k, v, rows, hq, hkv)
+    assert (second[[r - C for r in rows]].double() - ref).abs().max().item() <= 1.6e-2

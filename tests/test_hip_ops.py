@@ -840,3 +840,105 @@ def test_fp8_kv_cache_write_decode_extend_and_fused(ops, dtn):
     torch.cuda.synchronize()
     assert torch.equal(ka.view(torch.uint8), kf.view(torch.uint8)) and torch.equal(va.view(torch.uint8), vf.view(torch.uint8))
     assert torch.equal(o, o_ref)
+
+
+def _extend_kernel_case(ops, dt, Hq, Hkv, D, pre, ext, window, cap, seed, tol):
+    """mi355_extend_attention with the prefix lists a sliding-window layer hands it, against the
+    float64 statement of the reference kernel's masking rules."""
+    seq = [a + b for a, b in zip(pre, ext)]
+    B = len(seq)
+    kc, vc, r2t, pool = cases.paged_inputs(seed, dt, B, Hkv, D, seq)
+    q = cases.randn((sum(ext), Hq, D), seed + 1, dt)
+    wins = [ops_ref.window_of(p_, window) if window > 0 else (0, p_) for p_ in pre]
+    kvp = torch.zeros(B + 1, dtype=torch.int32)
+    kvp[1:] = torch.cumsum(torch.tensor([n for _, n in wins]), 0)
+    kvi = torch.cat([r2t[pool[b], wins[b][0]: wins[b][0] + wins[b][1]] for b in range(B)] + [torch.zeros(1, dtype=torch.int32)])
+    kext = torch.cat([kc[r2t[pool[b], pre[b]: seq[b]].long()] for b in range(B)])
+    vext = torch.cat([vc[r2t[pool[b], pre[b]: seq[b]].long()] for b in range(B)])
+    qo = torch.zeros(B + 1, dtype=torch.int32)
+    qo[1:] = torch.cumsum(torch.tensor(ext), 0)
+    o = torch.empty((sum(ext), Hq, D), dtype=dt, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), kext.to(DEV), vext.to(DEV), o, kc.to(DEV), vc.to(DEV), qo.to(DEV), kvp.to(DEV),
+                             kvi.to(DEV), None, True, None, max(ext), D ** -0.5, logit_cap=cap,
+                             sliding_window_size=window)
+    p = 0
+    for b in range(B):
+        toks = r2t[pool[b], wins[b][0]: wins[b][0] + wins[b][1]].long()
+        ref = ops_ref.extend_attention_kernel_rules_fp64(q[p: p + ext[b]], kc[toks], vc[toks], kext[p: p + ext[b]],
+                                                         vext[p: p + ext[b]], D ** -0.5, True, cap, window)
+        assert maxdiff(o[p: p + ext[b]], ref) <= tol, (Hq, Hkv, D, window, cap, b)
+        p += ext[b]
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_extend_attention_sliding_window_and_logit_cap(ops, dtn):
+    """Sliding-window prefix lists + the in-kernel window mask, and the tanh logit cap, alone and
+    together; windows shorter and longer than the prefix and than the new-token count (the window
+    term can cut keys only when the new tokens outnumber window: row i loses prefix key k < i - window)."""
+    dt = DT[dtn]
+    for (Hq, Hkv, D), (pre, ext) in [((8, 2, 128), ([40, 0, 13, 300], [30, 70, 3, 129])), ((12, 4, 64), ([7, 90], [100, 1]))]:
+        for window, cap in [(16, 0.0), (64, 0.0), (-1, 30.0), (16, 50.0), (1000, 0.0)]:
+            _extend_kernel_case(ops, dt, Hq, Hkv, D, pre, ext, window, cap, 140, ATTN_TOL[dtn])
+
+
+def test_backend_sliding_window_layers_follow_the_reference_window_lists(ops):
+    """Mi355AttnBackend on a model with sliding_window_size: an extend over cached prefixes reads the
+    last min(prefix, window + 1) prefix tokens (plus the in-kernel window mask), a decode the last
+    min(len, window + 1) tokens -- layers without a window in the same model read everything."""
+    from types import SimpleNamespace
+
+    from sglang_custom_amd.layers.attention.mi355_backend import Mi355AttnBackend
+    from sglang_custom_amd.layers.radix_attention import RadixAttention
+    from sglang_custom_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+    dt, Hq, Hkv, D, W = torch.bfloat16, 8, 2, 128, 24
+    pre, ext = [50, 0, 9], [40, 33, 1]
+    seq = [a + b for a, b in zip(pre, ext)]
+    kc, vc, r2t, pool_rows = cases.paged_inputs(150, dt, 3, Hkv, D, [n + 1 for n in seq])   # + one decode token each
+    q = cases.randn((sum(ext), Hq, D), 151, dt)
+    kvpool = MHATokenToKVPool(kc.shape[0] - 1, 1, dt, Hkv, D, 1, DEV)
+    kvpool.get_key_buffer(0).copy_(kc.to(DEV))
+    kvpool.get_value_buffer(0).copy_(vc.to(DEV))
+    r2tp = ReqToTokenPool(r2t.shape[0], r2t.shape[1], DEV)
+    r2tp.req_to_token.copy_(r2t.to(DEV))
+    runner = SimpleNamespace(device=DEV, req_to_token_pool=r2tp, token_to_kv_pool=kvpool, tp_size=1, sliding_window_size=W,
+                             model_config=SimpleNamespace(num_attention_heads=Hq, num_key_value_heads=Hkv))
+    be = Mi355AttnBackend(runner)
+    win_layer = RadixAttention(Hq, D, D ** -0.5, Hkv, 0, sliding_window_size=W)
+    full_layer = RadixAttention(Hq, D, D ** -0.5, Hkv, 0)
+    kext = torch.cat([kc[r2t[pool_rows[b], pre[b]: seq[b]].long()] for b in range(3)])
+    vext = torch.cat([vc[r2t[pool_rows[b], pre[b]: seq[b]].long()] for b in range(3)])
+    loc = torch.cat([r2t[pool_rows[b], pre[b]: seq[b]].long() for b in range(3)])
+    fb = ForwardBatch(forward_mode=ForwardMode.EXTEND, batch_size=3, input_ids=torch.zeros(sum(ext), dtype=torch.int64, device=DEV),
+                      req_pool_indices=pool_rows.to(DEV), seq_lens=torch.tensor(seq, device=DEV), out_cache_loc=loc.to(DEV),
+                      seq_lens_sum=sum(seq), seq_lens_cpu=torch.tensor(seq), extend_seq_lens=torch.tensor(ext, dtype=torch.int32, device=DEV),
+                      extend_prefix_lens=torch.tensor(pre, dtype=torch.int32, device=DEV), extend_prefix_lens_cpu=pre,
+                      extend_seq_lens_cpu=ext, req_to_token_pool=r2tp, token_to_kv_pool=kvpool, attn_backend=be)
+    be.init_forward_metadata(fb)
+    for layer, window in ((win_layer, W), (full_layer, -1)):
+        o = be.forward_extend(q.to(DEV).view(sum(ext), -1), kext.to(DEV), vext.to(DEV), layer, fb).view(-1, Hq, D)
+        p = 0
+        for b in range(3):
+            s0, n = ops_ref.window_of(pre[b], W) if window > 0 else (0, pre[b])
+            toks = r2t[pool_rows[b], s0: s0 + n].long()
+            ref = ops_ref.extend_attention_kernel_rules_fp64(q[p: p + ext[b]], kc[toks], vc[toks], kext[p: p + ext[b]],
+                                                             vext[p: p + ext[b]], D ** -0.5, True, 0.0, window)
+            assert maxdiff(o[p: p + ext[b]], ref) <= ATTN_TOL["bf16"], (window, b)
+            p += ext[b]
+    # decode: one more token per request (its K/V row is already in the cache)
+    dseq = [n + 1 for n in seq]
+    qd = cases.randn((3, Hq, D), 152, dt)
+    dloc = torch.stack([r2t[pool_rows[b], seq[b]] for b in range(3)]).long()
+    fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=3, input_ids=torch.zeros(3, dtype=torch.int64, device=DEV),
+                      req_pool_indices=pool_rows.to(DEV), seq_lens=torch.tensor(dseq, device=DEV), out_cache_loc=dloc.to(DEV),
+                      seq_lens_sum=sum(dseq), seq_lens_cpu=torch.tensor(dseq), req_to_token_pool=r2tp, token_to_kv_pool=kvpool,
+                      attn_backend=be)
+    be.init_forward_metadata(fb)
+    for layer, window in ((win_layer, W), (full_layer, -1)):
+        o = be.forward_decode(qd.to(DEV).view(3, -1), kc[dloc].to(DEV), vc[dloc].to(DEV), layer, fb).view(3, Hq, D)
+        for b in range(3):
+            s0, n = ops_ref.window_of(dseq[b], W) if window > 0 else (0, dseq[b])
+            toks = r2t[pool_rows[b], s0: s0 + n].long()
+            ref = ops_ref.attention_fp64(qd[b][:, None], kc[toks].transpose(0, 1), vc[toks].transpose(0, 1), D ** -0.5)[:, 0]
+            assert maxdiff(o[b], ref) <= ATTN_TOL["bf16"], (window, b)

@@ -424,3 +424,23 @@ def test_mla_oracle_rotation_is_the_pinned_interleaved_rope():
     table[pos] = cache64
     q, _ = ops_ref.apply_rope(pos, x.reshape(T, H * R), x[:, :1].reshape(T, R), R, table, False)
     assert (q.view(T, H, R) - mla_ref._rope_gptj(x, pos, theta)).abs().max().item() < 1e-12
+
+
+def test_bench_spawns_one_live_rank_per_gpu_and_refuses_to_mislabel():
+    """`python bench.py --gpus N` without a launcher starts N fresh rank processes (rendezvous
+    rehearsed over gloo, no GPU); a rank count that differs from --gpus is an error, never a line
+    that claims N GPUs."""
+    import json
+    import subprocess
+    import sys
+
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_alive"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["parallelism"] == "tp2" and "TP=2" in line["metric"]
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing to mislabel" in r.stderr and "{" not in r.stdout
