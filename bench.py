@@ -347,6 +347,9 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    from sglang_custom_amd.distributed.parallel_state import check_collectives
+
+    check_collectives()     # a custom collective that lost a peer filled its output with NaN: the run is void
     ms_per_step = elapsed * 1e3 / args.steps
     replicas = world if tp == 1 else 1
     value = bs * replicas * args.steps / elapsed

@@ -411,8 +411,11 @@ int mi355_fp8_scaled_mm_packed(void* y, const uint8_t* xq, const uint8_t* wq_pac
  * regions): the input is copied into the rank's region, same-numbered workgroups of all ranks meet
  * at a flag barrier, partial tensors are pulled over xGMI and summed in fp32 in rank order 0..n-1
  * with one rounding, so every rank gets the same bits and both algorithms give the same bits.
- * `in == out` is allowed.  A barrier wait gives up after one second and is counted; mi355_ar_status
- * reports it.  Calls of one communicator must be issued in the same order, with the same count,
+ * `in == out` is allowed.  A barrier wait gives up after the communicator's timeout (20 s unless
+ * mi355_ar_set_timeout_ms changed it; the value in force at launch -- or at capture -- applies): the
+ * wait is counted, the call's output is filled with NaN (a sum over data that never arrived must not
+ * look like a number) and mi355_ar_status reports it; the reference's kernels wait for ever
+ * instead (custom_all_reduce_hip.cuh:155-248).  Calls of one communicator must be issued in the same order, with the same count,
  * dtype and algo, on every rank, and must not overlap each other.
  * replaces: init_custom_ar / all_reduce_reg / all_reduce_unreg / dispose / meta_size /
  *           allocate_meta_buffer / get_meta_buffer_ipc_handle (sgl-kernel/csrc/allreduce/
@@ -429,6 +432,7 @@ int mi355_ar_close_ipc_handle(void* region);
 /* regions[r]: rank r's region as mapped in this process; world in {2, 4, 6, 8} */
 int mi355_ar_init(void** comm, void* const* regions, int rank, int world, int64_t max_bytes);
 int mi355_ar_dispose(void* comm);
+int mi355_ar_set_timeout_ms(void* comm, int64_t ms);        /* 1 .. 3 600 000; applies to later launches / captures */
 /* 1 = one-shot, 2 = two-shot (reduce-scatter + all-gather) for `bytes` on `world` ranks */
 int mi355_ar_choose_algo(int world, int64_t bytes);
 /* count * element size: a multiple of 16, at most max_bytes; algo 0 = mi355_ar_choose_algo */
@@ -448,6 +452,10 @@ int mi355_ar_fused_add_rmsnorm(void* comm, void* x, void* residual, const void* 
                                int64_t hidden, float eps, int dtype, void* stream);
 /* waits for `stream`, then MI355_OK, or MI355_ERR_LAUNCH if any barrier wait has timed out so far */
 int mi355_ar_status(void* comm, void* stream);
+/* the same answer WITHOUT waiting for any work stream (the counter is read over a private
+ * non-blocking stream): for a caller that has already waited for the step it asks about and has
+ * the next one in flight (overlap scheduling). */
+int mi355_ar_poll_status(void* comm);
 
 #ifdef __cplusplus
 }

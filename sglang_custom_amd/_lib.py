@@ -67,6 +67,8 @@ _SIGNATURES = {
     "mi355_ar_close_ipc_handle": (I, [P]),
     "mi355_ar_init": (I, [P, P, I, I, L]),
     "mi355_ar_dispose": (I, [P]),
+    "mi355_ar_set_timeout_ms": (I, [P, L]),
+    "mi355_ar_poll_status": (I, [P]),
     "mi355_ar_choose_algo": (I, [I, L]),
     "mi355_ar_all_reduce": (I, [P, P, P, L, I, I, P]),
     "mi355_ar_all_gather": (I, [P, P, P, L, P]),

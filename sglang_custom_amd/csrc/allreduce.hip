@@ -40,7 +40,8 @@ namespace mi355 {
 constexpr int AR_MAX_RANKS = 8;
 constexpr int AR_MAX_BLOCKS = 64;
 constexpr int AR_THREADS = 512;
-constexpr long long AR_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz constant clock
+constexpr long long AR_TICKS_PER_MS = 100000LL;       // the constant clock runs at 100 MHz
+constexpr long long AR_DEFAULT_TIMEOUT_MS = 20000LL;  // far above any rank skew a healthy job shows
 
 struct ArSignal {
   // sig[b][r]: written by rank r's workgroup b, read by the owner's workgroup b
@@ -59,6 +60,8 @@ struct ArComm {
   int64_t max_bytes;
   ArPeers peers;
   uint32_t* status;           // device word: number of waits that timed out
+  long long timeout_ticks;    // how long a barrier wait may last before the call gives up
+  hipStream_t poll_stream;    // non-blocking stream for reading `status` beside running work
 };
 
 __device__ __forceinline__ ArSignal* ar_signal(char* base) { return reinterpret_cast<ArSignal*>(base); }
@@ -69,15 +72,19 @@ __device__ __forceinline__ char* ar_scatter(char* base, int64_t max_bytes) { ret
 // visible to the peers' workgroups after it, and the other way round.
 // `epoch` is the workgroup's barrier count, loaded once per launch and stored back at its end.
 template <int NR>
-__device__ __forceinline__ void ar_barrier(const ArPeers& p, int rank, uint32_t& epoch, uint32_t* status) {
+__device__ __forceinline__ bool ar_barrier(const ArPeers& p, int rank, uint32_t& epoch, uint32_t* status,
+                                           long long timeout_ticks) {
   // Every wave completes its own stores and meets the others; the first wave then publishes them
   // for the whole workgroup with ONE system-scope release (a write-back of the cache level that
   // other devices do not see) instead of one per wave, and takes ONE system-scope acquire after
   // the last flag has arrived instead of one per poll.
+  // Returns false (to every thread of the workgroup) when a peer did not arrive in time: the wait
+  // is counted in *status and the caller must not publish what it computes from peer data.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   ArSignal* self = ar_signal(p.base[rank]);
   const uint32_t want = ++epoch;
+  int late = 0;
   if (threadIdx.x < NR) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __scoped_atomic_store_n(&ar_signal(p.base[threadIdx.x])->sig[blockIdx.x][rank], want, __ATOMIC_RELAXED,
@@ -85,16 +92,18 @@ __device__ __forceinline__ void ar_barrier(const ArPeers& p, int rank, uint32_t&
     const long long t0 = wall_clock64();
     while ((int32_t)(__scoped_atomic_load_n(&self->sig[blockIdx.x][threadIdx.x], __ATOMIC_RELAXED,
                                             __MEMORY_SCOPE_SYSTEM) - want) < 0) {
-      if (wall_clock64() - t0 > AR_TIMEOUT_TICKS) {
+      if (wall_clock64() - t0 > timeout_ticks) {
         atomicAdd(status, 1u);
+        late = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
-  __syncthreads();
+  late = __syncthreads_or(late);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return late == 0;
 }
 
 __device__ __forceinline__ uint32_t ar_load_epoch(const ArPeers& p, int rank) {
@@ -107,6 +116,10 @@ __device__ __forceinline__ void ar_store_epoch(const ArPeers& p, int rank, uint3
 // 16 bytes: 8 16-bit values or 4 floats.  A plain aggregate (not HIP's uint4 class): arrays of it
 // are split into registers by the compiler at every rank count.
 struct alignas(16) ArVec { uint32_t x, y, z, w; };
+
+// What a call leaves in its output when a barrier timed out: every 16-bit lane 0x7fc0, which reads
+// as NaN in bf16, f16 and (pairwise) f32 -- a wrong sum must never look like a number.
+__device__ __forceinline__ ArVec ar_poison() { return ArVec{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u}; }
 
 template <typename T> struct ArAcc {
   static constexpr int N = 16 / sizeof(T);
@@ -144,19 +157,20 @@ __device__ __forceinline__ ArVec ar_reduce(const ArVec* const* src, int64_t idx)
 
 template <typename T, int NR>
 __global__ __launch_bounds__(AR_THREADS) void ar_one_shot_kernel(ArPeers p, const ArVec* in, ArVec* out,
-                                                                 int64_t nvec, int rank, uint32_t* status) {
+                                                                 int64_t nvec, int rank, uint32_t* status,
+                                                                 long long timeout) {
   const int64_t tid = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
   ArVec* mine = reinterpret_cast<ArVec*>(ar_staging(p.base[rank]));
   uint32_t epoch = ar_load_epoch(p, rank);
   for (int64_t i = tid; i < nvec; i += stride) mine[i] = in[i];
-  ar_barrier<NR>(p, rank, epoch, status);
+  bool ok = ar_barrier<NR>(p, rank, epoch, status, timeout);
   const ArVec* src[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]));
-  for (int64_t i = tid; i < nvec; i += stride) out[i] = ar_reduce<T, NR>(src, i);
+  for (int64_t i = tid; i < nvec; i += stride) out[i] = ok ? ar_reduce<T, NR>(src, i) : ar_poison();
   // nobody may overwrite its staging area (the next call) while a peer still reads it
-  ar_barrier<NR>(p, rank, epoch, status);
+  ar_barrier<NR>(p, rank, epoch, status, timeout);
   ar_store_epoch(p, rank, epoch);
 }
 
@@ -167,7 +181,7 @@ __device__ __forceinline__ void gather_slices(const ArVec* const* red, ArVec* __
 template <typename T, int NR>
 __global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArPeers p, const ArVec* in, ArVec* out,
                                                                  int64_t nvec, int rank, int64_t max_bytes,
-                                                                 uint32_t* status) {
+                                                                 uint32_t* status, long long timeout) {
   const int64_t tid = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
   const int64_t part = nvec / NR;                       // slice r = [r*part, (r+1)*part), the last one
@@ -181,19 +195,23 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArPeers p, cons
     const int64_t len = r == NR - 1 ? last : part;
     for (int64_t i = tid; i < len; i += stride) mine[r * part + i] = in[r * part + i];
   }
-  ar_barrier<NR>(p, rank, epoch, status);
+  bool ok = ar_barrier<NR>(p, rank, epoch, status, timeout);
   const ArVec* src[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r])) + rank * part;
   ArVec* reduced = reinterpret_cast<ArVec*>(ar_scatter(p.base[rank], max_bytes));
   const int64_t my_len = rank == NR - 1 ? last : part;
-  for (int64_t i = tid; i < my_len; i += stride) reduced[i] = ar_reduce<T, NR>(src, i);
-  ar_barrier<NR>(p, rank, epoch, status);
+  // a slice reduced from data that may not have arrived is published as NaN, so the peers that
+  // gather it see the failure too
+  for (int64_t i = tid; i < my_len; i += stride) reduced[i] = ok ? ar_reduce<T, NR>(src, i) : ar_poison();
+  ok = ar_barrier<NR>(p, rank, epoch, status, timeout) && ok;
   const ArVec* red[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) red[r] = reinterpret_cast<const ArVec*>(ar_scatter(p.base[r], max_bytes));
   gather_slices<NR>(red, out, tid, stride, part, last);
-  ar_barrier<NR>(p, rank, epoch, status);
+  if (!ok)
+    for (int64_t i = tid; i < nvec; i += stride) out[i] = ar_poison();
+  ar_barrier<NR>(p, rank, epoch, status, timeout);
   ar_store_epoch(p, rank, epoch);
 }
 
@@ -224,13 +242,13 @@ __device__ __forceinline__ void gather_slices(const ArVec* const* red, ArVec* __
 // the same copy-in / barrier / pull structure (no arithmetic, so no element type).
 template <int NR>
 __global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, const ArVec* __restrict__ in, ArVec* __restrict__ out, int64_t nvec,
-                                                                   int rank, uint32_t* status) {
+                                                                   int rank, uint32_t* status, long long timeout) {
   const int64_t tid = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * AR_THREADS;
   ArVec* mine = reinterpret_cast<ArVec*>(ar_staging(p.base[rank]));
   uint32_t epoch = ar_load_epoch(p, rank);
   for (int64_t i = tid; i < nvec; i += stride) mine[i] = in[i];
-  ar_barrier<NR>(p, rank, epoch, status);
+  const bool ok = ar_barrier<NR>(p, rank, epoch, status, timeout);
   const ArVec* src[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]));
@@ -248,7 +266,9 @@ __global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, co
 #pragma unroll
     for (int r = H; r < NR; ++r) out[r * nvec + i] = hi[r - H];
   }
-  ar_barrier<NR>(p, rank, epoch, status);
+  if (!ok)
+    for (int64_t i = tid; i < nvec * NR; i += stride) out[i] = ar_poison();
+  ar_barrier<NR>(p, rank, epoch, status, timeout);
   ar_store_epoch(p, rank, epoch);
 }
 
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, co
 template <typename T, int NR, int CHUNKS>
 __global__ __launch_bounds__(256) void ar_fused_add_rmsnorm_kernel(ArPeers p, T* x, T* residual, const T* __restrict__ w,
                                                                    int rows, int64_t hidden, float eps, int rank,
-                                                                   uint32_t* status) {
+                                                                   uint32_t* status, long long timeout) {
   constexpr int VE = 16 / sizeof(T);
   constexpr int BT = 256;
   __shared__ float red[16];
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(256) void ar_fused_add_rmsnorm_kernel(ArPeers p, T*
       if (vi < nvec) mine[(int64_t)row * nvec + vi] = xin[vi];
     }
   }
-  ar_barrier<NR>(p, rank, epoch, status);
+  const bool ok = ar_barrier<NR>(p, rank, epoch, status, timeout);
   const ArVec* src[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) src[r] = reinterpret_cast<const ArVec*>(ar_staging(p.base[r]));
@@ -331,7 +351,14 @@ __global__ __launch_bounds__(256) void ar_fused_add_rmsnorm_kernel(ArPeers p, T*
       }
     }
   }
-  ar_barrier<NR>(p, rank, epoch, status);
+  if (!ok) {   // a peer's partial sums never arrived: both outputs become NaN
+    for (int row = blockIdx.x; row < rows; row += gridDim.x)
+      for (int vi = threadIdx.x; vi < nvec; vi += BT) {
+        reinterpret_cast<ArVec*>(x + (int64_t)row * hidden)[vi] = ar_poison();
+        reinterpret_cast<ArVec*>(residual + (int64_t)row * hidden)[vi] = ar_poison();
+      }
+  }
+  ar_barrier<NR>(p, rank, epoch, status, timeout);
   ar_store_epoch(p, rank, epoch);
 }
 
@@ -339,10 +366,11 @@ template <typename T, int NR>
 static void ar_launch(const ArComm* c, void* out, const void* in, int64_t nvec, int algo, hipStream_t st) {
   const int grid = (int)std::min<int64_t>(AR_MAX_BLOCKS, std::max<int64_t>(1, (nvec + AR_THREADS - 1) / AR_THREADS));
   if (algo == 1)
-    ar_one_shot_kernel<T, NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank, c->status);
+    ar_one_shot_kernel<T, NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank, c->status,
+                                                          c->timeout_ticks);
   else
     ar_two_shot_kernel<T, NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank,
-                                                          c->max_bytes, c->status);
+                                                          c->max_bytes, c->status, c->timeout_ticks);
 }
 
 template <typename T>
@@ -364,7 +392,8 @@ static int ar_fused_norm_launch(const ArComm* c, T* x, T* residual, const T* w, 
   const int chunks = (nvec + 255) / 256;
   const int grid = std::min(AR_MAX_BLOCKS, rows);
 #define AR_NORM(C) \
-  ar_fused_add_rmsnorm_kernel<T, NR, C><<<grid, 256, 0, st>>>(c->peers, x, residual, w, rows, hidden, eps, c->rank, c->status)
+  ar_fused_add_rmsnorm_kernel<T, NR, C><<<grid, 256, 0, st>>>(c->peers, x, residual, w, rows, hidden, eps, c->rank, c->status, \
+                                                              c->timeout_ticks)
   if (chunks <= 1) AR_NORM(1);
   else if (chunks <= 2) AR_NORM(2);
   else if (chunks <= 4) AR_NORM(4);
@@ -457,6 +486,7 @@ int mi355_ar_init(void** comm, void* const* regions, int rank, int world, int64_
   c->rank = rank;
   c->world = world;
   c->max_bytes = max_bytes;
+  c->timeout_ticks = AR_DEFAULT_TIMEOUT_MS * AR_TICKS_PER_MS;
   for (int r = 0; r < AR_MAX_RANKS; ++r) c->peers.base[r] = nullptr;
   for (int r = 0; r < world; ++r) {
     if (!regions[r] || !aligned16(regions[r])) {
@@ -467,6 +497,7 @@ int mi355_ar_init(void** comm, void* const* regions, int rank, int world, int64_
     c->peers.base[r] = static_cast<char*>(regions[r]);
   }
   if (hipMalloc(&c->status, 256) != hipSuccess || hipMemset(c->status, 0, 256) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->poll_stream, hipStreamNonBlocking) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess) {
     delete c;
     set_error("mi355_ar_init: could not allocate the status word");
@@ -476,10 +507,18 @@ int mi355_ar_init(void** comm, void* const* regions, int rank, int world, int64_
   return MI355_OK;
 }
 
+int mi355_ar_set_timeout_ms(void* comm, int64_t ms) {
+  MI355_REQUIRE(comm && ms > 0 && ms <= 3600000, MI355_ERR_INVALID, "mi355_ar_set_timeout_ms: null communicator or %lld ms outside 1..3600000",
+                (long long)ms);
+  static_cast<ArComm*>(comm)->timeout_ticks = ms * AR_TICKS_PER_MS;
+  return MI355_OK;
+}
+
 int mi355_ar_dispose(void* comm) {
   if (!comm) return MI355_OK;
   ArComm* c = static_cast<ArComm*>(comm);
   (void)hipFree(c->status);
+  (void)hipStreamDestroy(c->poll_stream);
   delete c;
   return MI355_OK;
 }
@@ -527,7 +566,7 @@ int mi355_ar_all_gather(void* comm, void* out, const void* in, int64_t bytes, vo
   const int grid = (int)std::min<int64_t>(AR_MAX_BLOCKS, (nvec + AR_THREADS - 1) / AR_THREADS);
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define AR_GATHER(NR) \
-  case NR: ar_all_gather_kernel<NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank, c->status); break
+  case NR: ar_all_gather_kernel<NR><<<grid, AR_THREADS, 0, st>>>(c->peers, (const ArVec*)in, (ArVec*)out, nvec, c->rank, c->status, c->timeout_ticks); break
   switch (c->world) {
     AR_GATHER(2);
     AR_GATHER(4);
@@ -560,6 +599,19 @@ int mi355_ar_fused_add_rmsnorm(void* comm, void* x, void* residual, const void* 
                        rc = ar_fused_norm_world<T>(c, x, residual, weight, (int)rows, hidden, eps, st));
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("mi355_ar_fused_add_rmsnorm");
+  return MI355_OK;
+}
+
+int mi355_ar_poll_status(void* comm) {
+  MI355_REQUIRE(comm, MI355_ERR_INVALID, "mi355_ar_poll_status: null communicator");
+  const ArComm* c = static_cast<const ArComm*>(comm);
+  uint32_t n = 0;
+  AR_HIP(hipMemcpyAsync(&n, c->status, sizeof(n), hipMemcpyDeviceToHost, c->poll_stream), "mi355_ar_poll_status");
+  AR_HIP(hipStreamSynchronize(c->poll_stream), "mi355_ar_poll_status");
+  if (n) {
+    set_error("mi355_ar_poll_status: %u barrier waits timed out (a peer did not arrive)", n);
+    return MI355_ERR_LAUNCH;
+  }
   return MI355_OK;
 }
 

@@ -156,10 +156,20 @@ class CustomAllreduce:
                                                         x.shape[0], x.shape[1], float(eps), _DT[x.dtype], stream),
                    "mi355_ar_fused_add_rmsnorm")
 
-    def check_status(self) -> None:
-        """Synchronises the current stream; raises if any barrier wait has timed out."""
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._lib.mi355_ar_status(self._comm, stream), "mi355_ar_status")
+    def set_timeout_ms(self, ms: int) -> None:
+        """How long a barrier may wait for a peer before the call gives up (fills its output with NaN
+        and makes check_status raise); applies to launches and graph captures made afterwards."""
+        _lib.check(self._lib.mi355_ar_set_timeout_ms(self._comm, int(ms)), "mi355_ar_set_timeout_ms")
+
+    def check_status(self, wait: bool = True) -> None:
+        """Raises if any barrier wait has timed out.  wait=True synchronises the current stream first;
+        wait=False reads the counter beside whatever is running (the caller has already waited for the
+        work it asks about)."""
+        if wait:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.mi355_ar_status(self._comm, stream), "mi355_ar_status")
+        else:
+            _lib.check(self._lib.mi355_ar_poll_status(self._comm), "mi355_ar_poll_status")
 
     def close(self) -> None:
         if self._comm:

@@ -46,6 +46,17 @@ def get_custom_all_reduce():
     return _CA_COMM
 
 
+def check_collectives(wait: bool = True) -> None:
+    """Raise if any custom collective issued so far gave up waiting for a peer (its output was then
+    filled with NaN).  Costs a stream synchronisation plus a 4-byte read-back, so the callers are the
+    places that synchronise anyway: the per-step token read-back of the scheduler, the end of graph
+    capture, the end of a benchmark's timed region.  wait=False skips the synchronisation (overlap
+    scheduling: the step in question has been waited for, the next one is already running).  No-op
+    without the custom collectives."""
+    if _CA_COMM is not None and not _CA_COMM.disabled:
+        _CA_COMM.check_status(wait)
+
+
 _SIMULATED = False
 
 

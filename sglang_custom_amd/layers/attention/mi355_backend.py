@@ -243,7 +243,7 @@ class Mi355AttnBackend(AttentionBackend):
         if save_kv_cache:
             pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
         md = self.forward_metadata
-        if hasattr(pool, "kv_lora_rank") and layer.qk_head_dim == pool.head_dim:
+        if hasattr(pool, "kv_lora_rank") and layer.qk_head_dim == pool.kv_lora_rank + pool.qk_rope_head_dim:
             # MLA in the absorbed form (attn_mqa) over a cached prefix: the new latent rows are in
             # the cache by now (written above), so token t of a request is a decode query over the
             # request's first position(t) + 1 rows -- the multi-query kernel of the decode path

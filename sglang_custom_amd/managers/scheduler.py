@@ -25,6 +25,7 @@ from typing import Dict, List, Optional
 
 import torch
 
+from ..distributed.parallel_state import check_collectives
 from ..mem_cache.radix_cache import RadixCache
 from ..model_executor.forward_batch_info import ForwardBatch
 from .schedule_batch import Req, ScheduleBatch
@@ -292,6 +293,7 @@ class Scheduler:
 
     def process_batch_result(self, batch: ScheduleBatch, next_token_ids: torch.Tensor) -> None:
         ids = next_token_ids.tolist()
+        check_collectives()    # the read-back has synchronised: a collective that lost a peer fails the step here
         if batch.forward_mode.is_extend():
             self.num_prefill_batches += 1
             keep = []
@@ -392,6 +394,7 @@ class Scheduler:
     def _collect(self, launched) -> None:
         if launched["done"] is not None:
             launched["done"].synchronize()
+        check_collectives(wait=False)   # this step is complete; the next one is in flight and is not waited for
         for req, tok in zip(launched["reqs"], launched["ids"].tolist()):
             if req is launched["mid_prompt"] or req.finished:
                 continue                        # mid-prompt sample, or a step past the request's end

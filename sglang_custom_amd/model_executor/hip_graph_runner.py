@@ -74,6 +74,11 @@ class HipGraphRunner:
                 self.outputs[bs] = out
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
+        # ranks capture at different speeds: a collective of the warm-up runs that gave up waiting
+        # for a slow peer must fail here, not as wrong tokens later
+        from ..distributed.parallel_state import check_collectives
+
+        check_collectives()
 
     def replay(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
         raw_bs = forward_batch.batch_size

@@ -105,6 +105,10 @@ E2E_CASES = [
     ("tiny128_f32", "tiny-llama-d128", "f32", (3, 40), 8),
     ("tiny128_bf16", "tiny-llama-d128", "bf16", (3, 40), 8),
 ]
+# configuration 1 at its real shape: Llama-3.2-1B (16 layers, vocab 128256, tied head, llama3 rope
+# scaling), one request, 128-token prompt, 128 greedy tokens.  The fixture keeps the tokens, the
+# prefill and last-step logits and the five largest logits of every step (not all 128 x 128256).
+E2E_LONG_CASES = [("llama1b_bf16", "llama-3.2-1b", "bf16", (128,), 128), ("llama1b_f32", "llama-3.2-1b", "f32", (128,), 128)]
 E2E_PREFIX_CUT = 4   # second scenario: first cache prompt[:4], then extend with the rest
 
 

@@ -121,7 +121,7 @@ def gen_fp8(out):
         print("fp8 fallback scaled mm not runnable on CPU here:", repr(e))
 
 
-def load_reference_runner(preset, dtype_name):
+def load_reference_runner(preset, dtype_name, context_length=None):
     from safetensors.torch import save_file
     from sglang.srt.configs.model_config import ModelConfig
     from sglang.srt.model_executor.model_runner import ModelRunner
@@ -138,7 +138,7 @@ def load_reference_runner(preset, dtype_name):
     sa = ServerArgs(model_path=d, load_format="auto", device="cpu", attention_backend="torch_native",
                     sampling_backend="pytorch", disable_cuda_graph=True, skip_tokenizer_init=True,
                     dtype=tname, max_total_tokens=2048, disable_radix_cache=True,
-                    chunked_prefill_size=-1, mem_fraction_static=0.5)
+                    chunked_prefill_size=-1, mem_fraction_static=0.5, context_length=context_length)
     pa = PortArgs.init_new(sa)
     mc = ModelConfig.from_server_args(sa)
     # The container's transformers (5.x) moves rope_theta into rope_parameters; the reference
@@ -232,6 +232,60 @@ def gen_e2e(out):
                 out[f"e2e/{name}/prefix_extend_positions"] = fb.positions.numpy().copy()
 
 
+def gen_e2e_long(out):
+    """One long greedy run at a real model shape: compact record (see cases.E2E_LONG_CASES)."""
+    from sglang.srt.managers.schedule_batch import Req, ScheduleBatch
+    from sglang.srt.model_executor.forward_batch_info import ForwardBatch
+    from sglang.srt.sampling.sampling_params import SamplingParams
+    from sglang.srt.speculative.spec_info import SpeculativeAlgorithm
+
+    for name, preset, dtn, lens, steps in cases.E2E_LONG_CASES:
+        if (preset, dtn) not in _RUNNERS:
+            continue
+        mr, cfg = _RUNNERS[(preset, dtn)]
+        prompts = cases.e2e_prompts(10000, lens)     # bench_one_batch draws ids below 10000 (bench_one_batch.py:211-232)
+        reqs = []
+        for i, ids in enumerate(prompts):
+            r = Req(rid=i, origin_input_text="", origin_input_ids=list(ids),
+                    sampling_params=SamplingParams(temperature=0, max_new_tokens=steps))
+            r.prefix_indices = []
+            r.fill_ids = r.origin_input_ids
+            r.extend_input_len = len(r.fill_ids)
+            r.logprob_start_len = len(r.origin_input_ids) - 1
+            reqs.append(r)
+
+        def run(batch):
+            fb = ForwardBatch.init_new(batch.get_model_worker_batch(), mr)
+            lo, _ = mr.forward(fb)
+            return mr.sample(lo, fb), lo.next_token_logits.clone()
+
+        with torch.no_grad():
+            mr.req_to_token_pool.clear()
+            mr.token_to_kv_pool_allocator.clear()
+            batch = ScheduleBatch.init_new(
+                reqs=reqs, req_to_token_pool=mr.req_to_token_pool,
+                token_to_kv_pool_allocator=mr.token_to_kv_pool_allocator, tree_cache=None,
+                model_config=mr.model_config, enable_overlap=False,
+                spec_algorithm=SpeculativeAlgorithm.NONE, enable_custom_logit_processor=False)
+            batch.prepare_for_extend()
+            nxt, logits = run(batch)
+            out[f"e2e/{name}/prefill_logits"] = f32(logits)
+            toks, top_v, top_i = [nxt.clone()], [], []
+            tv, ti = logits.float().topk(5, dim=-1)
+            top_v.append(f32(tv)); top_i.append(ti.numpy())
+            for _ in range(steps - 1):
+                batch.output_ids = nxt
+                batch.prepare_for_decode()
+                nxt, logits = run(batch)
+                toks.append(nxt.clone())
+                tv, ti = logits.float().topk(5, dim=-1)
+                top_v.append(f32(tv)); top_i.append(ti.numpy())
+            out[f"e2e/{name}/tokens"] = torch.stack(toks, 1).numpy()
+            out[f"e2e/{name}/last_logits"] = f32(logits)
+            out[f"e2e/{name}/top5_values"] = np.stack(top_v, 1)      # [B, steps, 5]
+            out[f"e2e/{name}/top5_ids"] = np.stack(top_i, 1)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "ops"
     out = {}
@@ -242,8 +296,10 @@ def main():
     else:
         # `python gen_golden.py e2e <preset> <dtype>`: one model per process
         preset, dtn = sys.argv[2], sys.argv[3]
-        _RUNNERS[(preset, dtn)] = load_reference_runner(preset, dtn)
+        long_run = any(c[1] == preset and c[2] == dtn for c in cases.E2E_LONG_CASES)
+        _RUNNERS[(preset, dtn)] = load_reference_runner(preset, dtn, context_length=512 if long_run else None)
         gen_e2e(out)
+        gen_e2e_long(out)
         path = os.path.join(HERE, f"e2e_{preset}_{dtn}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")

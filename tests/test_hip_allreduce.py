@@ -222,6 +222,82 @@ def test_tensor_parallel_two_ranks_on_one_gpu(preset, dtn):
     assert np.array_equal(results[0][1], results[1][1])
 
 
+def _skew_rank_main(rank, world, port, queue):
+    """Rank skew: a peer that is late but within the timeout changes nothing; a peer that stays away
+    longer than the timeout makes the waiting rank's call fail loudly (NaN output + status error)."""
+    try:
+        import time
+
+        import torch
+        import torch.distributed as dist
+
+        from oracle import ops_ref
+        from sglang_custom_amd._lib import Mi355Error
+        from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
+
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        ca = CustomAllreduce(dist.group.WORLD, 0, max_size=MAX_BYTES)
+        ins = _inputs(3000, world, 64 * 4096, torch.bfloat16)
+        want = ops_ref.custom_all_reduce(ins)
+        # (1) rank 1 arrives 2.5 s late: far inside the default timeout, results unchanged
+        dist.barrier()
+        if rank == 1:
+            time.sleep(2.5)
+        for algo in (1, 2):
+            out = ca.all_reduce(ins[rank].cuda(), algo=algo)
+            ca.check_status()
+            assert torch.equal(out.cpu(), want), algo
+        x, res = ins[rank].cuda().view(64, 4096), torch.zeros(64, 4096, dtype=torch.bfloat16, device="cuda")
+        # (2) with a 300 ms timeout rank 1 stays away for 1.5 s: rank 0 gives up
+        ca.set_timeout_ms(300)
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 1:
+            time.sleep(1.5)
+        out = ca.all_reduce(ins[rank].cuda(), algo=1)
+        torch.cuda.synchronize()
+        if rank == 0:
+            assert torch.isnan(out.float()).all(), "a sum over data that never arrived must be NaN"
+            for wait in (True, False):
+                try:
+                    ca.check_status(wait)
+                    raise AssertionError("check_status did not report the timed-out barrier")
+                except Mi355Error as e:
+                    assert "timed out" in str(e)
+        else:
+            # the late rank finds rank 0's flags and staged data in place: its own result is whole
+            ca.check_status()
+            assert torch.equal(out.cpu(), want)
+        del x, res
+        dist.barrier()
+        ca.close()
+        dist.destroy_process_group()
+        queue.put((rank, "ok"))
+    except BaseException:  # noqa: BLE001
+        queue.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+def test_all_reduce_rank_skew_and_lost_peer():
+    port = _free_port()
+    queue = _CTX.Queue()
+    procs = [_CTX.Process(target=_skew_rank_main, args=(r, 2, port, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(2):
+            rank, msg = queue.get(timeout=100)
+            results[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    assert results == {0: "ok", 1: "ok"}, "\n".join(f"rank {r}: {m}" for r, m in sorted(results.items()))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

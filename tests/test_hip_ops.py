@@ -942,3 +942,32 @@ def test_backend_sliding_window_layers_follow_the_reference_window_lists(ops):
             toks = r2t[pool_rows[b], s0: s0 + n].long()
             ref = ops_ref.attention_fp64(qd[b][:, None], kc[toks].transpose(0, 1), vc[toks].transpose(0, 1), D ** -0.5)[:, 0]
             assert maxdiff(o[b], ref) <= ATTN_TOL["bf16"], (window, b)
+
+
+def test_argmax_and_sampler_at_llama3_vocab(ops):
+    """vocab 128256 (sgl-kernel/tests/test_sampling.py runs its cases at 111 / 32000 / 128256): arg-max
+    with the first-index tie rule, softmax with temperature, and the joint top-k / top-p / min-p
+    sampler -- every draw inside the oracle's kept set, renormalised mass as the oracle's."""
+    V, B = 128256, 64
+    g = torch.Generator().manual_seed(77)
+    logits = (3.0 * torch.randn((B, V), generator=g)).bfloat16().float()     # bf16-valued: many exact ties
+    logits[3, 100] = logits[3, 90000] = logits[3].max() + 1.0                 # a tie for the maximum: first index wins
+    logits[5, V - 1] = logits[5].max() + 2.0                                  # the maximum in the last column
+    ids = ops.argmax(logits.to(DEV))
+    assert torch.equal(ids.cpu(), torch.argmax(logits, -1)) and ids[3].item() == 100 and ids[5].item() == V - 1
+    temps = torch.rand((B, 1), generator=g) + 0.5
+    probs = ops_ref.softmax_temperature(logits.clone(), temps)
+    got = logits.clone().to(DEV)
+    ops.softmax_temperature_(got, temps.to(DEV))
+    assert torch.allclose(got.cpu(), probs, rtol=2e-5, atol=1e-12)    # 128256-term sums in another order
+    # the sampler on untied probabilities (among exactly equal probabilities WHICH of them make the
+    # top-k cut is the sort's business in the reference and is not defined)
+    probs = ops_ref.softmax_temperature(3.0 * torch.randn((B, V), generator=g), temps)
+    top_ks = torch.randint(1, 60, (B,), generator=g).to(torch.int32)
+    top_ps = torch.rand((B,), generator=g) * 0.8 + 0.1
+    min_ps = torch.rand((B,), generator=g) * 0.05
+    dist = ops_ref.kept_distribution(probs, top_ks, top_ps, min_ps)
+    for trial in range(20):
+        u = torch.rand((B,), generator=g)
+        out = ops.top_k_top_p_min_p_sample(probs.to(DEV), top_ks.to(DEV), top_ps.to(DEV), min_ps.to(DEV), u.to(DEV))
+        assert (dist.gather(1, out.cpu().long()[:, None]) > 0).all(), trial

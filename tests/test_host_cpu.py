@@ -444,3 +444,101 @@ def test_bench_spawns_one_live_rank_per_gpu_and_refuses_to_mislabel():
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "refusing to mislabel" in r.stderr and "{" not in r.stdout
+
+
+class _Only:
+    """A stand-in that exposes exactly the attributes the reference's object of that kind has."""
+
+    def __init__(self, obj, allowed):
+        object.__setattr__(self, "_obj", obj)
+        object.__setattr__(self, "_allowed", set(allowed))
+
+    def __getattr__(self, name):
+        if name not in self._allowed:
+            raise AttributeError(f"the reference's object has no attribute {name!r}")
+        return getattr(self._obj, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._obj, name, value)
+
+
+def test_backend_is_a_drop_in_for_reference_shaped_objects():
+    """tests/golden/dropin.json records a run made where the reference is importable: the reference's
+    ModelRunner / RadixAttention / ForwardBatch / MHATokenToKVPool drove Mi355AttnBackend (assigned to
+    model_runner.attn_backend) and produced the reference backend's tokens and logits.  Here the same
+    backend runs on stand-ins that expose exactly the attribute surface recorded there, so a
+    dependency on anything the reference's objects lack fails with AttributeError."""
+    import json
+    from types import SimpleNamespace
+
+    import cases
+    import cpu_ops
+    from oracle import ops_ref
+    from sglang_custom_amd import ops_backend
+    from sglang_custom_amd.layers.attention.mi355_backend import Mi355AttnBackend
+    from sglang_custom_amd.layers.radix_attention import RadixAttention
+    from sglang_custom_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dropin.json")))
+    assert rec["tokens_equal_reference_backend"] and rec["max_abs_logit_difference"] < 1e-5
+    assert rec["mi355_backend_signatures"] == rec["reference_interface_signatures"]
+    import inspect
+
+    for m, params in rec["reference_interface_signatures"].items():      # and the code still has those signatures
+        assert list(inspect.signature(getattr(Mi355AttnBackend, m)).parameters) == params, m
+    attrs = rec["reference_attrs"]
+    ops_backend.set_ops_backend(cpu_ops)
+    try:
+        dt, Hq, Hkv, D = torch.float32, 8, 2, 64
+        pre, ext = [6, 0, 11], [9, 14, 1]
+        seq = [a + b for a, b in zip(pre, ext)]
+        kc, vc, r2t, rows = cases.paged_inputs(400, dt, 3, Hkv, D, [n + 1 for n in seq])
+        pool = MHATokenToKVPool(kc.shape[0] - 1, 1, dt, Hkv, D, 1, "cpu")
+        pool.get_key_buffer(0).copy_(kc)
+        pool.get_value_buffer(0).copy_(vc)
+        r2tp = ReqToTokenPool(r2t.shape[0], r2t.shape[1], "cpu")
+        r2tp.req_to_token.copy_(r2t)
+        spool, sr2t = _Only(pool, attrs["token_to_kv_pool"]), _Only(r2tp, attrs["req_to_token_pool"])
+        cfg = _Only(SimpleNamespace(num_attention_heads=Hq, num_key_value_heads=Hkv, context_len=64, head_dim=D, vocab_size=32),
+                    attrs["model_config"])
+        runner = _Only(SimpleNamespace(device="cpu", tp_size=1, req_to_token_pool=sr2t, token_to_kv_pool=spool, model_config=cfg,
+                                       sliding_window_size=None, attn_backend=None), attrs["model_runner"])
+        be = Mi355AttnBackend(runner)
+        layer = _Only(RadixAttention(Hq, D, D ** -0.5, Hkv, 0), attrs["radix_attention"])
+        q = cases.randn((sum(ext), Hq * D), 401, dt)
+        loc = torch.cat([r2t[rows[b], pre[b]: seq[b]].long() for b in range(3)])
+        knew, vnew = kc[loc].clone(), vc[loc].clone()
+
+        def mode(m):
+            return _Only(m, attrs["forward_mode"])
+
+        fb = _Only(ForwardBatch(forward_mode=mode(ForwardMode.EXTEND), batch_size=3, input_ids=torch.zeros(sum(ext), dtype=torch.int64),
+                                req_pool_indices=rows, seq_lens=torch.tensor(seq), out_cache_loc=loc, seq_lens_sum=sum(seq),
+                                seq_lens_cpu=torch.tensor(seq), extend_seq_lens=torch.tensor(ext, dtype=torch.int32),
+                                extend_prefix_lens=torch.tensor(pre, dtype=torch.int32), extend_prefix_lens_cpu=pre,
+                                extend_seq_lens_cpu=ext, req_to_token_pool=sr2t, token_to_kv_pool=spool, attn_backend=be),
+                   attrs["forward_batch"])
+        be.init_forward_metadata(fb)
+        o = be.forward(q, knew, vnew, layer, fb)
+        want = ops_ref.extend_attention(q.view(-1, Hq, D), kc, vc, r2t, rows, torch.tensor(seq), torch.tensor(pre),
+                                        torch.tensor(ext), D ** -0.5, True, True)
+        assert (o.view(-1, Hq, D) - want).abs().max().item() < 1e-5
+        dseq = [n + 1 for n in seq]
+        dloc = torch.stack([r2t[rows[b], seq[b]] for b in range(3)]).long()
+        qd = cases.randn((3, Hq * D), 402, dt)
+        fb = _Only(ForwardBatch(forward_mode=mode(ForwardMode.DECODE), batch_size=3, input_ids=torch.zeros(3, dtype=torch.int64),
+                                req_pool_indices=rows, seq_lens=torch.tensor(dseq), out_cache_loc=dloc, seq_lens_sum=sum(dseq),
+                                seq_lens_cpu=torch.tensor(dseq), req_to_token_pool=sr2t, token_to_kv_pool=spool, attn_backend=be),
+                   attrs["forward_batch"])
+        be.init_forward_metadata(fb)
+        o = be.forward(qd, kc[dloc].clone(), vc[dloc].clone(), layer, fb)
+        want = ops_ref.decode_attention(qd.view(3, Hq, D), kc, vc, r2t, rows, torch.tensor(dseq), D ** -0.5, True)
+        assert (o.view(3, Hq, D) - want).abs().max().item() < 1e-5
+        # the graph hooks as the reference's graph runner calls them (positionally, no extra arguments)
+        be.init_cuda_graph_state(4, 4)
+        be.init_forward_metadata_capture_cuda_graph(3, 3, rows, torch.tensor(dseq), None, mode(ForwardMode.DECODE), None)
+        be.init_forward_metadata_replay_cuda_graph(3, rows, torch.tensor(dseq), sum(dseq), None, mode(ForwardMode.DECODE), None, None)
+        assert be.get_cuda_graph_seq_len_fill_value() == 1
+    finally:
+        ops_backend.set_ops_backend(None)

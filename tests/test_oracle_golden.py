@@ -263,3 +263,32 @@ def test_mla_module_matches_reference(golden_mla, name, dtn, qr, scaling):
         for step in range(steps):
             ref = torch.stack([r[n + step] for r, n in zip(want, lens)]).float()
             assert (ref - g(f"decode_{step}")).abs().max().item() <= tol64 * g("absorb_prefill").abs().max().item()
+
+
+@pytest.mark.parametrize("name,preset,dtn,lens,steps", cases.E2E_LONG_CASES)
+def test_e2e_real_shape_matches_reference(name, preset, dtn, lens, steps):
+    """Configuration 1 at its real shape (Llama-3.2-1B, vocab 128256, tied head, llama3 rope scaling):
+    one request, 128-token prompt, 128 greedy tokens -- the oracle reproduces the reference's tokens
+    and its logits bit for bit (same op sequence on the same torch build)."""
+    g = load_e2e(preset, dtn)
+    dt = DT[dtn]
+    cfg = hf_config_dict(preset, {"f32": "float32", "bf16": "bfloat16"}[dtn])
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=dt)
+    m = OracleLlama(cfg, w, dt, max_total_tokens=2048, max_reqs=4, context_len=512)
+    prompts = cases.e2e_prompts(10000, lens)
+    logits, _ = m.extend(prompts)
+    tol = 0.0 if dtn == "bf16" else 1e-5      # fp32 GEMMs may block differently from run to run
+    assert (logits - t(g[f"e2e/{name}/prefill_logits"])).abs().max() <= tol
+    ref_toks = t(g[f"e2e/{name}/tokens"])
+    tv = t(g[f"e2e/{name}/top5_values"])
+    if dtn != "bf16":
+        steps = 24                              # the fp32 model is the slow one on CPU: its first 24 steps
+    toks = [ops_ref.greedy(logits)]
+    for s in range(1, steps):
+        logits, _ = m.decode(toks[-1])
+        v, i = logits.topk(5, dim=-1)
+        assert (v - tv[:, s]).abs().max() <= tol, s
+        toks.append(ops_ref.greedy(logits))
+    if steps == ref_toks.shape[1]:
+        assert (logits - t(g[f"e2e/{name}/last_logits"])).abs().max() <= tol
+    assert torch.equal(torch.stack(toks, 1), ref_toks[:, :steps])
