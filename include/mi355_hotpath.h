@@ -345,15 +345,6 @@ int mi355_linear_packed_silu_mul(void* y, const void* x, const void* w_packed, i
                                  int64_t k, int64_t x_stride, void* workspace,
                                  int64_t workspace_bytes, int dtype, void* stream);
 
-/* Tuning / ablation switches (development only): key 0 selects the decode GEMM variant
- * (0 = single-launch ring kernel, 1 = two-launch kernel), key 2 overrides the split-K plan, key 4 the weight tiles per workgroup. */
-void mi355_debug_set(int key, int value);
-/* Read-bandwidth probe (development only): streams `bytes` from src with `grid` workgroups. */
-int mi355_debug_read_bw(const void* src, int64_t bytes, int grid, int unroll, void* sink,
-                        void* stream);
-/* Development aid: out[wg] = XCD the workgroup ran on, for a 1-D grid of `grid` workgroups. */
-int mi355_debug_xcc_map(void* out, int grid, void* stream);
-
 /* ---- K14 fp8 W8A8 ------------------------------------------------------------------------------
  * Per-token dynamic quantisation to OCP e4m3fn (max 448): s[r] = max(absmax(x[r,:]), 1e-10)/448,
  * q = clamp(x/s, +-448) -> fp8.

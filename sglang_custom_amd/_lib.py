@@ -44,9 +44,6 @@ _SIGNATURES = {
     "mi355_linear_packed_silu_mul": (I, [P, P, P, L, L, L, L, P, L, I, P]),
     "mi355_fp8_packed_workspace_bytes": (L, [L, L, L]),
     "mi355_fp8_scaled_mm_packed": (I, [P, P, P, P, P, P, L, L, L, P, L, I, P]),
-    "mi355_debug_set": (None, [I, I]),
-    "mi355_debug_read_bw": (I, [P, L, I, I, P, P]),
-    "mi355_debug_xcc_map": (I, [P, I, P]),
     "mi355_prefetch_next": (I, [P, L, L, L, I, L]),
     "mi355_decode_attention_fused_qkv": (I, [P, I, P, P, P, P, P, I, P, P, P, P, I, P, P, P, L, P, P, I, L, I, I, I, L, F, I, P]),
     "mi355_copy_decode_inputs": (I, [P, P, I, L, P]),
@@ -84,6 +81,21 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+# extra entry points of the development build (include/mi355_hotpath_dev.h)
+_DEV_SIGNATURES = {
+    "mi355_debug_set": (None, [I, I]),
+    "mi355_debug_read_bw": (I, [P, L, I, I, P, P]),
+    "mi355_debug_xcc_map": (I, [P, I, P]),
+}
+_use_dev = False
+
+
+def use_dev_library() -> None:
+    """Tools only: load libmi355_hotpath_dev.so (ablation switches + bandwidth probes) instead of the
+    product library.  Must be called before the first load()."""
+    global _use_dev
+    assert _lib is None, "use_dev_library() must come before the library is loaded"
+    _use_dev = True
 
 _lib = None
 
@@ -98,17 +110,18 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH.replace("libmi355_hotpath.so", "libmi355_hotpath_dev.so") if _use_dev else LIB_PATH
+    if not os.path.exists(path):
         raise Mi355Error(
-            f"{LIB_PATH} not found: build it with `python -m sglang_custom_amd.build` "
+            f"{path} not found: build it with `python -m sglang_custom_amd.build{' --dev' if _use_dev else ''}` "
             "(hipcc --offload-arch=gfx950). There is no fallback path.")
     # torch (if used by the caller) must be imported first so that its libamdhip64.so.7 is the
     # one HIP runtime in the process; stream handles are only meaningful within one runtime.
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-    for name, (res, args) in _SIGNATURES.items():
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in list(_SIGNATURES.items()) + (list(_DEV_SIGNATURES.items()) if _use_dev else []):
         fn = getattr(lib, name, None)
         if fn is None:
-            raise Mi355Error(f"{LIB_PATH} does not export {name}")
+            raise Mi355Error(f"{path} does not export {name}")
         fn.restype = res
         fn.argtypes = args
     if lib.mi355_abi_version() != 1:

@@ -1191,7 +1191,13 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const float* __restri
   }
 }
 
-int g_decode_variant = 0;   // 0 = P.V on MFMA, 1 = P.V on the vector ALU (mi355_debug_set key 6)
+// 0 = P.V on MFMA, 1 = P.V on the vector ALU: an ablation switch of the development build
+// (mi355_debug_set key 6); a compile-time zero in the product library.
+#ifdef MI355_DEV_BUILD
+int g_decode_variant = 0;
+#else
+static constexpr int g_decode_variant = 0;
+#endif
 
 static thread_local bool g_kv8 = false;   // set by the entry point for the duration of one launch_decode call (fp8 KV cache)
 

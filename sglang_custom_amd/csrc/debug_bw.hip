@@ -1,6 +1,7 @@
 // Development aid: read-bandwidth probe used to calibrate what a streaming kernel can reach on
 // this chip for a given launch geometry (not part of the hot path).
 #include "common.cuh"
+#include "../../include/mi355_hotpath_dev.h"
 
 namespace mi355 {
 

@@ -10,6 +10,9 @@
 //  * tiled path (any M, any dtype): exact-fp32-accumulate LDS-tiled VALU kernel.  It is the
 //    fp32 parity path and the fallback for shapes the skinny kernel does not take.
 #include "common.cuh"
+#ifdef MI355_DEV_BUILD
+#include "../../include/mi355_hotpath_dev.h"
+#endif
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -177,9 +180,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 //     workgroup that consumes it).
 // grid: (ceil(N / (64*NT)), splits).  block: 256.
 // ------------------------------------------------------------------------------------------
+// Tuning / ablation switches.  They exist only in the development build of the library
+// (-DMI355_DEV_BUILD, libmi355_hotpath_dev.so, entry point mi355_debug_set); in the product build
+// they are compile-time zeros, so the library carries no process-global mutable state.
+#ifdef MI355_DEV_BUILD
 extern int g_decode_variant;
-int g_gemm_variant = 0;   // tuning switches, see mi355_debug_set
+int g_gemm_variant = 0;
 int g_force_splits = 0;
+#else
+static constexpr int g_gemm_variant = 0;
+static constexpr int g_force_splits = 0;
+#endif
 
 template <typename T, int MT, int NT, typename OUT, bool PACKED, int WAVES = 4, bool ACT = false>
 __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
@@ -590,7 +601,11 @@ struct SkinnyPlan {
   int64_t slab_bytes;      // fp32 split-K partials behind them
 };
 
+#ifdef MI355_DEV_BUILD
 int g_force_waves = 0;
+#else
+static constexpr int g_force_waves = 0;
+#endif
 
 // Decomposition of y[M, N] = x W^T over workgroups: `waves` 16-row weight tiles (x NT) side by
 // side per workgroup share one activation tile, K is split `splits` ways.  Aim: one or two
@@ -804,12 +819,14 @@ using namespace mi355;
 
 extern "C" {
 
+#ifdef MI355_DEV_BUILD
 void mi355_debug_set(int key, int value) {
   if (key == 0) g_gemm_variant = value;   // 0 = ring kernel (default), 1 = two-launch kernel
   if (key == 2) g_force_splits = value;   // > 0 overrides the split-K plan
   if (key == 4) g_force_waves = value;    // 4 | 6 | 7 | 8 overrides the tiles-per-workgroup plan
   if (key == 6) g_decode_variant = value; // decode attention P.V: 0 = on MFMA (default), 1 = on the vector ALU
 }
+#endif
 
 int64_t mi355_linear_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   if (m < 1 || m > 64 || n < 1 || k < 1) return 0;

@@ -229,8 +229,7 @@ class Mi355AttnBackend(AttentionBackend):
     @staticmethod
     def supports_fused_qkv(layer, rotary_emb, dtype) -> bool:
         g = layer.tp_q_head_num // max(layer.tp_k_head_num, 1)
-        return (hasattr(get_ops(), "decode_attention_fused_qkv") and layer.qk_head_dim == 128
-                and layer.v_head_dim == 128 and dtype in (torch.bfloat16, torch.float16)
+        return (layer.qk_head_dim == 128 and layer.v_head_dim == 128 and dtype in (torch.bfloat16, torch.float16)
                 and layer.tp_q_head_num % layer.tp_k_head_num == 0 and g in (1, 2, 4, 8)
                 and not layer.logit_cap and layer.sliding_window_size in (None, -1)
                 and rotary_emb.is_neox_style and rotary_emb.rotary_dim == 128

@@ -119,8 +119,6 @@ def decode_linear_deferred(layer, x, needs_all_reduce: bool = True):
         return None
     n = layer.weight.shape[0]
     if isinstance(layer.quant_method, W8A8Fp8LinearMethod):
-        if not hasattr(ops, "fp8_packed_partials"):
-            return None
         if isinstance(x, QuantizedAct):
             xq, xs = x.xq, x.x_scale
         else:
@@ -128,7 +126,7 @@ def decode_linear_deferred(layer, x, needs_all_reduce: bool = True):
         part = ops.fp8_packed_partials(xq, wp, n)
         return None if part is None else SplitKPartials(part, xs, layer.weight_scale.data)
     if (isinstance(x, QuantizedAct) or not isinstance(layer.quant_method, UnquantizedLinearMethod)
-            or not hasattr(ops, "linear_packed_partials") or x.stride(0) % 8 != 0):
+            or x.stride(0) % 8 != 0):
         return None
     part = ops.linear_packed_partials(x, wp, n)
     return None if part is None else SplitKPartials(part)

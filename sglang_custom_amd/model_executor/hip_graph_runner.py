@@ -91,7 +91,7 @@ class HipGraphRunner:
         srcs = [forward_batch.input_ids, forward_batch.req_pool_indices, forward_batch.seq_lens,
                 forward_batch.out_cache_loc, forward_batch.positions]
         ops = get_ops()
-        if hasattr(ops, "copy_decode_inputs") and all(t.dtype == torch.int64 and t.is_contiguous() for t in srcs):
+        if all(t.dtype == torch.int64 and t.is_contiguous() for t in srcs):
             ops.copy_decode_inputs(dsts, srcs, raw_bs)   # one launch instead of five copies
         else:
             for d, s_ in zip(dsts, srcs):

@@ -66,8 +66,7 @@ def wants_fp8_input(layer, m: int) -> bool:
     per-token-quantised rows directly (QuantizedAct) instead of a 16-bit tensor."""
     from ..layers.quantization import unquant
     return (unquant.DECODE_FUSION and isinstance(layer.quant_method, W8A8Fp8LinearMethod)
-            and 1 <= m <= SKINNY_MAX_M and getattr(layer, "weight_packed", None) is not None
-            and hasattr(get_ops(), "rmsnorm_ex"))
+            and 1 <= m <= SKINNY_MAX_M and getattr(layer, "weight_packed", None) is not None)
 
 
 class LlamaAttention(nn.Module):

@@ -2,6 +2,7 @@
 import ctypes, sys, torch
 sys.path.insert(0, '.')
 from sglang_custom_amd import ops, _lib
+_lib.use_dev_library()   # ablation switches and probes live in the development build only
 lib = _lib.load()
 lib.mi355_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
 bs, ctx, hq, hkv, D = 64, 1064, 32, 8, 128

@@ -1,6 +1,7 @@
 import sys, torch
 sys.path.insert(0, '.')
 from sglang_custom_amd import _lib
+_lib.use_dev_library()   # ablation switches and probes live in the development build only
 lib = _lib.load()
 dev = 'cuda'
 sink = torch.zeros(4, dtype=torch.int32, device=dev)

@@ -3,6 +3,7 @@ over forced split counts and tiles per workgroup."""
 import sys, torch
 sys.path.insert(0, '.')
 from sglang_custom_amd import _lib, ops
+_lib.use_dev_library()   # ablation switches and probes live in the development build only
 lib = _lib.load()
 def graph_time(fn, n=40, reps=3):
     fn(0); fn(1); torch.cuda.synchronize()

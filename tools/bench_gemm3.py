@@ -2,6 +2,7 @@
 import ctypes, sys, torch
 sys.path.insert(0, '.')
 from sglang_custom_amd import ops, _lib
+_lib.use_dev_library()   # ablation switches and probes live in the development build only
 lib = _lib.load()
 lib.mi355_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -2,6 +2,7 @@
 import ctypes, sys, torch
 sys.path.insert(0, '.')
 from sglang_custom_amd import ops, _lib
+_lib.use_dev_library()   # ablation switches and probes live in the development build only
 lib = _lib.load()
 bs, H, ctx = 64, 16, 4096
 if len(sys.argv) > 3: bs, H, ctx = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

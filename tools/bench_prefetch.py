@@ -3,6 +3,7 @@
 import sys, torch
 sys.path.insert(0, '.')
 from sglang_custom_amd import _lib, ops
+_lib.use_dev_library()   # ablation switches and probes live in the development build only
 lib = _lib.load()
 dev = 'cuda'
 st = lambda: torch.cuda.current_stream().cuda_stream
