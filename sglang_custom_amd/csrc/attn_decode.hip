@@ -546,6 +546,11 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const T* __restri
 // V tile through transposed reads.  The softmax maximum is shared by the 16 keys of a tile (two
 // cross-lane max steps), which leaves ~80 vector instructions per 16 keys instead of ~250.
 // The accumulator holds O^T[d = 16 dt + 4c + r][g]; columns g >= G are padding.
+// KROW (the product configuration): K rows are fetched the way V rows are -- the 16 lanes of a
+// quarter-wave read ONE whole 256-byte row (two cache lines) per instruction -- and reach MFMA
+// fragment order through the wave's own LDS tile.  Loading fragments straight from memory makes
+// every quarter-wave touch 16 rows x 16 bytes, i.e. sixteen cache-line look-ups for 256 bytes;
+// measured 58.8 -> 56.4 us at batch 64 x 1064 keys, 8 kv heads.
 // ------------------------------------------------------------------------------------------
 constexpr int DV_ROW = 128 + 16;   // V tile row in LDS (elements): 288 B -> conflict-free transposed reads
 
@@ -557,7 +562,7 @@ constexpr int DV_ROW = 128 + 16;   // V tile row in LDS (elements): 288 B -> con
 // required (G = all query heads of the kv head), so nobody else reads or writes that slot.
 // KV8: the cache holds e4m3fn bytes (kbuf / vbuf are byte buffers behind the T pointers): rows are
 // widened to T on load, the new token's rows are stored quantised and used at their stored value.
-template <typename T, int G, bool CAP, bool FUSED = false, bool KV8 = false>
+template <typename T, int G, bool CAP, bool FUSED = false, bool KV8 = false, bool KROW = false>
 __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __restrict__ q,
                                                                   const T* kbuf, const T* vbuf,
                                                                   T* __restrict__ o, DecodeParams p,
@@ -569,12 +574,16 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   using frag4 = typename Mfma16<T>::frag;
   // what the K/V register buffers hold between load and use: with an fp8 cache the raw 8 bytes
   // (widened when the tile is computed), so that two buffered tiles cost half the registers
-  using KRaw = typename std::conditional<KV8, uint2, frag>::type;
+  using KRaw = typename std::conditional<KV8, uint2, typename std::conditional<KROW, Vec<T, VE>, frag>::type>::type;
   using VRaw = typename std::conditional<KV8, uint2, Vec<T, VE>>::type;
   __shared__ float sm_acc[4][G][D];
   __shared__ float sm_m[4][G];
   __shared__ float sm_l[4][G];
   __shared__ __attribute__((aligned(16))) T sm_v[4][16 * DV_ROW];
+  // KROW: K rows are fetched like V rows (a quarter-wave reads one whole 256-byte row, i.e. two
+  // cache lines, instead of sixteen 16-byte pieces of sixteen rows) and reach MFMA fragment order
+  // through the wave's own LDS tile
+  __shared__ __attribute__((aligned(16))) T sm_k[KROW ? 4 : 1][KROW ? 16 * DV_ROW : 8];
 
   const int gtotal = p.hq / p.hkv;
   const int groups_per_kv = gtotal / G;
@@ -672,12 +681,14 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 
   const int32_t* pt = p.page_table + page_off;
   const int64_t row_stride = (int64_t)p.hkv * D;
-  const KVT* kbase = reinterpret_cast<const KVT*>(kbuf) + (int64_t)kvh * D + 8 * c4;     // + slot * row_stride + 32 s
+  const KVT* kbase = reinterpret_cast<const KVT*>(kbuf) + (int64_t)kvh * D + 8 * (KROW ? r16 : c4);   // + slot * row_stride (+ 32 s)
   const KVT* vbase = reinterpret_cast<const KVT*>(vbuf) + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
   const int64_t wave_first = k0 + (int64_t)wave * 16;
   const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 63) / 64) : 0;
   const int64_t last_key = len - 1;
   T* v_wr = &sm_v[wave][(4 * c4) * DV_ROW + 8 * r16];                           // + u rows
+  T* k_wr = &sm_k[KROW ? wave : 0][KROW ? (4 * c4) * DV_ROW + 8 * r16 : 0];     // + u rows
+  const T* k_rd = &sm_k[KROW ? wave : 0][KROW ? r16 * DV_ROW + 8 * c4 : 0];     // + 32 s
   const T* v_rd = &sm_v[wave][(4 * c4 + (r16 >> 2)) * DV_ROW + 4 * (r16 & 3)];  // + 16 dt
 
   // FUSED: the newest key (position len - 1) belongs to the last split; its 16-key tile is tile
@@ -708,11 +719,21 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 
   auto load_kv = [&](const int32_t& sk, const int32_t (&sv)[4], KRaw (&kf)[4], VRaw (&vv)[4]) {
     const KVT* krow = kbase + (int64_t)sk * row_stride;
-    if constexpr (KV8) {
+    if constexpr (KV8 && KROW) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kf[u] = *reinterpret_cast<const uint2*>(kbase + (int64_t)sv[u] * row_stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const uint2*>(vbase + (int64_t)sv[u] * row_stride);
+    } else if constexpr (KV8) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const uint2*>(krow + 32 * s);
 #pragma unroll
       for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const uint2*>(vbase + (int64_t)sv[u] * row_stride);
+    } else if constexpr (KROW) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kf[u] = ldvec<T, VE>(kbase + (int64_t)sv[u] * row_stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)sv[u] * row_stride);
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
@@ -786,7 +807,19 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 
   // widen an fp8 tile on use; a 16-bit tile is computed in place
   auto compute = [&](KRaw (&kraw)[4], VRaw (&vraw)[4], int it) {
-    if constexpr (KV8) {
+    if constexpr (KV8 && KROW) {
+      Vec<T, VE> vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) stvec<T, VE>(k_wr + u * DV_ROW, cvt8_from_fp8<T>(kraw[u]));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[u] = cvt8_from_fp8<T>(vraw[u]);
+      __builtin_amdgcn_wave_barrier();
+      frag kf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(k_rd + 32 * s);
+      __builtin_amdgcn_wave_barrier();
+      compute_tile(kf, vv, it);
+    } else if constexpr (KV8) {
       frag kf[4];
       Vec<T, VE> vv[4];
 #pragma unroll
@@ -794,6 +827,15 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 #pragma unroll
       for (int u = 0; u < 4; ++u) vv[u] = cvt8_from_fp8<T>(vraw[u]);
       compute_tile(kf, vv, it);
+    } else if constexpr (KROW) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) stvec<T, VE>(k_wr + u * DV_ROW, kraw[u]);
+      __builtin_amdgcn_wave_barrier();
+      frag kf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(k_rd + 32 * s);
+      __builtin_amdgcn_wave_barrier();
+      compute_tile(kf, vraw, it);
     } else {
       compute_tile(kraw, vraw, it);
     }
@@ -1211,14 +1253,24 @@ static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const D
   if constexpr (D == 128 && !std::is_same<T, float>::value) {
     if (g_kv8) {
       switch (G) {
-        case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
-        case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
-        case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
-        default: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, CAP, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP, false, true, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, CAP, false, true, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, CAP, false, true, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        default: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, CAP, false, true, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
       }
       return;
     }
     if (g_decode_variant == 0) {
+      switch (G) {
+        case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP, false, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, CAP, false, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, CAP, false, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+        default: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, CAP, false, false, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
+      }
+      return;
+    }
+#ifdef MI355_DEV_BUILD
+    if (g_decode_variant == 3) {   // ablation: K rows loaded straight into MFMA fragments (16 rows x 64 B per instruction)
       switch (G) {
         case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
         case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
@@ -1227,12 +1279,14 @@ static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const D
       }
       return;
     }
+    // ablation: P.V on the vector ALU (variant 1)
     switch (G) {
       case 8: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 8, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
       case 4: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 4, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
       case 2: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 2, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
       default: hipLaunchKernelGGL((decode_attn_mfma_kernel<T, 1, CAP>), grid, block, 0, st, q, kb, vb, o, p); break;
     }
+#endif
     return;
   }
   switch (G) {
@@ -1289,10 +1343,10 @@ static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParam
   const dim3 grid((unsigned)p.hkv, (unsigned)p.num_splits, (unsigned)bs), block(256);
   if (g_kv8) {
     switch (G) {
-      case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
-      case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
-      case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
-      case 1: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, false, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, false, true, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+      case 1: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, false, true, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
       default:
         set_error("decode_attention_fused_qkv: %d query heads per kv head (needs 1, 2, 4 or 8)", G);
         return MI355_ERR_UNSUPPORTED;
@@ -1303,10 +1357,10 @@ static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParam
     return MI355_OK;
   }
   switch (G) {
-    case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
-    case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
-    case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
-    case 1: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    case 2: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 2, false, true, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
+    case 1: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 1, false, true, false, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
     default:
       set_error("decode_attention_fused_qkv: %d query heads per kv head (needs 1, 2, 4 or 8)", G);
       return MI355_ERR_UNSUPPORTED;

@@ -46,8 +46,8 @@ qg = q.float().view(bs, hkv, hq // hkv, D)
 s = torch.einsum('bhgd,bkhd->bhgk', qg, K) * D ** -0.5
 ref = torch.einsum('bhgk,bkhd->bhgd', s.softmax(-1), V).reshape(bs, hq, D)
 nbytes = bs * ctx * hkv * D * 2 * kb[0].element_size()
-for dbg in (1, 0):
-    lib.mi355_debug_set(6, dbg)   # 1 = P.V on the vector ALU, 0 = on MFMA
+for dbg in (3, 0):
+    lib.mi355_debug_set(6, dbg)   # 3 = K rows straight into fragments (ablation), 0 = whole K rows staged through LDS (product)
     for ns in (1, 2, 3, 4):
         ops.decode_attention_paged(q, kb[0], vb[0], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5)
         err = (o.float() - ref).abs().max().item()
