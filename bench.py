@@ -197,7 +197,7 @@ def cpu_baseline(cfg, bs, ctx, dtype):
     from oracle.llama_ref import OracleLlama
     from oracle import ops_ref
 
-    nl = 1
+    nl = 2
     torch.manual_seed(0)
     small = dict(cfg)
     small["num_hidden_layers"] = nl
@@ -207,7 +207,7 @@ def cpu_baseline(cfg, bs, ctx, dtype):
     for name, shape in llama_param_shapes(small).items():
         w[name] = (torch.randn(shape, dtype=torch.bfloat16) * 0.02).to(dtype) if len(shape) > 1 \
             else torch.ones(shape, dtype=dtype)
-    m = OracleLlama(small, w, dtype, max_total_tokens=bs * (ctx + 4), max_reqs=bs, context_len=ctx + 8)
+    m = OracleLlama(small, w, dtype, max_total_tokens=bs * (ctx + 16), max_reqs=bs, context_len=ctx + 24)
     # fill the cache as if `ctx` tokens per request were already there (contents are irrelevant
     # to the timing): allocate slots and table entries without running a prefill
     m.req_pool_indices = torch.arange(bs, dtype=torch.int64)
@@ -218,24 +218,35 @@ def cpu_baseline(cfg, bs, ctx, dtype):
         c.normal_(0, 1)
     ids = torch.randint(0, 10000, (bs,))
     threads = torch.get_num_threads()
-    # layers: time the whole step, then the head alone, subtract
+    import statistics
+
+    # whole steps of the nl-layer model, then the LM head alone; median of `reps` each
+    reps = 7
     m.decode(ids)  # warm-up
-    t0 = time.perf_counter()
-    reps = 2
+    t_steps, t_heads = [], []
     for _ in range(reps):
+        t0 = time.perf_counter()
         m.decode(ids)
-    t_step = (time.perf_counter() - t0) / reps
+        t_steps.append(time.perf_counter() - t0)
     h = torch.randn(bs, cfg["hidden_size"]).to(dtype)
     m._logits(h)
-    t0 = time.perf_counter()
-    m._logits(h)
-    t_head = time.perf_counter() - t0
-    t_layer = max(t_step - t_head, 1e-9) / nl
-    full = t_layer * cfg["num_hidden_layers"] + t_head
-    return dict(value=bs / full, unit="tok/s", cores=threads, kind="port",
-                sample=f"oracle decode step bs={bs} ctx={ctx}: {nl} of {cfg['num_hidden_layers']} layers "
-                       f"({t_layer * 1e3:.0f} ms/layer) + LM head ({t_head * 1e3:.0f} ms) timed on "
-                       f"{threads} threads, scaled to {cfg['num_hidden_layers']} layers")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        m._logits(h)
+        t_heads.append(time.perf_counter() - t0)
+    t_head = statistics.median(t_heads)
+    L = cfg["num_hidden_layers"]
+
+    def scaled(t_step):
+        return max(t_step - t_head, 1e-9) / nl * L + t_head
+
+    full = scaled(statistics.median(t_steps))
+    lo, hi = bs / scaled(max(t_steps)), bs / scaled(min(t_steps))
+    return dict(value=round(bs / full, 2), unit="tok/s", cores=threads, kind="port",
+                spread=[round(lo, 2), round(hi, 2)],
+                sample=f"oracle decode step bs={bs} ctx={ctx}: {nl} of {L} layers + LM head, median of {reps} runs "
+                       f"({(statistics.median(t_steps) - t_head) / nl * 1e3:.0f} ms/layer, LM head {t_head * 1e3:.0f} ms) on "
+                       f"{threads} threads, scaled to {L} layers; spread = slowest..fastest run")
 
 
 def metric_name(args, tp, simulated):

@@ -39,7 +39,7 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     srcs = [s for s in SOURCES + (DEV_SOURCES if dev else []) if os.path.exists(os.path.join(CSRC, s))]
     lib = LIB_DEV if dev else LIB
-    flags = FLAGS + (["-DMI355_DEV_BUILD"] if dev else [])
+    flags = FLAGS + (["-DMI355_DEV_BUILD"] + os.environ.get("MI355_DEV_EXTRA_FLAGS", "").split() if dev else [])
     objs, procs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)

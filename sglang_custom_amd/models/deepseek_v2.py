@@ -69,13 +69,36 @@ class DeepseekV2AttentionMLA(nn.Module):
                 m.weight.data = m.weight.data.to(dtype=dtype, device=device)
         self.to(device)
 
+    def load_kv_b_proj_fp8(self, weight: torch.Tensor, weight_scale: torch.Tensor) -> None:
+        """kv_b_proj as an fp8 W8A8 checkpoint stores it: e4m3fn [N, K] + per-output-channel scale [N, 1].
+        The absorbed (decode) path is built from it by post_load_weights(); the multi-head prefill, which
+        would run kv_b_proj as an fp8 linear, is outside this module's fp8 support."""
+        assert weight.dtype == torch.float8_e4m3fn and weight_scale.shape == (weight.shape[0], 1)
+        self._kv_b_fp8 = (weight, weight_scale.float())
+
     def post_load_weights(self) -> None:
-        """w_kc [H, nope, rank] and w_vc [H, rank, v]: kv_b_proj split per head (:2080-2170)."""
+        """w_kc [H, nope, rank] and w_vc [H, rank, v]: kv_b_proj split per head (:2150-2313).  From an
+        fp8 kv_b_proj the reference re-quantises to ONE scale per tensor (channel_quant_to_tensor_quant,
+        :2251) and, on ROCm, multiplies as w.to(bf16) * w_scale on every call (:1242-1247, 1300-1306);
+        the same two bf16 tensors are built once here."""
+        fp8 = getattr(self, "_kv_b_fp8", None)
         w = self.kv_b_proj.weight.data
+        if fp8 is not None:
+            wq, ws = fp8
+            x = wq.to(torch.float32) * ws
+            lo, hi = x.aminmax()
+            amax = torch.maximum(lo.abs(), hi.abs()).float().clamp(min=1e-12)
+            fp_max = torch.finfo(torch.float8_e4m3fn).max
+            scale = fp_max / amax
+            w = (x.float() * scale).clamp(min=-fp_max, max=fp_max).to(torch.float8_e4m3fn)
+            self.w_scale = scale.float().reciprocal()
         w_kc, w_vc = w.unflatten(0, (-1, self.qk_nope_head_dim + self.v_head_dim)).split(
             [self.qk_nope_head_dim, self.v_head_dim], dim=1)
-        self.w_kc = w_kc.contiguous()
-        self.w_vc = w_vc.transpose(1, 2).contiguous()
+        if fp8 is not None:
+            w_kc = w_kc.to(torch.bfloat16) * self.w_scale
+            w_vc = w_vc.to(torch.bfloat16) * self.w_scale
+        self.w_kc = w_kc.contiguous().to(self.kv_b_proj.weight.dtype)
+        self.w_vc = w_vc.transpose(1, 2).contiguous().to(self.kv_b_proj.weight.dtype)
 
     # ---- shared front end ----
     def _q_and_latent(self, hidden_states):

@@ -142,6 +142,10 @@ YARN_ALT = dict(type="yarn", factor=8.0, original_max_position_embeddings=512, b
                 mscale=1.0, mscale_all_dim=0.5)             # cos/sin magnitude scale != 1
 MLA_MODULE_CASES = [("f32_plain", "f32", None, None), ("bf16_qlora", "bf16", 192, None),
                     ("f32_qlora_yarn", "f32", 192, YARN_V3), ("bf16_yarn_alt", "bf16", None, YARN_ALT)]
+# a fifth scenario, "bf16_fp8_kv_b": kv_b_proj stored as e4m3fn with per-output-channel scales (an fp8
+# W8A8 checkpoint); the absorbed path then runs on w_kc / w_vc re-quantised per tensor and widened to
+# bf16 times the tensor scale (models/deepseek_v2.py:2196-2252, 2271-2297, 1242-1247, 1300-1306)
+MLA_FP8_CASE = ("bf16_fp8_kv_b", "bf16", None, None)
 MLA_DIMS = dict(hidden=512, heads=16, nope=128, rope=64, v=128, kv_lora=512)
 MLA_THETA, MLA_EPS = 10000.0, 1e-6
 MLA_LENS, MLA_STEPS = (37, 5, 64), 3          # prompt lengths, decode steps
@@ -167,6 +171,14 @@ def mla_weights(q_lora_rank, seed=3):
         w["q_proj"] = r(H * (nope + rope), hidden, scale=hidden ** -0.5)
         w["kv_a_proj_with_mqa"] = r(kr + rope, hidden, scale=hidden ** -0.5)
     return w
+
+
+def mla_kv_b_fp8(w_kv_b):
+    """Per-output-channel e4m3fn quantisation of kv_b_proj as an fp8 checkpoint stores it:
+    returns (weight fp8 [N, K], weight_scale fp32 [N, 1])."""
+    w = w_kv_b.float()
+    scale = w.abs().amax(1, keepdim=True).clamp(min=1e-12) / 448.0
+    return (w / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn), scale
 
 
 def mla_hidden_states(lens, extra, seed, dt):

@@ -55,7 +55,7 @@ def gen_decode_kernel(out):
                 out[f"mla_decode_cpu_kernel/{name}/{i}"] = f32(o2)
 
 
-def build_module(dt, q_lora_rank, rope_scaling):
+def build_module(dt, q_lora_rank, rope_scaling, fp8_kv_b=False):
     from sglang.srt.managers.schedule_batch import global_server_args_dict
     from sglang.srt.models.deepseek_v2 import DeepseekV2AttentionMLA, DeepseekV2ForCausalLM
 
@@ -80,7 +80,26 @@ def build_module(dt, q_lora_rank, rope_scaling):
             getattr(m, name).weight.data = val.clone()
     fake = SimpleNamespace(config=SimpleNamespace(num_hidden_layers=1), quant_config=None,
                            model=SimpleNamespace(layers=[SimpleNamespace(self_attn=m)]))
-    DeepseekV2ForCausalLM.post_load_weights(fake)
+    if fp8_kv_b:
+        # an fp8 checkpoint: kv_b_proj.weight e4m3fn + per-channel weight_scale.  post_load_weights
+        # re-quantises per tensor (channel_quant_to_tensor_quant) and, on a host without an fp8 bmm,
+        # widens w_kc / w_vc to bf16 times the tensor scale (:2291-2297) -- the same expression its ROCm
+        # branch evaluates on every call (:1242-1247, 1300-1306).  That widening is keyed on the
+        # module-level CPU flags, set for the duration of this call.
+        import sglang.srt.models.deepseek_v2 as ds
+
+        wq, ws = cases.mla_kv_b_fp8(cases.mla_weights(q_lora_rank)["kv_b_proj"])
+        m.kv_b_proj.weight.data = wq
+        m.kv_b_proj.weight_scale = torch.nn.Parameter(ws, requires_grad=False)
+        saved = (ds._is_cpu, ds._is_cpu_amx_available)
+        ds._is_cpu, ds._is_cpu_amx_available = True, True
+        try:
+            DeepseekV2ForCausalLM.post_load_weights(fake)
+        finally:
+            ds._is_cpu, ds._is_cpu_amx_available = saved
+        assert m.w_kc.dtype == torch.bfloat16
+    else:
+        DeepseekV2ForCausalLM.post_load_weights(fake)
     return m
 
 
@@ -126,9 +145,12 @@ def gen_module(out):
     from sglang.srt.model_executor.forward_batch_info import ForwardMode  # noqa: F401
 
     d = cases.MLA_DIMS
-    for name, dtn, qr, scaling in cases.MLA_MODULE_CASES:
+    for name, dtn, qr, scaling in cases.MLA_MODULE_CASES + [cases.MLA_FP8_CASE]:
         dt = cases.DTYPES[dtn]
-        m = build_module(dt, qr, scaling)
+        fp8 = name == cases.MLA_FP8_CASE[0]
+        m = build_module(dt, qr, scaling, fp8_kv_b=fp8)
+        if fp8:
+            out[f"mla_module/{name}/w_scale"] = np.float64(float(m.w_scale))
         out[f"mla_module/{name}/softmax_scale"] = np.float64(m.scaling)
         out[f"mla_module/{name}/cos_sin_cache_head"] = f32(m.rotary_emb.cos_sin_cache[:128])
         lens, steps = cases.MLA_LENS, cases.MLA_STEPS
@@ -158,6 +180,8 @@ def gen_module(out):
                 o = m(fb.positions, x.clone(), fb, None)       # dispatch -> absorbed form on decode
                 out[f"mla_module/{name}/decode_{t}"] = f32(o)
 
+            if fp8:
+                continue   # the multi-head prefill would run kv_b_proj as an fp8 W8A8 linear: not this scenario
             # ---- (2) multi-head form of the same prefill ---------------------------------------------
             w = World(dt)
             write_table(w, rows, [0] * len(lens), per)

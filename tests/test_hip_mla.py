@@ -282,3 +282,48 @@ def test_mla_module_matches_reference_vectors(golden_mla, name, dtn, qr, scaling
     out, fb = run(runner, batch, torch.cat([s[f:n] for s, f, n in zip(cseqs, first, clens)]))
     assert fb.extend_prefix_lens_cpu == list(first)
     close(out, "chunk2")
+
+
+def test_mla_module_with_fp8_kv_b_proj_matches_reference_vectors(golden_mla):
+    """The absorbed (decode) path built from an fp8 kv_b_proj: tensor re-quantisation, w.to(bf16) * scale,
+    then the same kernels -- against the reference module's outputs for that checkpoint."""
+    import cases
+    from sglang_custom_amd.managers.schedule_batch import Req, ScheduleBatch
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardBatch
+    from sglang_custom_amd.models.deepseek_v2 import DeepseekV2AttentionMLA
+
+    name, dtn, qr, scaling = cases.MLA_FP8_CASE
+    dt, d = cases.DTYPES[dtn], cases.MLA_DIMS
+    g = lambda k: torch.from_numpy(golden_mla[f"mla_module/{name}/{k}"])   # noqa: E731
+    H = d["heads"]
+    attn = DeepseekV2AttentionMLA(d["hidden"], H, d["nope"], d["rope"], d["v"], qr, d["kv_lora"], 0, dt, DEV,
+                                  rope_theta=cases.MLA_THETA, max_position_embeddings=4096, rms_norm_eps=cases.MLA_EPS)
+    w = cases.mla_weights(qr)
+    with torch.no_grad():
+        for wname, val in w.items():
+            getattr(attn, wname).weight.data.copy_(val.to(dt).to(DEV))
+    wq, ws = cases.mla_kv_b_fp8(w["kv_b_proj"])
+    attn.load_kv_b_proj_fp8(wq.to(DEV), ws.to(DEV))
+    attn.post_load_weights()
+    assert abs(float(attn.w_scale) - float(golden_mla[f"mla_module/{name}/w_scale"])) < 1e-9
+    scale = g("absorb_prefill").abs().max().item()
+    lens, steps = cases.MLA_LENS, cases.MLA_STEPS
+    seqs = cases.mla_hidden_states(lens, steps, 9, dt)
+    runner, kvpool, alloc = _mla_world(dt, H)
+    batch = ScheduleBatch.init_new([Req(i, [1] * n) for i, n in enumerate(lens)], runner.req_to_token_pool, alloc,
+                                   model_config=runner.model_config)
+
+    def run(rows):
+        fb = ForwardBatch.init_new(batch.get_model_worker_batch(), runner)
+        runner.attn_backend.init_forward_metadata(fb)
+        with torch.no_grad():
+            return attn.forward_absorb(fb.positions, rows.to(DEV), fb).float().cpu()
+
+    batch.prepare_for_extend()
+    out = run(torch.cat([s[:n] for s, n in zip(seqs, lens)]))
+    assert (out - g("absorb_prefill")).abs().max().item() <= 4e-2 * scale
+    for step in range(steps):
+        batch.output_ids = torch.ones(len(lens), dtype=torch.int64, device=DEV)
+        batch.prepare_for_decode()
+        out = run(torch.stack([s[n + step] for s, n in zip(seqs, lens)]))
+        assert (out - g(f"decode_{step}")).abs().max().item() <= 4e-2 * scale, step

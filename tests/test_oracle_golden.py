@@ -292,3 +292,40 @@ def test_e2e_real_shape_matches_reference(name, preset, dtn, lens, steps):
     if steps == ref_toks.shape[1]:
         assert (logits - t(g[f"e2e/{name}/last_logits"])).abs().max() <= tol
     assert torch.equal(torch.stack(toks, 1), ref_toks[:, :steps])
+
+
+def test_mla_module_with_fp8_kv_b_proj_matches_reference(golden_mla):
+    """kv_b_proj from an fp8 checkpoint: the reference's post_load_weights re-quantises it per tensor and
+    the absorbed path multiplies by w.to(bf16) * w_scale; the oracle reproduces the tensor scale and
+    the module's prefill / decode outputs bit for bit."""
+    from oracle import mla_ref
+
+    name, dtn, qr, scaling = cases.MLA_FP8_CASE
+    dt, d = DT[dtn], cases.MLA_DIMS
+    g = lambda k: t(golden_mla[f"mla_module/{name}/{k}"])   # noqa: E731
+    w = cases.mla_weights(qr)
+    m = mla_ref.OracleMLA(w, dt, d["hidden"], d["heads"], d["nope"], d["rope"], d["v"], d["kv_lora"], qr, cases.MLA_THETA,
+                          cases.MLA_EPS, scaling, kv_b_fp8=cases.mla_kv_b_fp8(w["kv_b_proj"]))
+    assert abs(float(m.w_scale) - float(golden_mla[f"mla_module/{name}/w_scale"])) < 1e-12
+    lens, steps, rows = cases.MLA_LENS, cases.MLA_STEPS, torch.tensor([2, 0, 5])
+    seqs = cases.mla_hidden_states(lens, steps, 9, dt)
+    slots = cases.mla_slots(sum(lens) + steps * len(lens), 21)
+    per, p = [], 0
+    for n in lens:
+        per.append(slots[p: p + n])
+        p += n
+    zeros, lt = torch.zeros(3, dtype=torch.int64), torch.tensor(lens)
+    with torch.no_grad():
+        for r, sl in zip(rows, per):
+            m.req_to_token[r, : len(sl)] = sl.int()
+        loc = torch.cat(per)
+        pos, _ = ops_ref.compute_position(zeros, lt)
+        x = torch.cat([s[:n] for s, n in zip(seqs, lens)])
+        assert torch.equal(m.absorb("extend", pos, x, rows, lt, zeros, lt, loc).float(), g("absorb_prefill"))
+        for step in range(steps):
+            new_slots = slots[p: p + len(lens)]
+            p += len(lens)
+            m.req_to_token[rows, lt + step] = new_slots.int()
+            x = torch.stack([s[n + step] for s, n in zip(seqs, lens)])
+            sl = lt + step + 1
+            assert torch.equal(m.absorb("decode", sl - 1, x, rows, sl, None, None, new_slots).float(), g(f"decode_{step}"))
