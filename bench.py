@@ -253,7 +253,8 @@ def metric_name(args, tp, simulated):
     if simulated:
         return "per-GPU kernel time of one simulated TP shard (diagnostic)"
     names = {"llama-3-8b": "Llama-3-8B", "llama-3-70b": "Llama-3-70B", "llama-3.2-1b": "Llama-3.2-1B"}
-    dt = {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype] + (" fp8-W8A8" if args.quantization else "")
+    dt = ({"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype] + (" fp8-W8A8" if args.quantization else "")
+          + (" fp8-KV-cache" if args.kv_cache_dtype != "auto" else ""))
     return (f"decode output tok/s ({names.get(args.model, args.model)} {dt} TP={tp}, bs={args.batch_size}, "
             f"{args.input_len}-in) + p50 TTFT")
 
