@@ -519,6 +519,230 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same prefill case on v_mfma_f32_32x32x16: a wave owns 32 query rows, a workgroup 128 rows of
+// one query head (4 waves).  Why: with the 16x16x32 tile above every MFMA needs a fresh 1-KiB A
+// fragment from LDS (K rows for the scores, V^T for the outputs), and twelve waves' fragment reads
+// take as many LDS cycles as their MFMAs take matrix-core cycles; a 32x32x16 MFMA does twice the
+// work on a fragment of the same size, and the loop issues half as many MFMA + LDS instructions.
+//   S^T = K . Q^T    : A = 32 key rows (ds_read_b128), B = the wave's 32 queries, kept in registers
+//                      (8 k-steps of 16 features).  Lane (query j = l & 31, h = l >> 5) then owns the
+//                      scores of ITS query for keys 8 (i >> 2) + 4 h + (i & 3) of each 32-key half.
+//   O^T += V^T . P^T : registers 8 u' .. 8 u' + 7 of a score tile, rounded to T, ARE the B fragment of
+//                      the 16-key step u (element e <-> key 16 u + 8 (e >> 2) + 4 h + (e & 3)); the A
+//                      fragment (V^T in that key order) comes from two transposed reads of the
+//                      row-major V tile.
+// K and V tiles are plain 256-byte rows with the chunk index XOR-ed by ((row & 3) << 2 | (row >> 2) & 3):
+// conflict-free for the 32-row fragment reads and for the transposed reads.
+// Workgroup -> work mapping: a 1-D grid; consecutive workgroups go round-robin over the 8 XCDs, so
+// workgroup L serves the (sequence, kv head) pair number (L & 7) + 8 * ((L >> 3) / per_pair): every
+// query block and every query head of a pair runs on ONE XCD and finds the pair's K/V in that XCD's
+// L2 after the first touch (the 2-D grid fetched each K/V row from HBM 2.8 times).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xor_image_off(int row, int ch) {   // bytes; ch = 16-byte chunk 0..15 of a 256-byte row
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <typename T, bool KV8 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void extend_attn_mfma32_kernel(
+    const T* __restrict__ q_ext, const T* __restrict__ k_ext, const T* __restrict__ v_ext, T* __restrict__ o_ext,
+    const T* __restrict__ kbuf, const T* __restrict__ vbuf, ExtendParams p, int nqb, int npairs) {
+  constexpr int D = 128;
+  using frag = typename Mfma32<T>::frag;
+  __shared__ __attribute__((aligned(16))) char ks[64 * 256];
+  __shared__ __attribute__((aligned(16))) char vs[64 * 256];
+
+  const int G = p.hq / p.hkv;
+  const int per_pair = G * nqb;
+  const int slot = blockIdx.x >> 3;
+  const int pair = (blockIdx.x & 7) + 8 * (slot / per_pair);
+  if (pair >= npairs) return;
+  const int t_in_pair = slot % per_pair;
+  const int qb = nqb - 1 - t_in_pair / G;          // long (late) blocks first
+  const int b = pair / p.hkv, kvh = pair % p.hkv, h = kvh * G + t_in_pair % G;
+  const int q_start = p.qo_indptr[b];
+  const int ext = p.qo_indptr[b + 1] - q_start;
+  const int kv_start = p.kv_indptr[b];
+  const int prefix = p.kv_indptr[b + 1] - kv_start;
+  const int r0 = qb * 128;
+  if (r0 >= ext) return;   // whole workgroup: EXEC stays full for the transposed reads below
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j32 = lane & 31, hh = lane >> 5;
+  const int qrow = r0 + wave * 32 + j32;                  // this lane's query (row of the extend part)
+  const int qrow_c = qrow < ext ? qrow : ext - 1;
+  const float qmul = p.sm_scale * kLog2eE;
+
+  // B operand of S^T: Q[qrow][16 s + 8 h + 0..7]
+  frag qf[8];
+  {
+    const T* qp = q_ext + (int64_t)(q_start + qrow_c) * p.q_stride + (int64_t)h * D + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
+  }
+
+  const int last_row = min(r0 + 127, ext - 1);
+  const int total = p.is_causal ? prefix + last_row + 1 : prefix + ext;
+  const int n_tiles = (total + 63) / 64;
+  const int my_limit = p.is_causal ? prefix + qrow_c : prefix + ext - 1;   // last visible key of this lane's query
+  const int wave_min_limit = p.is_causal ? prefix + min(r0 + wave * 32, ext - 1) : prefix + ext - 1;
+  const int wave_max_limit = p.is_causal ? prefix + min(r0 + wave * 32 + 31, ext - 1) : prefix + ext - 1;
+
+  // tile staging: thread -> rows (threadIdx.x >> 4) + 16 i, 16-B chunk (threadIdx.x & 15)
+  const int srow = threadIdx.x >> 4, sch = threadIdx.x & 15;
+  Vec<T, 8> kreg[4], vreg[4];
+  const T* k_lin = k_ext + (int64_t)(q_start - prefix + srow) * p.k_stride + (int64_t)kvh * D + sch * 8;
+  const T* v_lin = v_ext + (int64_t)(q_start - prefix + srow) * p.v_stride + (int64_t)kvh * D + sch * 8;
+  auto load_tile = [&](int kt) {
+    if (kt * 64 >= prefix && kt * 64 + 63 < total) {   // whole tile in the extend part (workgroup-uniform)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t key = kt * 64 + 16 * i;
+        kreg[i] = ldvec<T, 8>(k_lin + key * p.k_stride);
+        vreg[i] = ldvec<T, 8>(v_lin + key * p.v_stride);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = kt * 64 + srow + 16 * i;
+      key = key < total ? key : total - 1;
+      if (KV8 && key < prefix) {
+        const int64_t slot_ = p.kv_indices[kv_start + key];
+        const uint8_t* kp8 = reinterpret_cast<const uint8_t*>(kbuf) + (slot_ * p.hkv + kvh) * D + sch * 8;
+        const uint8_t* vp8 = reinterpret_cast<const uint8_t*>(vbuf) + (slot_ * p.hkv + kvh) * D + sch * 8;
+        kreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(kp8));
+        vreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(vp8));
+        continue;
+      }
+      const T *kp, *vp;
+      if (key < prefix) {
+        const int64_t slot_ = p.kv_indices[kv_start + key];
+        kp = kbuf + (slot_ * p.hkv + kvh) * D;
+        vp = vbuf + (slot_ * p.hkv + kvh) * D;
+      } else {
+        const int64_t tok = q_start + key - prefix;
+        kp = k_ext + tok * p.k_stride + (int64_t)kvh * D;
+        vp = v_ext + tok * p.v_stride + (int64_t)kvh * D;
+      }
+      kreg[i] = ldvec<T, 8>(kp + sch * 8);
+      vreg[i] = ldvec<T, 8>(vp + sch * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = xor_image_off(srow + 16 * i, sch);
+      *reinterpret_cast<Vec<T, 8>*>(ks + off) = kreg[i];
+      *reinterpret_cast<Vec<T, 8>*>(vs + off) = vreg[i];
+    }
+  };
+
+  f32x16 ot[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ot[dt][i] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  // K fragment of (32-key half hf, k-step s): row 32 hf + j32, chunk 2 s + h.  The XOR term depends on
+  // (row & 15) only, i.e. on the lane: chunk ^ fx = (2 s) ^ (h ^ fx).
+  const int fx = ((j32 & 3) << 2) | ((j32 >> 2) & 3);
+  const int kcx = hh ^ fx;
+  const char* k_rd = ks + 256 * j32;                        // + 8192 hf + 16 * ((2 s) ^ kcx)
+  // V^T fragment of (d tile dt, 16-key step u): lane group (l >> 4) = 2 h + dhalf serves features
+  // 32 dt + 16 dhalf + 0..15; lane 4 q + pp of the group supplies row 16 u (+ 8) + 4 h + q, features 4 pp..4 pp + 3
+  const int l16 = lane & 15, dhalf = (lane >> 4) & 1, tq = l16 >> 2, tpp = l16 & 3;
+  const int vrow = 4 * hh + tq;                             // + 16 u (+ 8): (row & 3) = tq, (row >> 2) & 3 = (h + 2 hi) & 3
+  const int vf_lo = (tq << 2) | (hh & 3), vf_hi = (tq << 2) | ((hh + 2) & 3);
+  const int vch = 2 * dhalf + (tpp >> 1);                   // + 4 dt
+  const char* v_rd = vs + 256 * vrow + 8 * (tpp & 1);
+
+  load_tile(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();            // previous tile fully consumed
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
+    if (kt * 64 > wave_max_limit) continue;   // every key of the tile is masked for every query of this wave (wave-uniform)
+
+    f32x16 st[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[hf][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int co = 16 * ((2 * s) ^ kcx);
+      const frag k0 = *reinterpret_cast<const frag*>(k_rd + co);
+      const frag k1 = *reinterpret_cast<const frag*>(k_rd + 8192 + co);
+      st[0] = Mfma32<T>::run(k0, qf[s], st[0]);
+      st[1] = Mfma32<T>::run(k1, qf[s], st[1]);
+    }
+    const bool need_mask = kt * 64 + 63 > wave_min_limit;   // wave-uniform
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float x = st[hf][i] * qmul;
+        if (need_mask && kt * 64 + 32 * hf + 8 * (i >> 2) + 4 * hh + (i & 3) > my_limit) x = -INFINITY;
+        st[hf][i] = x;
+        mloc = fmaxf(mloc, x);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m, mloc);
+    const float ms = mnew == -INFINITY ? 0.f : mnew;
+    const float alpha = raw_exp2(m - ms);
+    m = mnew;
+    float psum = 0.f;
+    frag pb[4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pe = raw_exp2(st[hf][i] - ms);
+        psum += pe;                          // fp32 weights in the denominator, T-rounded weights in P.V
+        pb[2 * hf + (i >> 3)][i & 7] = (T)pe;
+      }
+    lsum = lsum * alpha + psum;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ot[dt] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int ch = 4 * dt + vch;
+        const auto lo = TrRead<T>::run(reinterpret_cast<const T*>(v_rd + 256 * (16 * u) + 16 * (ch ^ vf_lo)));
+        const auto hi = TrRead<T>::run(reinterpret_cast<const T*>(v_rd + 256 * (16 * u + 8) + 16 * (ch ^ vf_hi)));
+        frag va;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          va[e] = lo[e];
+          va[4 + e] = hi[e];
+        }
+        ot[dt] = Mfma32<T>::run(va, pb[u], ot[dt]);
+      }
+  }
+
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (qrow < ext) {
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    T* op = o_ext + ((int64_t)(q_start + qrow) * p.hq + h) * D + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        Vec<T, 4> w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.v[r] = from_f32<T>(ot[dt][4 * rq + r] * inv);
+        stvec<T, 4>(op + 32 * dt + 8 * rq, w);
+      }
+  }
+}
+
 template <typename T, int DP, int BN>
 static int launch_extend_cfg(const void* q, const void* k, const void* v, void* o, const void* kb,
                              const void* vb, const ExtendParams& p, int64_t bs,
@@ -546,6 +770,12 @@ static int launch_extend_cfg(const void* q, const void* k, const void* v, void* 
   return MI355_OK;
 }
 
+// 0 = 32x32x16 tile (product), 1 = the 16x16x32 tile above (ablation; development build, mi355_debug_set key 8)
+#ifdef MI355_DEV_BUILD
+int g_extend_variant = 0;
+#else
+static constexpr int g_extend_variant = 0;
+#endif
 static thread_local bool g_ext_kv8 = false;   // fp8 KV cache, set by the entry point around one launch
 
 template <typename T>
@@ -558,6 +788,23 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
                    p.k_stride % VE == 0 && p.v_stride % VE == 0 && aligned16(q) && aligned16(k) &&
                    aligned16(v) && aligned16(o) && aligned16(kb) && aligned16(vb);
   if constexpr (!std::is_same<T, float>::value) {
+    if (vec && p.D == 128 && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 && p.logit_cap <= 0.f &&
+        g_extend_variant == 0) {
+      // 128 query rows of one head per workgroup; (sequence, kv head) pairs dealt round-robin to the XCDs
+      const int nqb = (int)((max_len_extend + 127) / 128);
+      const int64_t npairs = bs * p.hkv;
+      const int64_t wgs = 8 * ((npairs + 7) / 8) * (p.hq / p.hkv) * nqb;
+      if (wgs < (int64_t)1 << 31) {
+        const dim3 grid1((unsigned)wgs);
+        if (g_ext_kv8)
+          hipLaunchKernelGGL((extend_attn_mfma32_kernel<T, true>), grid1, dim3(256), 0, st, (const T*)q, (const T*)k,
+                             (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p, nqb, (int)npairs);
+        else
+          hipLaunchKernelGGL((extend_attn_mfma32_kernel<T, false>), grid1, dim3(256), 0, st, (const T*)q, (const T*)k,
+                             (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p, nqb, (int)npairs);
+        return MI355_OK;
+      }
+    }
     if (vec && p.D == 128 && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 && p.logit_cap <= 0.f) {
       const dim3 grid((unsigned)((max_len_extend + 63) / 64), (unsigned)p.hq, (unsigned)bs);
       if (g_ext_kv8)

@@ -220,6 +220,23 @@ template <> struct Mfma16<f16_t> {
   }
 };
 
+// v_mfma_f32_32x32x16 on 16-bit operands: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8 h + 0..7]
+// and B[k = 8 h + 0..7][col r]; result register i of lane l is D[row (i & 3) + 8 (i >> 2) + 4 h][col r].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename T> struct Mfma32;
+template <> struct Mfma32<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma32<f16_t> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
 // fp8 (OCP e4m3fn): a 16-byte fragment feeds TWO k = 32 steps -- within a 64-wide K block lane
 // group c owns bytes [16c, 16c + 16) and step h uses its bytes [8h, 8h + 8); the other operand
 // uses the same map, so products pair up.

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 // they are compile-time zeros, so the library carries no process-global mutable state.
 #ifdef MI355_DEV_BUILD
 extern int g_decode_variant;
+extern int g_extend_variant;
 int g_gemm_variant = 0;
 int g_force_splits = 0;
 #else
@@ -824,7 +825,8 @@ void mi355_debug_set(int key, int value) {
   if (key == 0) g_gemm_variant = value;   // 0 = ring kernel (default), 1 = two-launch kernel
   if (key == 2) g_force_splits = value;   // > 0 overrides the split-K plan
   if (key == 4) g_force_waves = value;    // 4 | 6 | 7 | 8 overrides the tiles-per-workgroup plan
-  if (key == 6) g_decode_variant = value; // decode attention P.V: 0 = on MFMA (default), 1 = on the vector ALU
+  if (key == 6) g_decode_variant = value; // decode attention: 0 = product, 1 = P.V on the vector ALU, 3 = K rows straight into fragments
+  if (key == 8) g_extend_variant = value; // prefill attention: 0 = 32x32x16 tile (product), 1 = 16x16x32 tile
 }
 #endif
 

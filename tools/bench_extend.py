@@ -1,8 +1,11 @@
 """Dev tool: prefill (extend) attention at the bench shape: 64 x 1024 tokens, 32q/8kv x 128, causal."""
 import sys, torch
 sys.path.insert(0, '.')
-from sglang_custom_amd import ops
-bs, L, hq, hkv, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 1024, 32, 8, 128
+import ctypes
+from sglang_custom_amd import ops, _lib
+_lib.use_dev_library()   # ablation switches live in the development build only
+lib = _lib.load()
+bs, L, hq, hkv, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 32, 8, 128
 torch.manual_seed(0)
 T = bs * L
 q = torch.randn(T, hq, D, device='cuda').bfloat16()
@@ -14,18 +17,19 @@ qo = torch.arange(0, T + 1, L, dtype=torch.int32, device='cuda')
 kvi = torch.zeros(bs + 1, dtype=torch.int32, device='cuda'); kidx = torch.zeros(1, dtype=torch.int32, device='cuda')
 def run():
     ops.extend_attention_fwd(q, k, v, o, kb, vb, qo, kvi, kidx, None, True, None, L, D ** -0.5)
-run(); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5): run()
-e1.record(); torch.cuda.synchronize()
-t = e0.elapsed_time(e1) / 5
-flops = 4 * bs * hq * D * L * L / 2
-print(f"extend attention bs={bs} L={L}: {t:.3f} ms  {flops / t / 1e9:.1f} TFLOP/s")
-# check a few sequences against SDPA
 import torch.nn.functional as F
-for b in (0, bs - 1):
-    qq = q[b * L:(b + 1) * L].transpose(0, 1).float(); kk = k[b * L:(b + 1) * L].transpose(0, 1).float(); vv = v[b * L:(b + 1) * L].transpose(0, 1).float()
-    ref = F.scaled_dot_product_attention(qq[None], kk[None], vv[None], is_causal=True, enable_gqa=True)[0].transpose(0, 1)
-    err = (o[b * L:(b + 1) * L].float() - ref).abs().max().item()
-    print(f"seq {b}: max err vs SDPA fp32 = {err:.4f}")
+for variant, name in ((1, "16x16x32 tile, 64 rows per workgroup (ablation)"), (0, "32x32x16 tile, 128 rows per workgroup (product)")):
+    lib.mi355_debug_set(8, variant)
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): run()
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 5
+    flops = 4 * bs * hq * D * L * L / 2
+    print(f"{name}: bs={bs} L={L}: {t:.3f} ms  {flops / t / 1e9:.1f} TFLOP/s", flush=True)
+    for b in (0, bs - 1):   # a few sequences against SDPA
+        qq = q[b * L:(b + 1) * L].transpose(0, 1).float(); kk = k[b * L:(b + 1) * L].transpose(0, 1).float(); vv = v[b * L:(b + 1) * L].transpose(0, 1).float()
+        ref = F.scaled_dot_product_attention(qq[None], kk[None], vv[None], is_causal=True, enable_gqa=True)[0].transpose(0, 1)
+        err = (o[b * L:(b + 1) * L].float() - ref).abs().max().item()
+        print(f"   seq {b}: max err vs SDPA fp32 = {err:.4f}", flush=True)
