@@ -90,12 +90,16 @@ _DEV_SIGNATURES = {
 _use_dev = False
 
 
-def use_dev_library() -> None:
+def use_dev_library(path: str = None) -> None:
     """Tools only: load libmi355_hotpath_dev.so (ablation switches + bandwidth probes) instead of the
-    product library.  Must be called before the first load()."""
-    global _use_dev
+    product library; `path` names another development build (an A/B of two source trees).  Must be
+    called before the first load()."""
+    global _use_dev, _dev_path
     assert _lib is None, "use_dev_library() must come before the library is loaded"
     _use_dev = True
+    _dev_path = path
+
+_dev_path = None
 
 _lib = None
 
@@ -110,7 +114,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = LIB_PATH.replace("libmi355_hotpath.so", "libmi355_hotpath_dev.so") if _use_dev else LIB_PATH
+    path = (_dev_path or LIB_PATH.replace("libmi355_hotpath.so", "libmi355_hotpath_dev.so")) if _use_dev else LIB_PATH
     if not os.path.exists(path):
         raise Mi355Error(
             f"{path} not found: build it with `python -m sglang_custom_amd.build{' --dev' if _use_dev else ''}` "

@@ -679,19 +679,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       st[0] = Mfma32<T>::run(k0, qf[s], st[0]);
       st[1] = Mfma32<T>::run(k1, qf[s], st[1]);
     }
-    const bool need_mask = kt * 64 + 63 > wave_min_limit;   // wave-uniform
+    // Softmax on the raw scores: the scale (sm_scale * log2 e > 0, checked by the launcher) commutes with
+    // the maximum and folds into the exponent's multiply-add.  Only tiles that cross the wave's diagonal
+    // pay for masking (two instructions per score: the key offsets within a tile are compile-time
+    // constants, the lane's limit is one subtraction per tile); the branch is wave-uniform.
     float mloc = -INFINITY;
+    if (kt * 64 + 63 > wave_min_limit) {
+      const int lim = my_limit - kt * 64 - 4 * hh;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+      for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float x = st[hf][i] * qmul;
-        if (need_mask && kt * 64 + 32 * hf + 8 * (i >> 2) + 4 * hh + (i & 3) > my_limit) x = -INFINITY;
-        st[hf][i] = x;
-        mloc = fmaxf(mloc, x);
-      }
+        for (int i = 0; i < 16; ++i) {
+          const float x = (32 * hf + 8 * (i >> 2) + (i & 3)) > lim ? -INFINITY : st[hf][i];
+          st[hf][i] = x;
+          mloc = fmaxf(mloc, x);
+        }
+    } else {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[hf][i]);
+    }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float mnew = fmaxf(m, mloc);
+    const float mnew = fmaxf(m, mloc * qmul);
     const float ms = mnew == -INFINITY ? 0.f : mnew;
     const float alpha = raw_exp2(m - ms);
     m = mnew;
@@ -701,7 +711,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pe = raw_exp2(st[hf][i] - ms);
+        const float pe = raw_exp2(__builtin_fmaf(st[hf][i], qmul, -ms));
         psum += pe;                          // fp32 weights in the denominator, T-rounded weights in P.V
         pb[2 * hf + (i >> 3)][i & 7] = (T)pe;
       }
@@ -789,7 +799,7 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
                    aligned16(v) && aligned16(o) && aligned16(kb) && aligned16(vb);
   if constexpr (!std::is_same<T, float>::value) {
     if (vec && p.D == 128 && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 && p.logit_cap <= 0.f &&
-        g_extend_variant == 0) {
+        p.sm_scale > 0.f && g_extend_variant == 0) {   // the 32x32 kernel takes the maximum of unscaled scores
       // 128 query rows of one head per workgroup; (sequence, kv head) pairs dealt round-robin to the XCDs
       const int nqb = (int)((max_len_extend + 127) / 128);
       const int64_t npairs = bs * p.hkv;

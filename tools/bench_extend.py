@@ -1,9 +1,9 @@
 """Dev tool: prefill (extend) attention at the bench shape: 64 x 1024 tokens, 32q/8kv x 128, causal."""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, '.')
 import ctypes
 from sglang_custom_amd import ops, _lib
-_lib.use_dev_library()   # ablation switches live in the development build only
+_lib.use_dev_library(os.environ.get('MI355_AB_LIB'))   # MI355_AB_LIB: a development build of another source tree; ablation switches live in the development build only
 lib = _lib.load()
 bs, L, hq, hkv, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 32, 8, 128
 torch.manual_seed(0)
@@ -20,12 +20,13 @@ def run():
 import torch.nn.functional as F
 for variant, name in ((1, "16x16x32 tile, 64 rows per workgroup (ablation)"), (0, "32x32x16 tile, 128 rows per workgroup (product)")):
     lib.mi355_debug_set(8, variant)
-    run(); torch.cuda.synchronize()
+    for _ in range(30): run()   # clocks settle: a cold GPU times the same kernel 20-30 % slower
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): run()
+    for _ in range(30): run()
     e1.record(); torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / 5
+    t = e0.elapsed_time(e1) / 30
     flops = 4 * bs * hq * D * L * L / 2
     print(f"{name}: bs={bs} L={L}: {t:.3f} ms  {flops / t / 1e9:.1f} TFLOP/s", flush=True)
     for b in (0, bs - 1):   # a few sequences against SDPA
