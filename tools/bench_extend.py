@@ -1,6 +1,6 @@
 """Dev tool: prefill (extend) attention at the bench shape: 64 x 1024 tokens, 32q/8kv x 128, causal."""
 import os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
 from sglang_custom_amd import ops, _lib
 _lib.use_dev_library(os.environ.get('MI355_AB_LIB'))   # MI355_AB_LIB: a development build of another source tree; ablation switches live in the development build only
