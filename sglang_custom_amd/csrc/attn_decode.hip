@@ -1211,6 +1211,233 @@ __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __re
   (void)inv;
 }
 
+// ------------------------------------------------------------------------------------------
+// MLA decode, latent rows landed in LDS by the load unit itself (global_load_lds_dwordx4: no
+// register destination).  The register version above keeps two 16-key tiles in 144 registers next
+// to 128 accumulators: one workgroup per CU, and everything a workgroup does before its first row
+// arrives (sequence bounds -> page table -> rows: three dependent trips to memory) or after its
+// last one (the four waves' merge) leaves the CU's memory pipe idle, 0.47 of the HBM peak.  Here:
+//   * a ring of 4 tiles x 16 keys in LDS; a step consumes two tiles while the next two (36 KiB per
+//     workgroup) are in flight; 74 KiB of LDS and 150 registers -> two workgroups per CU, so one
+//     workgroup's start-up and steps overlap the other's loads;
+//   * all four waves compute the (cheap) 32 x 16 scores of a step redundantly, so they agree on the
+//     softmax statistics bit for bit, and each accumulates ONE quarter of the 512 value features:
+//     32 accumulator registers per lane, the 18 query fragments stay in registers, and there is no
+//     cross-wave merge at the end;
+//   * page-table entries come through the scalar unit (they are wave-uniform: a 1-KiB load
+//     instruction fetches the first 1024 bytes of ONE row, addressed as scalar base + 16 * lane), so
+//     the vector-memory counter counts nothing but tile loads.
+// LDS image of a tile: row r's 512 latent features at 1056 r (1024 + 32 bytes of padding: the
+// A-fragment reads (ds_read_b128) and the transposed value reads are both conflict-free), then the
+// rows' 64 rope features as [16][128 bytes] with the 16-byte chunk index XOR-ed by (r >> 1) & 7 on
+// the SOURCE address and again on the read (the load unit writes lane-linear).
+// A wave issues 5 loads per tile: rows 4 w .. 4 w + 3 (1 KiB each) and their rope parts (half a wave).
+// grid (ceil(hq / 16), num_splits, B), block 256.
+// ------------------------------------------------------------------------------------------
+constexpr int MLR_ROWB = 1056;                       // bytes between rows' latent parts
+constexpr int MLR_TAIL = 16 * MLR_ROWB;              // byte offset of the rope parts
+constexpr int MLR_TILE = MLR_TAIL + 16 * 128;        // 18944
+constexpr int MLR_NBUF = 4;
+constexpr int MLR_LDS_BYTES = MLR_NBUF * MLR_TILE;   // 75776
+
+__device__ __forceinline__ unsigned lds_byte_address(const void* p) {
+  return (unsigned)(uintptr_t)(const char __attribute__((address_space(3)))*)(p);
+}
+
+// One wave-wide load of 16 bytes per active lane to LDS at `lds_base` (wave-uniform) + 16 * lane.
+// M0 carries the LDS base; it is saved and restored inside the statement.
+//   _v: per-lane 64-bit source address; _s: wave-uniform 64-bit base + per-lane 32-bit byte offset.
+__device__ __forceinline__ void load_to_lds_16_v(const void* src, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ void load_to_lds_16_s(uint64_t base, unsigned lane_off, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_off), "s"(base), "s"(lds_base)
+      : "memory");
+}
+
+template <typename T, bool CAP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decode_attn_mla_ring_kernel(
+    const T* __restrict__ q, const T* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p) {
+  constexpr int NS = MLA_D / 32;   // 18 score k-steps
+  using frag = typename Mfma<T>::frag;
+  using frag4 = typename Mfma16<T>::frag;
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // MLR_LDS_BYTES
+
+  const int head0 = blockIdx.x * 16, split = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, c4 = lane >> 4;
+
+  int64_t page_off, len;
+  seq_range(p, b, page_off, len);
+  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t k0 = (int64_t)split * chunk;
+  const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
+  const int n_steps = k1 > k0 ? (int)((k1 - k0 + 31) / 32) : 0;   // 32 keys (two tiles) per step
+  const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  // page-table reads through the scalar unit (wave-uniform index, read-only data)
+  const int32_t __attribute__((address_space(4)))* pt =
+      (const int32_t __attribute__((address_space(4)))*)(p.page_table + page_off);
+  const int64_t last_key = len - 1;
+  struct Slots { int32_t a0, a1, a2, a3, b0, b1, b2, b3; };   // rows 4 wave .. + 3 of a step's two tiles
+  auto slot_of = [&](int64_t key) -> int32_t { return pt[key < last_key ? key : last_key]; };
+  auto slots_of = [&](int step) -> Slots {
+    const int64_t key = k0 + (int64_t)step * 32 + 4 * wave;
+    return Slots{slot_of(key), slot_of(key + 1), slot_of(key + 2), slot_of(key + 3),
+                 slot_of(key + 16), slot_of(key + 17), slot_of(key + 18), slot_of(key + 19)};
+  };
+  const unsigned ring = lds_byte_address(sm_raw);
+  const uint64_t kv_base = (uint64_t)(uintptr_t)kvbuf;
+  const uint64_t row_bytes = (uint64_t)p.k_slot_stride * sizeof(T);
+  const unsigned lane16 = 16u * lane;
+  const int trow = lane >> 3, tch = lane & 7;   // rope part: lane (row 4 wave + trow (lanes 0..31), chunk tch)
+  const unsigned tsw = MLA_RANK * sizeof(T) + 16 * (tch ^ (((4 * wave + trow) >> 1) & 7));   // byte offset of the chunk this lane fetches
+  const int tm0 = -(int)(trow == 0), tm1 = -(int)(trow == 1), tm2 = -(int)(trow == 2), tm3 = -(int)(trow == 3);
+  auto issue_tile = [&](int buf, int32_t s0, int32_t s1, int32_t s2, int32_t s3) {
+    const unsigned base = ring + (unsigned)buf * MLR_TILE + (unsigned)(4 * wave) * MLR_ROWB;
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s0 * row_bytes, lane16, base);
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s1 * row_bytes, lane16, base + MLR_ROWB);
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s2 * row_bytes, lane16, base + 2 * MLR_ROWB);
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s3 * row_bytes, lane16, base + 3 * MLR_ROWB);
+    // row trow's slot by masks (a chain of selects would be turned into an indexed array in scratch memory)
+    const uint32_t ts = (uint32_t)((s0 & tm0) | (s1 & tm1) | (s2 & tm2) | (s3 & tm3));
+    if (lane < 32)
+      load_to_lds_16_v(reinterpret_cast<const char*>(kvbuf) + (uint64_t)ts * row_bytes + tsw,
+                       ring + (unsigned)buf * MLR_TILE + MLR_TAIL + (unsigned)(4 * wave) * 128);
+  };
+  auto issue_step = [&](int step, const Slots& sl) {
+    const int buf = 2 * (step & 1);
+    issue_tile(buf, sl.a0, sl.a1, sl.a2, sl.a3);
+    issue_tile(buf + 1, sl.b0, sl.b1, sl.b2, sl.b3);
+  };
+
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // read addresses inside a tile (bytes)
+  const int k_rd = MLR_ROWB * r16 + 16 * c4;                                          // + 64 s
+  const int kt_rd0 = MLR_TAIL + 128 * r16 + 16 * (c4 ^ ((r16 >> 1) & 7));             // rope k-step 16
+  const int kt_rd1 = MLR_TAIL + 128 * r16 + 16 * ((4 + c4) ^ ((r16 >> 1) & 7));       // rope k-step 17
+  const int v_rd = MLR_ROWB * (4 * c4 + (r16 >> 2)) + 8 * (r16 & 3) + 256 * wave;    // + 32 dt
+
+  Slots s_nxt{};
+  if (n_steps > 0) {   // (an empty sequence has no page-table entry to read)
+    s_nxt = slots_of(0);
+    issue_step(0, s_nxt);
+    s_nxt = slots_of(1);   // clamped to the last key when past the end
+  }
+
+  // B operand of the scores: this lane's head (r16), features 32 s + 8 c4 .. + 7.  Fetched AFTER the first
+  // tiles were requested, and waited for here, before the loop: the compiler does not count the
+  // loads-to-LDS, and a wait for these fragments placed inside the loop would drain the ring every step.
+  frag qf[NS];
+  {
+    const int hq_c = head0 + r16 < p.hq ? head0 + r16 : p.hq - 1;   // rows of heads past hq are computed and dropped
+    const T* qp = q + (int64_t)b * p.q_stride + (int64_t)hq_c * MLA_D + 8 * c4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 32 * s);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(qf[s]));
+  }
+
+  for (int t = 0; t < n_steps; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of step t has landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its reads of step t - 1 have returned
+    __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's tiles are free
+    if (t + 1 < n_steps) issue_step(t + 1, s_nxt);
+    s_nxt = slots_of(t + 2);
+
+    const char* tile = sm_raw + 2 * (t & 1) * MLR_TILE;
+    f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      sa = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + k_rd + 64 * s), qf[s], sa);
+      sb = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + MLR_TILE + k_rd + 64 * s), qf[s], sb);
+    }
+    sa = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + kt_rd0), qf[16], sa);
+    sb = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + MLR_TILE + kt_rd0), qf[16], sb);
+    sa = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + kt_rd1), qf[17], sa);
+    sb = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + MLR_TILE + kt_rd1), qf[17], sb);
+
+    const int64_t kb0 = k0 + (int64_t)t * 32 + 4 * c4;
+    float x[8], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float v = (r < 4 ? sa[r & 3] : sb[r & 3]) * qmul;
+      if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
+      x[r] = kb0 + (r & 3) + 16 * (r >> 2) < k1 ? v : -INFINITY;
+      mx = fmaxf(mx, x[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // lazy rescale, as in the register kernel: the reference point moves only when a step's maximum exceeds it by 2^8
+    const bool need = mx > m + 8.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+      const float mnew = need ? mx : m;
+      const float alpha = exp2f(m - safe_m(mnew));
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) acc[dt] *= alpha;
+      m = mnew;
+    }
+    const float ms = safe_m(m);
+    float psum = 0.f;
+    T pa4[4], pb4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pa = exp2f(x[r] - ms), pb = exp2f(x[4 + r] - ms);
+      psum += pa + pb;
+      pa4[r] = from_f32<T>(pa);
+      pb4[r] = from_f32<T>(pb);
+    }
+    l += psum;
+    const frag4 pa = __builtin_bit_cast(frag4, pa4), pb = __builtin_bit_cast(frag4, pb4);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const auto va = TrRead<T>::run(reinterpret_cast<const T*>(tile + v_rd + 32 * dt));
+      const auto vb = TrRead<T>::run(reinterpret_cast<const T*>(tile + MLR_TILE + v_rd + 32 * dt));
+      acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, va), pa, acc[dt]);
+      acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, vb), pb, acc[dt]);
+    }
+  }
+
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (head0 + r16 < p.hq) {
+    const int head = head0 + r16;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    // lane (head r16, c4) holds features 128 wave + 16 dt + 4 c4 .. + 3
+    if (p.num_splits == 1) {
+      T* dst = o + ((int64_t)b * p.hq + head) * MLA_RANK + 128 * wave + 4 * c4;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        Vec<T, 4> w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.v[r] = from_f32<T>(acc[dt][r] * inv);
+        stvec<T, 4>(dst + 16 * dt, w);
+      }
+    } else {
+      const int64_t ph = ((int64_t)b * p.hq + head) * p.num_splits + split;
+      float* dst = p.part_o + ph * MLA_RANK + 128 * wave + 4 * c4;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(dst + 16 * dt) = acc[dt] * inv;
+      if (c4 == 0 && wave == 0) p.part_lse[ph] = l > 0.f ? m * kLn2 + logf(l) : -INFINITY;
+    }
+  }
+}
+
 // Stage 2: o[b,h,:] = sum_s w_s * part_o[b,h,s,:], w_s = exp(lse_s - lse_total).
 // grid (B*Hq), block 128.
 template <typename T>
@@ -1625,8 +1852,24 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   p.v_slot_stride = D;
   hipStream_t st = (hipStream_t)stream;
   if (kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
-      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && g_decode_variant == 0) {
+      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && (g_decode_variant == 0 || g_decode_variant == 2)) {
     const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)num_splits, (unsigned)bs);
+    if (g_decode_variant == 0 && aligned16(attn_logits)) {   // rows through the LDS ring (2 = the register kernel, for ablation)
+#define MLR_LAUNCH(T_, CAP_)                                                                                   \
+  do {                                                                                                         \
+    auto kern = decode_attn_mla_ring_kernel<T_, CAP_>;                                                         \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MLR_LDS_BYTES);   \
+    hipLaunchKernelGGL(kern, grid, dim3(256), MLR_LDS_BYTES, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p); \
+    if (num_splits > 1)                                                                                        \
+      hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
+                         p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
+  } while (0)
+      if (dtype == MI355_BF16) { if (logit_cap > 0.f) MLR_LAUNCH(bf16_t, true); else MLR_LAUNCH(bf16_t, false); }
+      else { if (logit_cap > 0.f) MLR_LAUNCH(f16_t, true); else MLR_LAUNCH(f16_t, false); }
+#undef MLR_LAUNCH
+      MI355_CHECK_LAUNCH("decode_attention_mla");
+      return MI355_OK;
+    }
 #define MLA_LAUNCH(T_, CAP_)                                                                                   \
   do {                                                                                                         \
     auto kern = decode_attn_mla_mfma_kernel<T_, CAP_>;                                                         \

@@ -1,8 +1,8 @@
 """MLA decode attention micro-benchmark (DeepSeek-V3 TP=8 shard: 16 heads, latent 512 + 64 rope)."""
-import ctypes, sys, torch
-sys.path.insert(0, '.')
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_custom_amd import ops, _lib
-_lib.use_dev_library()   # ablation switches and probes live in the development build only
+_lib.use_dev_library(os.environ.get('MI355_AB_LIB'))   # MI355_AB_LIB: a development build of another source tree; ablation switches and probes live in the development build only
 lib = _lib.load()
 bs, H, ctx = 64, 16, 4096
 if len(sys.argv) > 3: bs, H, ctx = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
@@ -35,10 +35,11 @@ K = kv[0][r2t[:nb].long(), 0].float()
 s = torch.einsum('bhd,bkd->bhk', q[:nb].float(), K) * D ** -0.5
 ref = torch.einsum('bhk,bkd->bhd', s.softmax(-1), K[..., :rank])
 nbytes = bs * ctx * D * 2
-for dbg in (1, 0):
-    lib.mi355_debug_set(6, dbg)   # 1 = generic wave-per-head kernel, 0 = MFMA kernel
+for dbg in (1, 2, 0):
+    lib.mi355_debug_set(6, dbg)   # 1 = generic wave-per-head kernel, 2 = MFMA kernel with rows in registers, 0 = rows through the LDS ring (product)
     for ns in (1, 2, 4, 8):
         if dbg == 1 and ns not in (1, 4): continue
+        if len(sys.argv) > 4 and ns != int(sys.argv[4]): continue
         ops.decode_attention_mla(q, kv[0], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5)
         err = (o[:nb].float() - ref).abs().max().item()
         t = timeit(lambda i: ops.decode_attention_mla(q, kv[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5))
