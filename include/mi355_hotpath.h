@@ -79,6 +79,12 @@ int mi355_prefetch_next(const void* w_packed, int64_t m, int64_t n, int64_t k, i
 int mi355_silu_and_mul(void* out, const void* x, int64_t rows, int64_t d, int dtype,
                        void* stream);
 
+/* ---- K12 epilogue: final-logit soft cap ---------------------------------------------------
+ * logits[i] <- cap * tanh(logits[i] / cap), in place on n contiguous fp32 values, cap > 0.
+ * replaces: fused_softcap / fused_softcap_kernel (python/sglang/srt/layers/logits_processor.py:579-618),
+ *           called from LogitsProcessor._get_logits (:492-493). */
+int mi355_softcap_inplace(float* logits, int64_t n, float cap, void* stream);
+
 /* ---- K9 (+K7) RoPE from a cos|sin cache, in place, optional fused KV-cache write ----------
  * q: [T, Hq, D] view with row stride q_stride; k: [T, Hkv, D] with k_stride; rotates the first
  * rotary_dim of every head with cos_sin_cache[positions[t]] ([max_pos, rotary_dim], first half

@@ -26,6 +26,17 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     return F.silu(x[..., :d]) * x[..., d:]
 
 
+# ---- layers/logits_processor.py:579-604 fused_softcap_kernel ----------------------------------
+# The reference's kernel is Triton (no CPU build of it exists): this is its arithmetic restated in
+# fp32, x / cap -> (e^{2x} - 1) / (e^{2x} + 1) -> * cap; parity unpinned by reference outputs, the
+# tests also hold it to torch.tanh in fp64.  Where e^{2x} overflows fp32 (|x / cap| > 44) the
+# reference's quotient is inf / inf; this restatement returns the limit, +cap.
+def softcap(x: torch.Tensor, cap: float) -> torch.Tensor:
+    y = x.float() / cap
+    e = torch.exp(torch.clamp(2 * y, max=40.0))
+    return (e - 1) / (e + 1) * cap
+
+
 # ---- layers/rotary_embedding.py:113-136 cache, :806-827 llama3 inverse frequencies -----------
 def rope_inv_freq(rotary_dim: int, base: float, llama3: Optional[dict] = None) -> torch.Tensor:
     inv = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))

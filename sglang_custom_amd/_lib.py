@@ -23,6 +23,7 @@ _SIGNATURES = {
     "mi355_rmsnorm": (I, [P, P, P, L, L, L, L, F, I, P]),
     "mi355_fused_add_rmsnorm": (I, [P, P, P, L, L, F, I, P]),
     "mi355_silu_and_mul": (I, [P, P, L, L, I, P]),
+    "mi355_softcap_inplace": (I, [P, L, F, P]),
     "mi355_rope_inplace": (I, [P, P, P, P, P, I, L, I, I, I, I, L, L, L, I, P, P, P, I, L, I, P]),
     "mi355_set_kv_buffer": (I, [P, P, P, P, P, I, L, L, L, L, L, L, I, P]),
     "mi355_embedding": (I, [P, P, P, L, L, L, L, I, P]),

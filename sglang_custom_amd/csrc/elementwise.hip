@@ -276,6 +276,27 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(T* __restrict__ out,
   }
 }
 
+// Final-logit soft cap, in place on fp32 logits: x <- cap * tanh(x / cap), with tanh written as
+// (e^{2y} - 1) / (e^{2y} + 1) the way the reference's kernel writes it
+// (python/sglang/srt/layers/logits_processor.py:579-604).  The exponent is clamped at 40: beyond
+// |y| = 10 the quotient is +-1 in fp32, and without the clamp e^{2y} overflows to inf / inf.
+__device__ __forceinline__ float softcap_one(float x, float cap) {
+  const float y = fminf(2.f * (x / cap), 40.f);
+  const float e = expf(y);
+  return (e - 1.f) / (e + 1.f) * cap;
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void softcap_kernel(float* __restrict__ x, int64_t n, float cap) {
+  constexpr int VE = VEC ? 4 : 1;
+  const int64_t total = n / VE;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    Vec<float, VE> v = ldvec<float, VE>(x + i * VE);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) v.v[j] = softcap_one(v.v[j], cap);
+    stvec<float, VE>(x + i * VE, v);
+  }
+}
+
 // SiLU-and-mul fused with the per-token fp8 quantisation of its output (the activation of an fp8
 // down projection): one workgroup per row, the row stays in registers between the activation, the
 // absmax and the conversion.  d % 8 == 0, d <= 16384 (1024 threads x 2 vectors of 8).  Same values as silu_and_mul followed by
@@ -677,6 +698,21 @@ int mi355_silu_and_mul(void* out, const void* x, int64_t rows, int64_t d, int dt
                          (hipStream_t)stream, (T*)out, (const T*)x, rows, d);
   });
   MI355_CHECK_LAUNCH("silu_and_mul");
+  return MI355_OK;
+}
+
+int mi355_softcap_inplace(float* logits, int64_t n, float cap, void* stream) {
+  MI355_REQUIRE(logits || n == 0, MI355_ERR_INVALID, "softcap_inplace: null pointer");
+  MI355_REQUIRE(n >= 0 && cap > 0.f, MI355_ERR_INVALID, "softcap_inplace: bad size / cap");
+  if (n == 0) return MI355_OK;
+  const bool vec = n % 4 == 0 && aligned16(logits);
+  const int64_t items = vec ? n / 4 : n;
+  const int grid = (int)std::min<int64_t>((items + 255) / 256, 256 * 16);
+  if (vec)
+    hipLaunchKernelGGL((softcap_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, n, cap);
+  else
+    hipLaunchKernelGGL((softcap_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, n, cap);
+  MI355_CHECK_LAUNCH("softcap_inplace");
   return MI355_OK;
 }
 

@@ -1,6 +1,7 @@
 """LogitsProcessor: last-token gather -> lm_head GEMM -> (TP all-gather) -> fp32 logits.
 Mirrors python/sglang/srt/layers/logits_processor.py:230-270 (which rows), :453-455 (matmul in
-the weight dtype), :464-477 (all-gather), :490 (slice to vocab, .float())."""
+the weight dtype), :464-477 (all-gather), :490 (slice to vocab, .float()), :217-224 and :492-493
+(final_logit_softcapping: negative = off; applied to the fp32 logits in place)."""
 import dataclasses
 from typing import Optional
 
@@ -31,6 +32,8 @@ class LogitsProcessor(nn.Module):
         self.config = config
         self.logit_scale = logit_scale
         self.do_tensor_parallel_all_gather = get_tensor_model_parallel_world_size() > 1
+        cap = getattr(config, "final_logit_softcapping", None)
+        self.final_logit_softcapping = None if (cap is not None and cap < 0) else cap
 
     def forward(self, input_ids, hidden_states, lm_head, forward_batch) -> LogitsProcessorOutput:
         ops = get_ops()
@@ -41,6 +44,10 @@ class LogitsProcessor(nn.Module):
             last_index = torch.cumsum(forward_batch.extend_seq_lens, dim=0, dtype=torch.int64) - 1
             pruned = ops.embedding(last_index, hidden_states.contiguous())  # row gather
         logits = self._get_logits(pruned, lm_head)
+        if self.final_logit_softcapping:
+            if not logits.is_contiguous():   # a vocab-sliced view of padded logits
+                logits = logits.contiguous()
+            ops.softcap_inplace(logits, self.final_logit_softcapping)
         return LogitsProcessorOutput(next_token_logits=logits)
 
     def _get_logits(self, hidden_states: torch.Tensor, lm_head) -> torch.Tensor:

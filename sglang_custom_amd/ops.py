@@ -97,6 +97,16 @@ def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     return out
 
 
+def softcap_inplace(logits: torch.Tensor, cap: float) -> torch.Tensor:
+    """fused_softcap(full_logits, final_logit_softcapping) (logits_processor.py:607-618): in place,
+    fp32, logits <- cap * tanh(logits / cap)."""
+    _gpu(logits)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and cap > 0
+    check(_lib_().mi355_softcap_inplace(logits.data_ptr(), logits.numel(), float(cap), _stream(logits)),
+          "softcap_inplace")
+    return logits
+
+
 # ---------------------------------------------------------------------------------- rope / kv
 def rope_inplace(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, head_size: int,
                  cos_sin_cache: torch.Tensor, is_neox: bool, v: Optional[torch.Tensor] = None,

@@ -32,6 +32,11 @@ def silu_and_mul(x, out=None):
     return out
 
 
+def softcap_inplace(logits, cap):
+    logits.copy_(ops_ref.softcap(logits, cap))
+    return logits
+
+
 def rope_inplace(positions, q, k, head_size, cos_sin_cache, is_neox, v=None, k_buffer=None,
                  v_buffer=None, loc=None):
     qn, kn = ops_ref.apply_rope(positions, q, k, head_size, cos_sin_cache, is_neox)

@@ -38,7 +38,7 @@ def _inputs(case, world, count, dtype):
     return [(torch.randn(count, generator=g) * (r + 1)).to(dtype) for r in range(world)]
 
 
-def _rank_main(rank, world, port, queue):
+def _rank_main(rank, world, port, queue, one_gpu_per_rank=False):
     try:
         import torch
         import torch.distributed as dist
@@ -47,8 +47,9 @@ def _rank_main(rank, world, port, queue):
         from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
 
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-        torch.cuda.set_device(0)
-        ca = CustomAllreduce(dist.group.WORLD, 0, max_size=MAX_BYTES)
+        dev = rank if one_gpu_per_rank else 0
+        torch.cuda.set_device(dev)
+        ca = CustomAllreduce(dist.group.WORLD, dev, max_size=MAX_BYTES)
         assert not ca.disabled
         case = 0
         for dtn in DTYPES:
@@ -323,6 +324,122 @@ def test_all_reduce_ranks_on_one_gpu(world):
             if p.is_alive():
                 p.kill()
     assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in sorted(results.items()))
+
+
+def _ops_rank_main(rank, world, port, queue, one_gpu_per_rank=False):
+    """The reference's CustomAllreduce HIP branch, call for call (custom_all_reduce.py:282-300, :384-393,
+    :439-450, :500-506), against the op-set module; integer-valued inputs, so the sum is exact in every
+    dtype and must equal the gloo sum bit for bit (as test/srt/test_custom_allreduce.py:58-170 compares
+    with NCCL)."""
+    try:
+        import torch
+        import torch.distributed as dist
+
+        from sglang_custom_amd.distributed.device_communicators import custom_all_reduce_ops as ops
+
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        dev = rank if one_gpu_per_rank else 0
+        torch.cuda.set_device(dev)
+
+        def gather(shard):
+            data = [[None, None] for _ in range(world)]
+            data[rank] = list(shard)
+            for i in range(world):
+                dist.broadcast_object_list(data[i], src=i, device="cpu")
+            return [d[0] for d in data], [d[1] for d in data]
+
+        max_size = 1 << 20
+        meta = ops.allocate_meta_buffer(ops.meta_size() + max_size)
+        assert meta.is_cuda and meta.dtype == torch.uint8 and meta.numel() >= ops.meta_size() + max_size
+        assert int(meta.max()) == 0
+        buffer = torch.empty(max_size, dtype=torch.uint8, device="cuda")
+        handles, offsets = gather((bytes(ops.get_meta_buffer_ipc_handle(meta)), 0))
+        rank_data = torch.empty(1024, dtype=torch.uint8, device="cuda")
+        fa = ops.init_custom_ar(meta, rank_data, handles, offsets, rank, True)
+        bh, bo = gather((bytes(ops.get_meta_buffer_ipc_handle(meta)), 0))
+        ops.register_buffer(fa, buffer, bh, bo)
+        dist.barrier()
+        for dtype in (torch.float32, torch.float16, torch.bfloat16):
+            for sz in (512, 2560, 32768, 262144, 524288):
+                if sz * dtype.itemsize >= max_size:      # should_custom_ar (custom_all_reduce.py:414-437)
+                    continue
+                g = torch.Generator().manual_seed(sz + 7 * rank)
+                inp = torch.randint(1, 16, (sz,), generator=g, dtype=torch.int32).to(dtype)
+                want = inp.float().clone()
+                dist.all_reduce(want)
+                out = torch.empty(sz, dtype=dtype, device="cuda")
+                ops.all_reduce_unreg(fa, inp.cuda(), buffer, out)          # eager form
+                assert torch.equal(out.float().cpu(), want), ("unreg", dtype, sz)
+                x = inp.cuda()
+                g_out = torch.empty_like(x)
+                torch.cuda.synchronize()
+                dist.barrier()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):                              # graph form
+                    ops.all_reduce_reg(fa, x, g_out)
+                h, o = ops.get_graph_buffer_ipc_meta(fa)
+                hs, os_ = gather((bytes(h), o))
+                ops.register_graph_buffers(fa, hs, os_)
+                dist.barrier()
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(g_out.float().cpu(), want), ("reg", dtype, sz)
+                del graph
+                dist.barrier()
+        try:
+            ops.all_reduce_unreg(fa, torch.zeros(max_size, device="cuda"), buffer, torch.zeros(max_size, device="cuda"))
+            raise AssertionError("an input larger than the registered buffer was accepted")
+        except RuntimeError:
+            pass
+        dist.barrier()
+        ops.dispose(fa)
+        del meta
+        dist.destroy_process_group()
+        queue.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        queue.put((rank, traceback.format_exc()))
+
+
+def _run_ranks(target, world, *extra):
+    port = _free_port()
+    queue = _CTX.Queue()
+    procs = [_CTX.Process(target=target, args=(r, world, port, queue) + extra) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            rank, msg = queue.get(timeout=150)
+            results[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in sorted(results.items()))
+
+
+@pytest.mark.gpu
+def test_reference_op_set_two_ranks_on_one_gpu():
+    _run_ranks(_ops_rank_main, 2)
+
+
+def _hive_size():
+    import torch
+
+    n = torch.cuda.device_count()     # counting devices does not initialise the GPU in this process
+    return 8 if n >= 8 else n // 2 * 2
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_hive_size() < 2, reason="needs at least two GPUs of one xGMI hive")
+def test_all_reduce_one_gpu_per_rank_over_xgmi():
+    """One process per GPU, regions allocated uncached on each device and opened across devices: both
+    algorithms and every size class bit for bit against the rank-ordered fp32 sum, then the
+    reference's op set (eager and captured) against the host sum of integer-valued inputs."""
+    world = _hive_size()
+    _run_ranks(_rank_main, world, True)
+    _run_ranks(_ops_rank_main, world, True)
 
 
 def test_all_reduce_argument_checks_need_no_gpu():

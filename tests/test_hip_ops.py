@@ -971,3 +971,35 @@ def test_argmax_and_sampler_at_llama3_vocab(ops):
         u = torch.rand((B,), generator=g)
         out = ops.top_k_top_p_min_p_sample(probs.to(DEV), top_ks.to(DEV), top_ps.to(DEV), min_ps.to(DEV), u.to(DEV))
         assert (dist.gather(1, out.cpu().long()[:, None]) > 0).all(), trial
+
+
+@pytest.mark.gpu
+def test_final_logit_softcap(ops):
+    """fused_softcap (logits_processor.py:579-618) at Gemma-2's cap (30) and a small one, on logits from
+    tiny to far past the cap, sizes with and without a 4-element tail: the restated arithmetic to a few
+    ulp, fp64 tanh to 1e-6 of the cap, finite where e^{2x} would overflow; then through LogitsProcessor
+    (config.final_logit_softcapping; negative = off, logits_processor.py:217-224)."""
+    from types import SimpleNamespace
+
+    from sglang_custom_amd.layers.logits_processor import LogitsProcessor
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardMode
+
+    g = torch.Generator().manual_seed(5)
+    for cap, shape in ((30.0, (64, 128256)), (30.0, (3, 1001)), (2.5, (7, 333))):
+        x = torch.randn(shape, generator=g) * 25.0
+        x.view(-1)[:6] = torch.tensor([0.0, 1e-7, -1e-7, 1e4, -1e4, 3.4e38])
+        got = ops.softcap_inplace(x.clone().to(DEV), cap).cpu()
+        assert torch.isfinite(got).all()
+        assert (got - ops_ref.softcap(x, cap)).abs().max().item() <= 4e-6 * cap
+        assert (got.double() - cap * torch.tanh(x.double() / cap)).abs().max().item() <= 1e-6 * cap
+    V, H = 1000, 64
+    w = (torch.randn((V, H), generator=g) * 0.5).to(DEV)
+    h = (torch.randn((5, H), generator=g) * 4.0).to(DEV)
+    fb = SimpleNamespace(forward_mode=ForwardMode.DECODE)
+    outs = {}
+    for cap in (None, -1.0, 20.0):
+        lp = LogitsProcessor(SimpleNamespace(vocab_size=V, final_logit_softcapping=cap))
+        outs[cap] = lp(None, h, SimpleNamespace(weight=w), fb).next_token_logits.cpu()
+    assert torch.equal(outs[None], outs[-1.0])
+    assert outs[None].abs().max().item() > 20.0           # the cap bites
+    assert (outs[20.0] - ops_ref.softcap(outs[None], 20.0)).abs().max().item() <= 1e-4

@@ -542,3 +542,32 @@ def test_backend_is_a_drop_in_for_reference_shaped_objects():
         assert be.get_cuda_graph_seq_len_fill_value() == 1
     finally:
         ops_backend.set_ops_backend(None)
+
+
+def test_logits_processor_final_logit_softcapping():
+    """LogitsProcessor applies config.final_logit_softcapping to the fp32 logits and treats a negative
+    value as off (python/sglang/srt/layers/logits_processor.py:217-224, :492-493); the oracle's
+    restatement of the kernel's arithmetic equals cap * tanh(x / cap)."""
+    from types import SimpleNamespace
+
+    import cpu_ops
+    from oracle import ops_ref
+    from sglang_custom_amd import ops_backend
+    from sglang_custom_amd.layers.logits_processor import LogitsProcessor
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardMode
+
+    x = torch.linspace(-200, 200, 4001)
+    assert (ops_ref.softcap(x, 30.0).double() - 30.0 * torch.tanh(x.double() / 30.0)).abs().max() < 3e-5
+    assert torch.isfinite(ops_ref.softcap(torch.tensor([3.0e38, -3.0e38]), 30.0)).all()
+    ops_backend.set_ops_backend(cpu_ops)
+    try:
+        g = torch.Generator().manual_seed(3)
+        w, h = torch.randn((50, 16), generator=g), torch.randn((4, 16), generator=g) * 6
+        fb = SimpleNamespace(forward_mode=ForwardMode.DECODE)
+        out = {c: LogitsProcessor(SimpleNamespace(vocab_size=50, final_logit_softcapping=c))(
+            None, h, SimpleNamespace(weight=w), fb).next_token_logits for c in (None, -1.0, 10.0)}
+        assert torch.equal(out[None], out[-1.0])
+        assert out[None].abs().max() > 10 and out[10.0].abs().max() <= 10
+        assert torch.allclose(out[10.0], 10.0 * torch.tanh(out[None] / 10.0), atol=1e-5)
+    finally:
+        ops_backend.set_ops_backend(None)
