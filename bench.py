@@ -12,7 +12,7 @@ N > 1: one process per GPU.  Started under torchrun the ranks are torchrun's; st
 (as the reference starts one process per tensor-parallel rank, bench_one_batch.py:524-544), and the
 run fails if fewer than N ranks come up.  Default `--parallelism tp`: ONE model sharded over the N
 GPUs (heads / MLP columns / vocabulary, two sum-all-reduces per layer over RCCL, or the one-launch
-xGMI kernels with --custom-all-reduce), the global batch fixed ("strong" scaling); `--parallelism dp`
+xGMI kernels when their start-up self-test passes, see --custom-all-reduce), the global batch fixed ("strong" scaling); `--parallelism dp`
 runs N independent TP=1 replicas instead ("weak").  `n_gpus` in the line is the number of ranks that
 actually ran.
 
@@ -51,9 +51,10 @@ def parse_args():
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
                     help="fp8_e4m3: optional reduced-precision KV cache (NOT the headline configuration)")
     ap.add_argument("--parallelism", default="tp", choices=["dp", "tp"])
-    ap.add_argument("--custom-all-reduce", action="store_true",
-                    help="with --parallelism tp: row-parallel sums and the logits gather through the "
-                         "one-launch xGMI collectives instead of RCCL")
+    ap.add_argument("--custom-all-reduce", choices=["auto", "on", "off"], default="auto",
+                    help="with --parallelism tp: row-parallel sums and the logits gather through the one-launch "
+                         "xGMI collectives.  auto (default): only if their start-up self-test agrees bit for bit "
+                         "with RCCL on this machine; on: without the self-test; off: RCCL only")
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="measurement aid (not the contract metric): run ONE rank's shard of a TP=N "
                          "configuration on one GPU with the collectives stubbed out")
@@ -310,7 +311,8 @@ def main():
                     disable_cuda_graph=args.no_graph, cuda_graph_bs=[bs], tp_size=tp,
                     quantization=args.quantization, random_seed=rank if tp == 1 else 0,
                     simulate_tp_shard=bool(sim), kv_cache_dtype=args.kv_cache_dtype,
-                    disable_custom_all_reduce=not args.custom_all_reduce)
+                    disable_custom_all_reduce=args.custom_all_reduce == "off",
+                    custom_all_reduce_self_test=args.custom_all_reduce == "auto")
     mc = ModelConfig(cfg, dtype=args.dtype, context_length=in_len + out_len + 16)
     graph_ok = True
     try:
@@ -398,7 +400,12 @@ def main():
         # exchange steps of one decode step on every rank: 2 per layer (o_proj, down_proj) + the
         # embedding, each a sum over ranks of a [bs, hidden] tensor; + the all-gather of the logits shards
         n_ar = 2 * cfg["num_hidden_layers"] + 1
-        out["collectives"] = {"backend": "custom one-launch xGMI kernels" if args.custom_all_reduce else "rccl",
+        from sglang_custom_amd.distributed.parallel_state import custom_all_reduce_state, get_custom_all_reduce
+
+        ca = get_custom_all_reduce()
+        out["collectives"] = {"backend": "custom one-launch xGMI kernels (RCCL above their size limit)"
+                              if ca is not None and not ca.disabled else "rccl",
+                              "custom_all_reduce": custom_all_reduce_state(),
                               "ranks": world, "all_reduces_per_step": n_ar,
                               "all_reduce_message_bytes": bs * cfg["hidden_size"] * dtype_bytes,
                               "all_gather_bytes_per_rank": bs * (cfg["vocab_size"] // tp) * dtype_bytes}

@@ -156,6 +156,49 @@ class CustomAllreduce:
                                                         x.shape[0], x.shape[1], float(eps), _DT[x.dtype], stream),
                    "mi355_ar_fused_add_rmsnorm")
 
+    def self_test(self, reference_all_reduce, reference_all_gather) -> Optional[str]:
+        """Run every collective of this class once per algorithm and size class on integer-valued
+        inputs (sums exact in bf16, so any correct all-reduce gives the same bits) and compare with the
+        process group's own collectives, passed in as callables.  Returns None when every rank agreed
+        on every case, else the first reason (the same string on every rank).  A peer that never
+        arrives costs one 2-second barrier timeout, not a hang."""
+        reason = None
+        try:
+            self.set_timeout_ms(2000)
+            g = torch.Generator().manual_seed(1234 + self.rank)
+            for count, algo in ((4096, 1), (4096, 2), (64 * 4096, 1), (64 * 4096, 2), (1 << 20, 0)):
+                if count * 2 >= self.max_size:
+                    continue
+                x = torch.randint(-8, 9, (count,), generator=g, dtype=torch.int32).to(torch.bfloat16).to(self.device)
+                want = reference_all_reduce(x.clone())
+                got = self.all_reduce(x, algo=algo)
+                if not torch.equal(got, want):
+                    reason = reason or f"all_reduce of {count} bf16 (algo {algo}) differs from the process group's sum"
+            x = torch.randint(-8, 9, (64, 2048), generator=g, dtype=torch.int32).to(torch.bfloat16).to(self.device)
+            if self.should_custom_ag(x) and not torch.equal(self.all_gather(x), reference_all_gather(x)):
+                reason = reason or "all_gather differs from the process group's"
+            res = torch.randint(-8, 9, (64, 2048), generator=g, dtype=torch.int32).to(torch.bfloat16).to(self.device)
+            w = torch.ones(2048, dtype=torch.bfloat16, device=self.device)
+            if self.should_fuse_norm(x, 2048):
+                from ...ops_backend import get_ops
+
+                a, ra = self.all_reduce(x), res.clone()
+                get_ops().fused_add_rmsnorm(a, ra, w, 1e-5)
+                b, rb = x.clone(), res.clone()
+                self.fused_add_rmsnorm(b, rb, w, 1e-5)
+                if not (torch.equal(a, b) and torch.equal(ra, rb)):
+                    reason = reason or "all-reduce fused with add+RMSNorm differs from the two steps"
+            self.check_status()
+        except Exception as e:  # noqa: BLE001 -- any failure means: do not use these kernels here
+            reason = reason or f"{type(e).__name__}: {e}"
+        finally:
+            try:
+                self.set_timeout_ms(20000)
+            except Exception:  # noqa: BLE001
+                pass
+        reasons = self._gather(reason)
+        return next((r for r in reasons if r), None)
+
     def set_timeout_ms(self, ms: int) -> None:
         """How long a barrier may wait for a peer before the call gives up (fills its output with NaN
         and makes check_status raise); applies to launches and graph captures made afterwards."""

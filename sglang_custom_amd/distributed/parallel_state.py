@@ -15,18 +15,20 @@ _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANK = 0
 _TP_SIZE = 1
 _CA_COMM = None      # CustomAllreduce over the TP group, when enabled
+_CA_STATE = "off"
 _BACKEND = "nccl"
 
 
 def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: str = "nccl",
                                  init_method: Optional[str] = None, use_custom_all_reduce: bool = False,
-                                 local_device: int = 0) -> None:
+                                 local_device: int = 0, custom_all_reduce_self_test: bool = True) -> None:
     """Create the default process group (if world_size > 1) and use it as the TP group.
 
     use_custom_all_reduce: also build the one-launch xGMI all-reduce for tensors below its size
     limit (the reference's GroupCoordinator does the same, parallel_state.py:285-297); handles are
-    exchanged over a gloo group created beside the device group.  All ranks must be in one node."""
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM, _BACKEND
+    exchanged over a gloo group created beside the device group.  All ranks must be in one node.
+    custom_all_reduce_self_test: keep those kernels only if CustomAllreduce.self_test passes."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM, _BACKEND, _CA_STATE
     _TP_RANK, _TP_SIZE, _BACKEND = rank, world_size, backend
     if world_size == 1:
         _TP_GROUP = None
@@ -35,11 +37,39 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: st
         dist.init_process_group(backend=backend, init_method=init_method or "env://",
                                 world_size=world_size, rank=rank)
     _TP_GROUP = dist.group.WORLD
+    _CA_STATE = "off"
     if use_custom_all_reduce:
         from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
 
         side = _TP_GROUP if backend == "gloo" else dist.new_group(backend="gloo")
-        _CA_COMM = CustomAllreduce(side, local_device)
+        try:
+            _CA_COMM = CustomAllreduce(side, local_device)
+        except Exception as e:  # noqa: BLE001 -- e.g. a peer's memory cannot be mapped on this machine
+            _CA_COMM, _CA_STATE = None, f"off (set-up failed: {type(e).__name__}: {e})"
+        if _CA_COMM is not None and _CA_COMM.disabled:
+            _CA_COMM, _CA_STATE = None, f"off (world size {world_size} not supported)"
+        if _CA_COMM is not None and custom_all_reduce_self_test:
+            # used only after agreeing, on THIS machine and with THESE ranks, with the process group's
+            # own collectives; otherwise every collective goes through the process group (RCCL)
+            comm, _CA_COMM = _CA_COMM, None
+            why = comm.self_test(tensor_model_parallel_all_reduce,
+                                 lambda t: tensor_model_parallel_all_gather(t.unsqueeze(0), 0))
+            if why is None:
+                _CA_COMM, _CA_STATE = comm, "on (self-test passed)"
+            else:
+                import sys
+
+                if rank == 0:
+                    print(f"[parallel_state] custom all-reduce disabled: {why}", file=sys.stderr, flush=True)
+                comm.close()
+                _CA_STATE = f"off (self-test: {why})"
+        elif _CA_COMM is not None:
+            _CA_STATE = "on (no self-test)"
+
+
+def custom_all_reduce_state() -> str:
+    """"on (...)" / "off (...)": whether the one-launch collectives are in use, and why not."""
+    return _CA_STATE
 
 
 def get_custom_all_reduce():

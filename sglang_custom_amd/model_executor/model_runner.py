@@ -72,8 +72,10 @@ class ModelRunner:
             "nccl" if str(self.device).startswith("cuda") else "gloo")
         parallel_state.init_distributed_environment(
             self.tp_size, self.tp_rank, backend, self.server_args.dist_init_method,
-            use_custom_all_reduce=not self.server_args.disable_custom_all_reduce,
-            local_device=torch.device(self.device).index or 0)
+            use_custom_all_reduce=(not self.server_args.disable_custom_all_reduce
+                                   and str(self.device).startswith("cuda")),
+            local_device=torch.device(self.device).index or 0,
+            custom_all_reduce_self_test=self.server_args.custom_all_reduce_self_test)
 
     def init_memory_pool(self):
         cfg, sa = self.model_config, self.server_args

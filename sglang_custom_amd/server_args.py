@@ -27,9 +27,11 @@ class ServerArgs:
     enable_mixed_chunk: bool = False              # decode requests ride along prefill batches as 1-token extends
     schedule_conservativeness: float = 1.0        # scales the initial new-token estimate (0.7) of admission
     page_size: int = 1                            # KV slots per page (> 1: page-aligned allocation)
-    # The reference's flag (server_args.py: disable_custom_all_reduce, default False).  True here: the
-    # one-launch all-reduce has been exercised with ranks sharing one GPU, not yet across xGMI.
-    disable_custom_all_reduce: bool = True
+    # The reference's flag (server_args.py: disable_custom_all_reduce, default False).  The one-launch
+    # collectives are built on GPU ranks and kept only if their start-up self-test agrees bit for bit
+    # with the process group's own collectives on this machine (else RCCL serves every call).
+    disable_custom_all_reduce: bool = False
+    custom_all_reduce_self_test: bool = True
     max_prefill_tokens: int = 16384
     dist_backend: Optional[str] = None          # default: nccl (RCCL) on GPU, gloo on CPU
     dist_init_method: Optional[str] = None

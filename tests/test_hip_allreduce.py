@@ -165,6 +165,11 @@ def _tp_rank_main(rank, world, port, queue, preset, dtn):
                          weights={k: v.cuda() for k, v in w.items()})
         ca = parallel_state.get_custom_all_reduce()
         assert ca is not None and not ca.disabled
+        # kept only because its start-up self-test agreed with the process group (gloo here) on every case
+        assert parallel_state.custom_all_reduce_state() == "on (self-test passed)"
+        # ... and a self-test against a reference that is NOT the sum names the first disagreement, on every rank
+        why = ca.self_test(lambda t: t, lambda t: parallel_state.tensor_model_parallel_all_gather(t.unsqueeze(0), 0))
+        assert why is not None and "all_reduce" in why, why
         assert mr.graph_runner is not None
         nxt, logits, batch = bob.extend([Req(i, p) for i, p in enumerate(prompts)], mr)
         toks, lgs = [nxt.cpu()], [logits.float().cpu()]
