@@ -37,6 +37,17 @@ class ModelConfig:
             want = _DTYPES.get(str(c.get("torch_dtype", "bfloat16")), torch.bfloat16)
         self.dtype = want
         self.is_encoder_decoder = False
+        # multi-head latent attention (model_config.py:186-204): the cache holds one latent row per token
+        arch = (c.get("architectures") or [""])[0]
+        self.is_mla = arch in ("DeepseekV2ForCausalLM", "DeepseekV3ForCausalLM")
+        if self.is_mla:
+            self.head_dim = 256
+            self.kv_lora_rank = c["kv_lora_rank"]
+            self.qk_nope_head_dim = c["qk_nope_head_dim"]
+            self.qk_rope_head_dim = c["qk_rope_head_dim"]
+            self.v_head_dim = c["v_head_dim"]
+            self.q_lora_rank = c.get("q_lora_rank")
+            self.num_key_value_heads = 1
 
     @classmethod
     def from_path(cls, model_path: str, **kw) -> "ModelConfig":

@@ -48,6 +48,9 @@ class Mi355AttnBackend(AttentionBackend):
         tp = model_runner.tp_size
         self.num_head = cfg.num_attention_heads // tp
         self.num_kv_head = max(1, cfg.num_key_value_heads // tp)
+        if hasattr(model_runner.token_to_kv_pool, "kv_lora_rank"):
+            # MLA: what the split plan counts is workgroups per sequence, one per 16 query heads
+            self.num_kv_head = (self.num_head + 15) // 16
         # value width as the pool stores it (an MLA pool's value is the first kv_lora_rank features of
         # its rows); read from the buffer so that any pool with the reference's accessors works
         self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]

@@ -14,7 +14,7 @@ from ..layers.logits_processor import LogitsProcessorOutput
 from ..layers.quantization.w8a8_fp8 import W8A8Fp8LinearMethod
 from ..layers.sampler import Sampler
 from ..mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
-from ..mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+from ..mem_cache.memory_pool import MHATokenToKVPool, MLATokenToKVPool, ReqToTokenPool
 from ..models.llama import LlamaForCausalLM
 from ..server_args import ServerArgs
 from .forward_batch_info import ForwardBatch
@@ -43,8 +43,16 @@ class ModelRunner:
             quant_factory = W8A8Fp8LinearMethod
         elif server_args.quantization is not None:
             raise ValueError(f"unsupported quantization {server_args.quantization!r}")
-        self.model = LlamaForCausalLM(model_config, dtype=self.dtype, device=self.device,
-                                      quant_method_factory=quant_factory)
+        model_cls = LlamaForCausalLM
+        if getattr(model_config, "is_mla", False):
+            # registry lookup by config.architectures in the reference (model_loader/utils.py); two families here
+            from ..models.deepseek_v2 import DeepseekV2ForCausalLM
+
+            model_cls = DeepseekV2ForCausalLM
+            if tp_size != 1:
+                raise NotImplementedError("the DeepSeek stack runs at tensor-parallel size 1")
+        self.model = model_cls(model_config, dtype=self.dtype, device=self.device,
+                               quant_method_factory=quant_factory)
         if weights is not None:
             self.model.load_weights(weights)
         else:
@@ -84,7 +92,14 @@ class ModelRunner:
         if kvd not in ("auto", "fp8_e4m3"):
             raise ValueError(f"kv_cache_dtype {kvd!r}: expected 'auto' or 'fp8_e4m3'")
         self.kv_cache_dtype = torch.float8_e4m3fn if kvd == "fp8_e4m3" else self.dtype
-        cell = 2 * kv_heads * cfg.head_dim * cfg.num_hidden_layers * torch.finfo(self.kv_cache_dtype).bits // 8
+        mla = getattr(cfg, "is_mla", False)
+        if mla:
+            if kvd != "auto":
+                raise NotImplementedError("fp8 latent cache")
+            # one latent row per token and layer (model_runner.py:950-957)
+            cell = (cfg.kv_lora_rank + cfg.qk_rope_head_dim) * cfg.num_hidden_layers * torch.finfo(self.kv_cache_dtype).bits // 8
+        else:
+            cell = 2 * kv_heads * cfg.head_dim * cfg.num_hidden_layers * torch.finfo(self.kv_cache_dtype).bits // 8
         if sa.max_total_tokens is not None:
             self.max_total_num_tokens = sa.max_total_tokens
         else:
@@ -97,9 +112,15 @@ class ModelRunner:
         page = max(1, int(getattr(sa, "page_size", 1) or 1))
         # whole pages only (model_runner.py:1101-1106 rounds the same way)
         self.max_total_num_tokens = self.max_total_num_tokens // page * page
-        self.token_to_kv_pool = MHATokenToKVPool(
-            self.max_total_num_tokens, page, self.kv_cache_dtype, kv_heads, cfg.head_dim,
-            cfg.num_hidden_layers, self.device)
+        if mla:
+            # model_runner.py:1192-1206
+            self.token_to_kv_pool = MLATokenToKVPool(
+                self.max_total_num_tokens, page, self.kv_cache_dtype, cfg.kv_lora_rank, cfg.qk_rope_head_dim,
+                cfg.num_hidden_layers, self.device)
+        else:
+            self.token_to_kv_pool = MHATokenToKVPool(
+                self.max_total_num_tokens, page, self.kv_cache_dtype, kv_heads, cfg.head_dim,
+                cfg.num_hidden_layers, self.device)
         if page == 1:
             self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(
                 self.max_total_num_tokens, self.dtype, self.device, self.token_to_kv_pool)

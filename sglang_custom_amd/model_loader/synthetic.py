@@ -52,9 +52,33 @@ LLAMA_PRESETS = {
 }
 
 
+# DeepSeek (multi-head latent attention) presets whose layers are all dense.  "tiny-deepseek*": the
+# attention geometry of one DeepSeek-V3 tensor-parallel rank of 8 (16 heads, 128 + 64 query/key
+# features, 128 value features, latent rank 512) on a small hidden size; "-yarn" adds DeepSeek-V3's
+# published rope_scaling.
+_YARN_V3 = dict(type="yarn", factor=40.0, original_max_position_embeddings=4096, beta_fast=32, beta_slow=1,
+                mscale=1.0, mscale_all_dim=1.0)
+DEEPSEEK_PRESETS = {
+    "tiny-deepseek": dict(
+        hidden_size=512, num_hidden_layers=2, num_attention_heads=16, q_lora_rank=None, kv_lora_rank=512,
+        qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=1024, vocab_size=2048,
+        rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=4096, rope_scaling=None),
+    "tiny-deepseek-yarn": dict(
+        hidden_size=512, num_hidden_layers=2, num_attention_heads=16, q_lora_rank=192, kv_lora_rank=512,
+        qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=1024, vocab_size=2048,
+        rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=4096, rope_scaling=_YARN_V3),
+}
+
+
 def hf_config_dict(preset: str, torch_dtype: str = "bfloat16") -> dict:
     """A HuggingFace-style config.json body for the preset (what the reference's
     ModelConfig.from_server_args reads, python/sglang/srt/configs/model_config.py)."""
+    if preset in DEEPSEEK_PRESETS:
+        c = dict(DEEPSEEK_PRESETS[preset])
+        c.update(architectures=["DeepseekV3ForCausalLM"], model_type="deepseek_v3", hidden_act="silu",
+                 n_routed_experts=None, first_k_dense_replace=c["num_hidden_layers"], tie_word_embeddings=False,
+                 bos_token_id=0, eos_token_id=1, torch_dtype=torch_dtype, initializer_range=0.02, use_cache=True)
+        return c
     c = dict(LLAMA_PRESETS[preset])
     c.update(
         architectures=["LlamaForCausalLM"], model_type="llama", hidden_act="silu",
@@ -88,6 +112,36 @@ def llama_param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     return shapes
 
 
+def deepseek_param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
+    """HuggingFace names of a dense-layer DeepSeek-V2/V3 checkpoint."""
+    h, H = cfg["hidden_size"], cfg["num_attention_heads"]
+    nope, rope, v, kr, qr = (cfg["qk_nope_head_dim"], cfg["qk_rope_head_dim"], cfg["v_head_dim"], cfg["kv_lora_rank"],
+                             cfg.get("q_lora_rank"))
+    inter, vocab = cfg["intermediate_size"], cfg["vocab_size"]
+    shapes = OrderedDict()
+    shapes["model.embed_tokens.weight"] = (vocab, h)
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        shapes[p + "input_layernorm.weight"] = (h,)
+        if qr is not None:
+            shapes[p + "self_attn.q_a_proj.weight"] = (qr, h)
+            shapes[p + "self_attn.q_a_layernorm.weight"] = (qr,)
+            shapes[p + "self_attn.q_b_proj.weight"] = (H * (nope + rope), qr)
+        else:
+            shapes[p + "self_attn.q_proj.weight"] = (H * (nope + rope), h)
+        shapes[p + "self_attn.kv_a_proj_with_mqa.weight"] = (kr + rope, h)
+        shapes[p + "self_attn.kv_a_layernorm.weight"] = (kr,)
+        shapes[p + "self_attn.kv_b_proj.weight"] = (H * (nope + v), kr)
+        shapes[p + "self_attn.o_proj.weight"] = (h, H * v)
+        shapes[p + "post_attention_layernorm.weight"] = (h,)
+        shapes[p + "mlp.gate_proj.weight"] = (inter, h)
+        shapes[p + "mlp.up_proj.weight"] = (inter, h)
+        shapes[p + "mlp.down_proj.weight"] = (h, inter)
+    shapes["model.norm.weight"] = (h,)
+    shapes["lm_head.weight"] = (vocab, h)
+    return shapes
+
+
 def make_synthetic_llama_weights(
     cfg: dict, seed: int = 1234, std: float = 0.02, dtype: torch.dtype = torch.bfloat16,
     device: str = "cpu",
@@ -100,7 +154,8 @@ def make_synthetic_llama_weights(
         g = torch.Generator(device="cpu").manual_seed(seed)
     else:
         g = torch.Generator(device=device).manual_seed(seed)
-    for name, shape in llama_param_shapes(cfg).items():
+    is_mla = (cfg.get("architectures") or [""])[0].startswith("Deepseek")
+    for name, shape in (deepseek_param_shapes(cfg) if is_mla else llama_param_shapes(cfg)).items():
         if name.endswith("layernorm.weight") or name == "model.norm.weight":
             w = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float32, device=device)
         else:

@@ -1,5 +1,8 @@
-"""Multi-head latent attention of DeepSeek-V2/V3: the attention module only (tensor-parallel size 1),
-with the reference's two forward methods (python/sglang/srt/models/deepseek_v2.py):
+"""DeepSeek-V2/V3 with multi-head latent attention (tensor-parallel size 1): the attention module with
+the reference's two forward methods (python/sglang/srt/models/deepseek_v2.py), and -- at the end of
+the file -- the decoder stack around it for configurations whose layers are all dense
+(first_k_dense_replace >= num_hidden_layers or no routed experts; :1826-1832 picks DeepseekV2MLP for
+those).  Mixture-of-experts layers are outside this path and are refused at construction.
 
   forward_normal  (:1131-1179)  prefill without a cached prefix: the latent is expanded through
                   kv_b_proj into per-head keys (nope 128 + rope 64) and values (128) and runs as
@@ -16,15 +19,18 @@ With rope_scaling (DeepSeek's YaRN) the rotary table is the interpolated, magnit
 softmax scale is multiplied by mscale(factor, mscale_all_dim)^2 (:845-862); the rotation is the
 interleaved (GPT-J) layout.
 """
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 from torch import nn
 
+from ..layers.activation import SiluAndMul
 from ..layers.layernorm import RMSNorm
 from ..layers.linear import ReplicatedLinear
+from ..layers.logits_processor import LogitsProcessor
 from ..layers.radix_attention import RadixAttention
 from ..layers.rotary_embedding import get_rope, yarn_get_mscale
+from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
 
 
 class DeepseekV2AttentionMLA(nn.Module):
@@ -156,3 +162,136 @@ class DeepseekV2AttentionMLA(nn.Module):
         if forward_batch.forward_mode.is_decode() or sum(forward_batch.extend_prefix_lens_cpu) > 0:
             return self.forward_absorb(positions, hidden_states, forward_batch)
         return self.forward_normal(positions, hidden_states, forward_batch)
+
+
+# =============================== the decoder stack (dense layers) ===================================
+class DeepseekV2MLP(nn.Module):
+    """gate_up -> SiLU-and-mul -> down (:167-219)."""
+
+    def __init__(self, hidden_size: int, intermediate_size: int, dtype, device):
+        super().__init__()
+        self.gate_up_proj = ReplicatedLinear(hidden_size, 2 * intermediate_size, dtype, device)
+        self.down_proj = ReplicatedLinear(intermediate_size, hidden_size, dtype, device)
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)[0]))[0]
+
+
+class DeepseekV2DecoderLayer(nn.Module):
+    """input_layernorm -> MLA -> post_attention_layernorm -> MLP with the residual carried beside the
+    hidden states (:1740-1968, the dense branch)."""
+
+    def __init__(self, config, layer_id: int, dtype, device):
+        super().__init__()
+        self.self_attn = DeepseekV2AttentionMLA(
+            config.hidden_size, config.num_attention_heads, config.qk_nope_head_dim, config.qk_rope_head_dim,
+            config.v_head_dim, config.q_lora_rank, config.kv_lora_rank, layer_id, dtype, device,
+            rope_theta=config.rope_theta, max_position_embeddings=config.max_position_embeddings,
+            rms_norm_eps=config.rms_norm_eps, rope_scaling=config.rope_scaling)
+        self.mlp = DeepseekV2MLP(config.hidden_size, config.intermediate_size, dtype, device)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, positions, hidden_states, forward_batch, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states), residual
+
+
+class DeepseekV2Model(nn.Module):
+    def __init__(self, config, dtype, device):
+        super().__init__()
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size, dtype, device)
+        self.layers = nn.ModuleList([DeepseekV2DecoderLayer(config, i, dtype, device)
+                                     for i in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, input_ids, positions, forward_batch):
+        hidden_states = self.embed_tokens(input_ids)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class DeepseekV2ForCausalLM(nn.Module):
+    """DeepseekV2ForCausalLM / DeepseekV3ForCausalLM (:2064-2148) restricted to dense layers."""
+
+    def __init__(self, config, dtype=torch.bfloat16, device="cuda", quant_method_factory=None):
+        super().__init__()
+        if quant_method_factory is not None:
+            raise NotImplementedError("fp8 linears of the DeepSeek stack: only kv_b_proj (load_kv_b_proj_fp8) is supported")
+        hf = config.hf_config
+        n_experts = getattr(hf, "n_routed_experts", None)
+        if n_experts is not None and getattr(hf, "first_k_dense_replace", 0) < config.num_hidden_layers:
+            raise NotImplementedError(
+                "mixture-of-experts layers are outside this path: use a configuration whose layers are all dense "
+                "(first_k_dense_replace >= num_hidden_layers)")
+        self.config = config
+        self.dtype = dtype
+        self.model = DeepseekV2Model(config, dtype, device)
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size, dtype, device)
+        self.logits_processor = LogitsProcessor(config)
+        for m in self.modules():
+            if isinstance(m, RMSNorm):
+                m.weight.data = m.weight.data.to(dtype=dtype, device=device)
+        self.to(device)
+
+    @torch.no_grad()
+    def forward(self, input_ids, positions, forward_batch):
+        hidden_states = self.model(input_ids, positions, forward_batch)
+        return self.logits_processor(input_ids, hidden_states, self.lm_head, forward_batch)
+
+    @torch.no_grad()
+    def load_weights(self, weights: Dict[str, torch.Tensor]) -> None:
+        """HuggingFace-named tensors; q_a_proj + kv_a_proj_with_mqa are stacked into
+        fused_qkv_a_proj_with_mqa and gate_proj + up_proj into gate_up_proj, as the reference's loader
+        does (:2330-2345, :2417-2457)."""
+        def put(param, value):
+            param.data.copy_(value.to(dtype=param.dtype), non_blocking=True)
+
+        put(self.model.embed_tokens.weight, weights["model.embed_tokens.weight"])
+        put(self.lm_head.weight, weights["lm_head.weight"])
+        put(self.model.norm.weight, weights["model.norm.weight"])
+        for i, layer in enumerate(self.model.layers):
+            p = f"model.layers.{i}."
+            at = layer.self_attn
+            put(layer.input_layernorm.weight, weights[p + "input_layernorm.weight"])
+            put(layer.post_attention_layernorm.weight, weights[p + "post_attention_layernorm.weight"])
+            if at.q_lora_rank is not None:
+                put(at.fused_qkv_a_proj_with_mqa.weight, torch.cat(
+                    [weights[p + "self_attn.q_a_proj.weight"], weights[p + "self_attn.kv_a_proj_with_mqa.weight"]], 0))
+                put(at.q_a_layernorm.weight, weights[p + "self_attn.q_a_layernorm.weight"])
+                put(at.q_b_proj.weight, weights[p + "self_attn.q_b_proj.weight"])
+            else:
+                put(at.q_proj.weight, weights[p + "self_attn.q_proj.weight"])
+                put(at.kv_a_proj_with_mqa.weight, weights[p + "self_attn.kv_a_proj_with_mqa.weight"])
+            put(at.kv_a_layernorm.weight, weights[p + "self_attn.kv_a_layernorm.weight"])
+            put(at.kv_b_proj.weight, weights[p + "self_attn.kv_b_proj.weight"])
+            put(at.o_proj.weight, weights[p + "self_attn.o_proj.weight"])
+            put(layer.mlp.gate_up_proj.weight, torch.cat(
+                [weights[p + "mlp.gate_proj.weight"], weights[p + "mlp.up_proj.weight"]], 0))
+            put(layer.mlp.down_proj.weight, weights[p + "mlp.down_proj.weight"])
+        self.post_load_weights()
+
+    def post_load_weights(self) -> None:
+        for layer in self.model.layers:
+            layer.self_attn.post_load_weights()
+
+    @torch.no_grad()
+    def init_random_weights(self, seed: int = 0, std: float = 0.02) -> None:
+        g = torch.Generator(device=self.model.norm.weight.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            w = torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32)
+            if "layernorm" in name or name.endswith("norm.weight"):
+                p.data.copy_((1.0 + 0.1 * w).to(p.dtype))
+            else:
+                p.data.copy_((std * w).to(p.dtype))
+        self.post_load_weights()

@@ -95,6 +95,14 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
                                      sm_scale, gqa))
 
 
+def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
+                         num_kv_splits, kv_lora_rank, sm_scale, logit_cap=0.0):
+    """Multi-query attention over latent rows: keys = whole rows, values = their first kv_lora_rank features."""
+    assert not logit_cap
+    o.copy_(ops_ref.decode_attention(q, kv_buffer, kv_buffer[..., :kv_lora_rank], req_to_token, req_pool_indices,
+                                     seq_lens, sm_scale, True))
+
+
 def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
                          kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend,
                          sm_scale=None, logit_cap=0.0, skip_prefix_custom_mask=True,
@@ -106,8 +114,11 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         qs, qe = int(qo_indptr[i]), int(qo_indptr[i + 1])
         ps, pe = int(kv_indptr[i]), int(kv_indptr[i + 1])
         idx = kv_indices[ps:pe].long()
-        k = torch.cat([k_buffer[idx], k_extend[qs:qe]], 0).movedim(0, 1)
-        v = torch.cat([v_buffer[idx], v_extend[qs:qe]], 0).movedim(0, 1)
+        if pe > ps:
+            k = torch.cat([k_buffer[idx], k_extend[qs:qe]], 0).movedim(0, 1)
+            v = torch.cat([v_buffer[idx], v_extend[qs:qe]], 0).movedim(0, 1)
+        else:   # no prefix: the buffers are not read (an MLA pool's rows do not even have this shape)
+            k, v = k_extend[qs:qe].movedim(0, 1), v_extend[qs:qe].movedim(0, 1)
         ext, pre = qe - qs, pe - ps
         qq = torch.zeros((Hq, pre + ext, q_extend.shape[2]), dtype=q_extend.dtype)
         qq[:, pre:] = q_extend[qs:qe].movedim(0, 1)

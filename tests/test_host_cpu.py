@@ -571,3 +571,45 @@ def test_logits_processor_final_logit_softcapping():
         assert torch.allclose(out[10.0], 10.0 * torch.tanh(out[None] / 10.0), atol=1e-5)
     finally:
         ops_backend.set_ops_backend(None)
+
+
+@pytest.mark.parametrize("preset", ["tiny-deepseek", "tiny-deepseek-yarn"])
+def test_deepseek_dense_stack_host_wiring_matches_oracle(preset):
+    """ModelRunner picks DeepseekV2ForCausalLM + MLATokenToKVPool from config.architectures
+    (model_config.py:186-204, model_runner.py:950-957, 1192-1206); prefill in the multi-head form, decode
+    in the absorbed form; fp32 tokens equal to the oracle stack's and logits within 1e-4.  A
+    mixture-of-experts configuration is refused."""
+    import cases
+    import cpu_ops
+    from oracle.deepseek_ref import OracleDeepseek
+    from sglang_custom_amd import bench_one_batch as bob
+    from sglang_custom_amd import ops_backend
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.mem_cache.memory_pool import MLATokenToKVPool
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+    from sglang_custom_amd.server_args import ServerArgs
+
+    ops_backend.set_ops_backend(cpu_ops)
+    try:
+        cfg = hf_config_dict(preset, "float32")
+        w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+        sa = ServerArgs(dtype="float32", device="cpu", max_total_tokens=512, max_running_requests=8, disable_cuda_graph=True)
+        mr = ModelRunner(ModelConfig(cfg, dtype="float32"), sa, weights=w)
+        assert isinstance(mr.token_to_kv_pool, MLATokenToKVPool)
+        prompts = cases.e2e_prompts(cfg["vocab_size"], (5, 33))
+        ref_toks, ref_logits = OracleDeepseek(cfg, w, torch.float32, max_total_tokens=512, max_reqs=8,
+                                              context_len=256).generate_greedy(prompts, 4)
+        nxt, lg, batch = bob.extend([Req(i, p) for i, p in enumerate(prompts)], mr)
+        toks, err = [nxt.clone()], (lg - ref_logits[0]).abs().max().item()
+        for s in range(3):
+            nxt, lg = bob.decode(nxt, batch, mr)
+            toks.append(nxt.clone())
+            err = max(err, (lg - ref_logits[s + 1]).abs().max().item())
+        assert torch.equal(torch.stack(toks, 1), ref_toks) and err < 1e-4, err
+        moe = dict(cfg, n_routed_experts=8, first_k_dense_replace=1)
+        with pytest.raises(NotImplementedError):
+            ModelRunner(ModelConfig(moe, dtype="float32"), sa, weights=w)
+    finally:
+        ops_backend.set_ops_backend(None)
