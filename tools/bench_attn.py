@@ -1,6 +1,7 @@
 """Dev tool: decode attention micro-benchmark at the bench shape (bs=64, ctx~1064, 32q/8kv x128)."""
 import ctypes, sys, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_custom_amd import ops, _lib
 _lib.use_dev_library()   # ablation switches and probes live in the development build only
 lib = _lib.load()
