@@ -1606,11 +1606,13 @@ extern "C" {
 
 int mi355_decode_num_splits(int64_t bs, int hkv, int64_t max_seq_len, int max_splits) {
   if (bs <= 0 || hkv <= 0 || max_splits <= 1) return 1;
-  // Aim for >= 2 workgroups (8 waves) per CU (256 CUs) while keeping >= 128 keys per split: the
-  // key loop is software-pipelined, so 8 waves per CU already saturate HBM, and every extra split
-  // costs partial-result traffic and the merge launch.
+  // Split only until the launch can saturate HBM, and no further: a workgroup of the MFMA kernel
+  // streams ~45 GB/s, so ~112 of them already draw what the chip delivers to this access pattern,
+  // and every extra split costs fp32 partial traffic plus ~1 us of the merge launch.  Measured at
+  // 1064 keys, head_dim 128 (microseconds, best in brackets): 8 workgroups unsplit 17.6 [6-8 splits:
+  // 11.6]; 64: 19.9 [3: 14.4; 8: 19.1]; 128: 20.5 [2: 19.7; 4: 22.3]; 256: 31.7 [1; 2: 34.4].
   const int64_t wgs = bs * hkv;
-  int64_t want = (2 * 256 + wgs - 1) / wgs;
+  int64_t want = wgs >= 112 ? 1 : (160 + wgs - 1) / wgs;
   const int64_t by_len = max_seq_len / 128 > 0 ? max_seq_len / 128 : 1;
   if (want > by_len) want = by_len;
   if (want > max_splits) want = max_splits;

@@ -48,8 +48,9 @@ class Mi355AttnBackend(AttentionBackend):
         tp = model_runner.tp_size
         self.num_head = cfg.num_attention_heads // tp
         self.num_kv_head = max(1, cfg.num_key_value_heads // tp)
-        if hasattr(model_runner.token_to_kv_pool, "kv_lora_rank"):
-            # MLA: what the split plan counts is workgroups per sequence, one per 16 query heads
+        self.is_mla = hasattr(model_runner.token_to_kv_pool, "kv_lora_rank")
+        if self.is_mla:
+            # what the split plan counts is workgroups per sequence, one per 16 query heads
             self.num_kv_head = (self.num_head + 15) // 16
         # value width as the pool stores it (an MLA pool's value is the first kv_lora_rank features of
         # its rows); read from the buffer so that any pool with the reference's accessors works
@@ -92,6 +93,11 @@ class Mi355AttnBackend(AttentionBackend):
         return indptr[: bs + 1], indices
 
     def _plan_splits(self, bs: int, max_seq_len: int) -> int:
+        if self.is_mla:
+            # the MLA kernel keeps two workgroups per CU busy and streams 1152-byte rows: it is fastest at
+            # 512 workgroups (64 sequences x 16 heads x 4096 keys: 255 / 141 / 85 / 76 us at 1 / 2 / 4 / 8 splits)
+            wgs = max(1, bs * self.num_kv_head)
+            return max(1, min(MAX_KV_SPLITS, (512 + wgs - 1) // wgs, max(1, max_seq_len // 128)))
         return get_ops().decode_num_splits(bs, self.num_kv_head, max_seq_len, MAX_KV_SPLITS)
 
     # ---- eager ----

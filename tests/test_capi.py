@@ -66,7 +66,9 @@ def test_abi_version_and_error_codes(lib):
 
 def test_planner_is_pure_host_logic(lib):
     assert lib.mi355_decode_num_splits(64, 8, 1100, 64) == 1
-    assert lib.mi355_decode_num_splits(16, 8, 1100, 64) == 4
+    assert lib.mi355_decode_num_splits(16, 8, 1100, 64) == 1     # 128 workgroups already saturate the stream
+    assert lib.mi355_decode_num_splits(64, 1, 1100, 64) == 3     # one local kv head (tensor-parallel rank of 8)
+    assert lib.mi355_decode_num_splits(8, 8, 1100, 64) == 3
     assert lib.mi355_decode_num_splits(1, 8, 1100, 64) == 8
     assert lib.mi355_decode_num_splits(1, 8, 100000, 16) == 16
     assert lib.mi355_decode_num_splits(256, 8, 50, 64) == 1

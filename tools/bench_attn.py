@@ -49,7 +49,7 @@ ref = torch.einsum('bhgk,bkhd->bhgd', s.softmax(-1), V).reshape(bs, hq, D)
 nbytes = bs * ctx * hkv * D * 2 * kb[0].element_size()
 for dbg in (3, 0):
     lib.mi355_debug_set(6, dbg)   # 3 = K rows straight into fragments (ablation), 0 = whole K rows staged through LDS (product)
-    for ns in (1, 2, 3, 4):
+    for ns in [int(x) for x in os.environ.get('SPLITS', '1,2,3,4').split(',')]:
         ops.decode_attention_paged(q, kb[0], vb[0], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5)
         err = (o.float() - ref).abs().max().item()
         t = timeit(lambda i: ops.decode_attention_paged(q, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5))
