@@ -1237,8 +1237,9 @@ __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __re
 constexpr int MLR_ROWB = 1056;                       // bytes between rows' latent parts
 constexpr int MLR_TAIL = 16 * MLR_ROWB;              // byte offset of the rope parts
 constexpr int MLR_TILE = MLR_TAIL + 16 * 128;        // 18944
-constexpr int MLR_NBUF = 4;
-constexpr int MLR_LDS_BYTES = MLR_NBUF * MLR_TILE;   // 75776
+// NSB step buffers of two tiles each: 2 -> 75776 bytes (two workgroups per CU, one step in flight),
+// 4 -> 151552 bytes (one workgroup per CU, three steps = 111 KiB in flight)
+constexpr int mlr_lds_bytes(int nsb) { return 2 * nsb * MLR_TILE; }
 
 __device__ __forceinline__ unsigned lds_byte_address(const void* p) {
   return (unsigned)(uintptr_t)(const char __attribute__((address_space(3)))*)(p);
@@ -1264,13 +1265,15 @@ __device__ __forceinline__ void load_to_lds_16_s(uint64_t base, unsigned lane_of
       : "memory");
 }
 
-template <typename T, bool CAP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decode_attn_mla_ring_kernel(
+template <typename T, bool CAP, int NSB>
+__global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
     const T* __restrict__ q, const T* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p) {
   constexpr int NS = MLA_D / 32;   // 18 score k-steps
   using frag = typename Mfma<T>::frag;
   using frag4 = typename Mfma16<T>::frag;
-  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // MLR_LDS_BYTES
+  constexpr int P = NSB - 1;   // steps requested ahead of the one being computed
+  static_assert(P >= 1 && P <= 3, "the wait below knows 0, 10 or 20 younger loads");
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // mlr_lds_bytes(NSB)
 
   const int head0 = blockIdx.x * 16, split = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63;
@@ -1316,7 +1319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                        ring + (unsigned)buf * MLR_TILE + MLR_TAIL + (unsigned)(4 * wave) * 128);
   };
   auto issue_step = [&](int step, const Slots& sl) {
-    const int buf = 2 * (step & 1);
+    const int buf = 2 * (step % NSB);
     issue_tile(buf, sl.a0, sl.a1, sl.a2, sl.a3);
     issue_tile(buf + 1, sl.b0, sl.b1, sl.b2, sl.b3);
   };
@@ -1334,9 +1337,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   Slots s_nxt{};
   if (n_steps > 0) {   // (an empty sequence has no page-table entry to read)
-    s_nxt = slots_of(0);
-    issue_step(0, s_nxt);
-    s_nxt = slots_of(1);   // clamped to the last key when past the end
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      s_nxt = slots_of(i);   // clamped to the last key when past the end
+      if (i < n_steps) issue_step(i, s_nxt);
+    }
+    s_nxt = slots_of(P);
   }
 
   // B operand of the scores: this lane's head (r16), features 32 s + 8 c4 .. + 7.  Fetched AFTER the first
@@ -1353,13 +1359,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   for (int t = 0; t < n_steps; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of step t has landed
+    // this wave's part of step t has landed when at most the loads (10 per step) of the younger steps are out
+    const int younger = min(P - 1, n_steps - 1 - t);
+    if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its reads of step t - 1 have returned
     __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's tiles are free
-    if (t + 1 < n_steps) issue_step(t + 1, s_nxt);
-    s_nxt = slots_of(t + 2);
+    if (t + P < n_steps) issue_step(t + P, s_nxt);
+    s_nxt = slots_of(t + P + 1);
 
-    const char* tile = sm_raw + 2 * (t & 1) * MLR_TILE;
+    const char* tile = sm_raw + 2 * (t % NSB) * MLR_TILE;
     f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -1854,14 +1864,17 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   p.v_slot_stride = D;
   hipStream_t st = (hipStream_t)stream;
   if (kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
-      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && (g_decode_variant == 0 || g_decode_variant == 2)) {
+      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && (g_decode_variant == 0 || g_decode_variant == 2 || g_decode_variant == 5)) {
     const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)num_splits, (unsigned)bs);
-    if (g_decode_variant == 0 && aligned16(attn_logits)) {   // rows through the LDS ring (2 = the register kernel, for ablation)
+    if ((g_decode_variant == 0 || g_decode_variant == 5) && aligned16(attn_logits)) {   // rows through the LDS ring (2 = the register kernel, 5 = the deep ring, for ablation)
+      constexpr int NSB_ = 2;
+      const bool deep = g_decode_variant == 5;
 #define MLR_LAUNCH(T_, CAP_)                                                                                   \
   do {                                                                                                         \
-    auto kern = decode_attn_mla_ring_kernel<T_, CAP_>;                                                         \
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MLR_LDS_BYTES);   \
-    hipLaunchKernelGGL(kern, grid, dim3(256), MLR_LDS_BYTES, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p); \
+    auto kern = deep ? decode_attn_mla_ring_kernel<T_, CAP_, 4> : decode_attn_mla_ring_kernel<T_, CAP_, NSB_>; \
+    const int lds_ = deep ? mlr_lds_bytes(4) : mlr_lds_bytes(NSB_);                                            \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p);        \
     if (num_splits > 1)                                                                                        \
       hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
                          p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
