@@ -57,30 +57,56 @@ class CustomAllreduce:
         self.rank, self.world_size, self.max_size = rank, world_size, int(max_size)
         lib = _lib.load()
         self._lib = lib
-        with torch.cuda.device(device):
-            region = ctypes.c_void_p()
-            _lib.check(lib.mi355_ar_alloc_region(ctypes.byref(region), self.max_size), "mi355_ar_alloc_region")
-            self._region = region.value
-            hbytes = lib.mi355_ar_ipc_handle_bytes()
-            buf = (ctypes.c_uint8 * hbytes)()
-            _lib.check(lib.mi355_ar_get_ipc_handle(self._region, buf), "mi355_ar_get_ipc_handle")
-            handles = self._gather(bytes(buf))
-            ptrs = (ctypes.c_void_p * world_size)()
-            for r, h in enumerate(handles):
-                if r == rank:
-                    ptrs[r] = self._region
-                else:
-                    p = ctypes.c_void_p()
-                    hb = (ctypes.c_uint8 * hbytes).from_buffer_copy(h)
-                    _lib.check(lib.mi355_ar_open_ipc_handle(hb, ctypes.byref(p)), "mi355_ar_open_ipc_handle")
-                    ptrs[r] = p.value
-                    self._opened.append(p.value)
-            comm = ctypes.c_void_p()
-            _lib.check(lib.mi355_ar_init(ctypes.byref(comm), ptrs, rank, world_size, self.max_size), "mi355_ar_init")
-            self._comm = comm.value
+        # Set-up is collective: a rank whose step fails must not leave the others waiting in the next
+        # exchange, so every step's outcome is gathered and all ranks raise together.
+        err, handle = None, b""
+        hbytes = lib.mi355_ar_ipc_handle_bytes()
+        try:
+            with torch.cuda.device(device):
+                region = ctypes.c_void_p()
+                _lib.check(lib.mi355_ar_alloc_region(ctypes.byref(region), self.max_size), "mi355_ar_alloc_region")
+                self._region = region.value
+                buf = (ctypes.c_uint8 * hbytes)()
+                _lib.check(lib.mi355_ar_get_ipc_handle(self._region, buf), "mi355_ar_get_ipc_handle")
+                handle = bytes(buf)
+        except Exception as e:  # noqa: BLE001
+            err = f"rank {rank}: {type(e).__name__}: {e}"
+        gathered = self._gather((handle, err))
+        self._raise_together([g[1] for g in gathered])
+        try:
+            with torch.cuda.device(device):
+                ptrs = (ctypes.c_void_p * world_size)()
+                for r, (h, _) in enumerate(gathered):
+                    if r == rank:
+                        ptrs[r] = self._region
+                    else:
+                        p = ctypes.c_void_p()
+                        hb = (ctypes.c_uint8 * hbytes).from_buffer_copy(h)
+                        _lib.check(lib.mi355_ar_open_ipc_handle(hb, ctypes.byref(p)), "mi355_ar_open_ipc_handle")
+                        ptrs[r] = p.value
+                        self._opened.append(p.value)
+                comm = ctypes.c_void_p()
+                _lib.check(lib.mi355_ar_init(ctypes.byref(comm), ptrs, rank, world_size, self.max_size), "mi355_ar_init")
+                self._comm = comm.value
+        except Exception as e:  # noqa: BLE001
+            err = f"rank {rank}: {type(e).__name__}: {e}"
+        self._raise_together(self._gather(err))
         # every rank's region is zeroed and mapped everywhere before the first launch
         dist.barrier(group=group)
         self.disabled = False
+
+    def _raise_together(self, errors) -> None:
+        first = next((e for e in errors if e), None)
+        if first is None:
+            return
+        for p in self._opened:
+            self._lib.mi355_ar_close_ipc_handle(p)
+        if self._comm:
+            self._lib.mi355_ar_dispose(self._comm)
+        if self._region:
+            self._lib.mi355_ar_free_region(self._region)
+        self._comm, self._region, self._opened = None, None, []
+        raise RuntimeError(f"custom all-reduce set-up failed on at least one rank ({first})")
 
     def _gather(self, obj):
         """all_gather of a Python object by per-rank broadcasts (all_gather_object does not work on
