@@ -351,6 +351,19 @@ int mi355_linear_packed_silu_mul(void* y, const void* x, const void* w_packed, i
                                  int64_t k, int64_t x_stride, void* workspace,
                                  int64_t workspace_bytes, int dtype, void* stream);
 
+/* Large-M (prefill) projection: y = x @ W^T with 16-bit operands, fp32 accumulation on the matrix
+ * cores, one rounding to the output dtype (= dtype).  x [M, K] (row stride x_stride, a multiple
+ * of 8), W [N, K] contiguous, bias (may be NULL) [N].  epilogue 0: y [M, N] = T(acc + bias);
+ * epilogue 1 (W = [gate; up], N = 2 I): y [M, I], y[m, j] = T(silu(T(g_j))) * T(u_j) with the rounding
+ * points of the unfused GEMM + SiluAndMul pair.  Needs K % 64 == 0, K >= 128, N % 16 == 0
+ * (mi355_linear_tiled_supported returns 1); no workspace, nothing allocated.
+ * replaces: UnquantizedLinearMethod.apply / F.linear at prefill sizes
+ *           (layers/quantization/unquant.py:110-122) and, with epilogue 1, LlamaMLP.forward's
+ *           gate_up_proj + act_fn (models/llama.py:94-98, layers/activation.py:55-65). */
+int mi355_linear_tiled_supported(int64_t m, int64_t n, int64_t k, int dtype, int epilogue);
+int mi355_linear_tiled(void* y, const void* x, const void* w, const void* bias, int64_t m, int64_t n,
+                       int64_t k, int64_t x_stride, int dtype, int epilogue, void* stream);
+
 /* ---- K14 fp8 W8A8 ------------------------------------------------------------------------------
  * Per-token dynamic quantisation to OCP e4m3fn (max 448): s[r] = max(absmax(x[r,:]), 1e-10)/448,
  * q = clamp(x/s, +-448) -> fp8.

@@ -1,0 +1,335 @@
+// Large-M projection GEMM  y[M, N] = x[M, K] @ W[N, K]^T  (16-bit operands, fp32 accumulation) for
+// gfx950: the prefill side of UnquantizedLinearMethod.apply
+// (python/sglang/srt/layers/quantization/unquant.py:110-122), with the MLP's SiLU-and-mul
+// (python/sglang/srt/models/llama.py:94-98, layers/activation.py:55-65) optionally applied in the
+// epilogue.  The decode side (M <= 64) is the weight-streaming kernel in gemm.hip.
+//
+// Structure (one 512-thread workgroup per CU, 128 KiB of LDS, one 256 x 256 output tile):
+//   * K is walked in tiles of 64; a tile's operands live in LDS as four HALF-TILES of 128 rows x 128
+//     bytes (x rows 0..127, x rows 128..255, W rows 0..127, W rows 128..255), two tiles resident;
+//   * the load unit writes LDS itself (global_load_lds_dwordx4, 8 rows x 128 B per wave-instruction:
+//     whole cache lines); every wave issues two such loads per SLOT, i.e. one half-tile per slot for
+//     the workgroup, five half-tiles ahead of the slot that first reads it, and waits with a COUNTED
+//     vmcnt so that two half-tiles stay in flight across every barrier;
+//   * the eight waves form two groups of four (group = row half of the tile, wave-in-group = 64
+//     output columns).  A wave alternates a MEM slot (12 ds_read_b128: the A/B fragments of one
+//     32-deep k-step) with an MFMA slot (32 x v_mfma_f32_16x16x32 on those fragments); the groups run
+//     one slot apart, so on every SIMD one wave's matrix work covers the other wave's LDS reads
+//     and load issue.  One s_barrier per slot.
+//   * LDS rows are 128 bytes; the 16-byte chunk index is XOR-ed with (row >> 1) & 7 on the SOURCE
+//     address of the load (the load unit writes lane-linear) and again on the fragment read:
+//     conflict-free ds_read_b128.
+//   * W rows are assigned to MFMA row slots so that a lane ends up with 16 consecutive output
+//     columns (or, for SiLU-and-mul, 8 gate columns and the 8 matching up columns): the epilogue
+//     writes whole 128-byte lines with 16-byte stores and needs no cross-lane traffic.
+//   * workgroup -> tile: consecutive workgroups round-robin over the 8 XCDs, so workgroups b and
+//     b + 8 share an L2; each XCD works through 8 x 4 blocks of tiles (32 CUs = one block).
+#include "common.cuh"
+
+namespace mi355 {
+namespace {
+
+constexpr int GT_HALF = 128 * 128;      // bytes of one half-tile
+constexpr int GT_STAGE = 4 * GT_HALF;   // one K tile: x (2 halves) + W (2 halves)
+constexpr int GT_LDS = 2 * GT_STAGE;    // 131072
+
+struct GemmTiledParams {
+  const void* x;
+  const void* w;
+  const void* bias;
+  void* y;
+  int M, N, K;      // N = rows of W
+  int64_t ldx;      // elements between rows of x
+  int ldy;          // elements between rows of y
+  int mt, nt;       // output tiles along M and N
+  int snt, nsuper;  // 8 x 4 blocks of tiles: count along N, total
+};
+
+__device__ __forceinline__ void glds16(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// EPI 0: y = T(acc (+ bias)); EPI 1: W = [gate; up] (N = 2 I rows), y[m, j] = silu_mul(T(gate_j), T(up_j))
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  using frag = typename Mfma<T>::frag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wc = wave & 3;
+
+  // ---- workgroup -> output tile ------------------------------------------------------------
+  const int b = blockIdx.x, li = b >> 3;
+  const int st = (li >> 5) * 8 + (b & 7), within = li & 31;
+  if (st >= p.nsuper) return;
+  const int sup_m = st / p.snt, sup_n = st - sup_m * p.snt;
+  const int tm = sup_m * 8 + (within & 7), tn = sup_n * 4 + (within >> 3);
+  if (tm >= p.mt || tn >= p.nt) return;
+
+  const int T_ = p.K >> 6;   // K tiles
+  const T* xg = (const T*)p.x;
+  const T* wg = (const T*)p.w;
+  const int ncols = EPI == 1 ? (p.N >> 1) : p.N;   // output columns
+
+  // ---- per-lane source pointers of the eight load instructions a wave issues per K tile -----
+  // half-tile `which`: 0 = x rows 0..127, 1 = W rows 0..127, 2 = W rows 128..255, 3 = x rows 128..255
+  // (the order in which they are requested: H[4 t + which])
+  const T* src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rr = (wave * 2 + i) * 8 + (lane >> 3);           // row inside the half-tile
+    const int c = (lane & 7) ^ ((rr >> 1) & 7);                // logical 16-byte chunk this lane fetches
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int m = tm * 256 + h * 128 + rr;
+      m = m < p.M ? m : p.M - 1;
+      src[h == 0 ? 0 : 3][i] = xg + (int64_t)m * p.ldx + c * 8;
+      const int rb = h * 128 + rr, wcb = rb >> 6, sl = rb & 63, ni = sl >> 4, ii = sl & 15;
+      int n;
+      if (EPI == 1) {
+        int j = tn * 128 + wcb * 32 + (ii >> 2) * 8 + (ni & 1) * 4 + (ii & 3);
+        j = j < ncols ? j : ncols - 1;
+        n = j + (ni >> 1) * ncols;
+      } else {
+        n = tn * 256 + wcb * 64 + (ii >> 2) * 16 + ni * 4 + (ii & 3);
+        n = n < p.N ? n : p.N - 1;
+      }
+      src[1 + h][i] = wg + (int64_t)n * p.K + c * 8;
+    }
+  }
+  const int lds_half[4] = {0, 2 * GT_HALF, 3 * GT_HALF, GT_HALF};
+  char* const lds_w = sm + wave * 2048;   // this wave's two 1-KiB pieces inside a half-tile
+
+  // ---- prologue: H0..H4 = all of tile 0 and x rows 0..127 of tile 1 ---------------------------
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(src[h][i], lds_w + lds_half[h] + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) glds16(src[0][i] + 64, lds_w + GT_STAGE + lds_half[0] + i * 1024);
+
+  // The wave's own request sequence: entry e of loop tile t is H[4 t + 5 + g + e]; `which` and the
+  // tile distance d (1 or 2) of each entry are fixed per group.
+  const T* seq[4][2];
+  int seq_lds[4];   // LDS offset (without the tile-parity term) of the entry's half-tile
+  int seq_d[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = e + 1 + g, which = idx & 3;
+    seq_d[e] = 1 + (idx >> 2);
+    seq_lds[e] = which == 0 ? lds_half[0] : which == 1 ? lds_half[1] : which == 2 ? lds_half[2] : lds_half[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const T* s = which == 0 ? src[0][i] : which == 1 ? src[1][i] : which == 2 ? src[2][i] : src[3][i];
+      seq[e][i] = s + seq_d[e] * 64;   // at t = 0
+    }
+  }
+
+  // ---- fragment read addresses ----------------------------------------------------------------
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int rd0 = r16 * 128 + ((q4 ^ (r16 >> 1)) << 4);   // k-step 0; k-step 1 is rd0 ^ 64
+  const int a_off = g * GT_HALF, b_off = 2 * GT_HALF + wc * 8192;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  frag af[8], bf[4];
+#ifndef GT_ABL
+#define GT_ABL 0   // development ablations: 1 no loads in the loop, 2 no fragment reads, 3 no MFMA, 4 no vmcnt waits
+#endif
+  if (GT_ABL == 2) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const frag*>(sm + rd0 + mi * 2048);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const frag*>(sm + rd0 + ni * 2048 + 32768);
+  }
+
+#ifndef GT_ABL
+#define GT_ABL 0   // development ablations: 1 no loads in the loop, 2 no fragment reads, 3 no MFMA, 4 no vmcnt waits
+#endif
+#define GT_ISSUE(e, t)                                                                       \
+  do {                                                                                       \
+    if (GT_ABL != 1 && (t) + seq_d[e] < T_) {                                                               \
+      char* d_ = lds_w + ((((t) + seq_d[e]) & 1) ? GT_STAGE : 0) + seq_lds[e];               \
+      glds16(seq[e][0] + (int64_t)(t) * 64, d_);                                             \
+      glds16(seq[e][1] + (int64_t)(t) * 64, d_ + 1024);                                      \
+    }                                                                                        \
+  } while (0)
+// two half-tiles (four loads of this wave) may stay in flight; near the end nothing is assumed
+#define GT_WAIT(t)                                                                           \
+  do {                                                                                       \
+    if (GT_ABL == 4) break;                                                                  \
+    if ((t) + 3 < T_) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                       \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+  } while (0)
+#define GT_READ(kk, cur)                                                                     \
+  do {                                                                                       \
+    if (GT_ABL == 2) break;                                                                  \
+    const char* ab_ = sm + (cur) + a_off + (rd0 ^ ((kk) << 6));                              \
+    const char* bb_ = sm + (cur) + b_off + (rd0 ^ ((kk) << 6));                              \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                         \
+        bf[ni] = *reinterpret_cast<const frag*>(bb_ + ni * 2048);                            \
+    _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                         \
+        af[mi] = *reinterpret_cast<const frag*>(ab_ + mi * 2048);                            \
+  } while (0)
+#define GT_MFMA()                                                                            \
+  do {                                                                                       \
+    if (GT_ABL == 3) {                                                                       \
+      _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"v"(af[mi]));       \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(bf[ni]));       \
+      break;                                                                                 \
+    }                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                           \
+    _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                         \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                       \
+          acc[mi][ni] = Mfma<T>::run(bf[ni], af[mi], acc[mi][ni]);                           \
+    __builtin_amdgcn_s_setprio(0);                                                           \
+  } while (0)
+#define GT_SLOT_END(t)                                                                       \
+  do {                                                                                       \
+    GT_WAIT(t);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    __builtin_amdgcn_s_barrier();                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // H0..H2 have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (g == 1) {   // the second group runs one slot behind the first
+    GT_ISSUE(3, -1);
+    GT_SLOT_END(-1);
+  }
+
+  for (int t = 0; t < T_; ++t) {
+    const int cur = (t & 1) ? GT_STAGE : 0;
+    // MEM slot, k-step 0
+    GT_ISSUE(0, t);
+    GT_READ(0, cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GT_SLOT_END(t);
+    // MFMA slot
+    GT_ISSUE(1, t);
+    GT_MFMA();
+    GT_SLOT_END(t);
+    // MEM slot, k-step 1
+    GT_ISSUE(2, t);
+    GT_READ(1, cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GT_SLOT_END(t);
+    // MFMA slot
+    GT_ISSUE(3, t);
+    GT_MFMA();
+    GT_SLOT_END(t);
+  }
+  if (g == 0) __builtin_amdgcn_s_barrier();
+#undef GT_ISSUE
+#undef GT_WAIT
+#undef GT_READ
+#undef GT_MFMA
+#undef GT_SLOT_END
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // acc[mi][ni][r]: row m = 16 mi + (lane & 15) of the wave's 128 rows; W slot 16 ni + 4 q4 + r, which
+  // the load mapping above made output column 16 q4 + 4 ni + r (plain) or gate/up column 8 q4 + 4 (ni & 1) + r.
+  T* yg = (T*)p.y;
+  const T* bias = (const T*)p.bias;
+  if (EPI == 1) {
+    const int j0 = tn * 128 + wc * 32 + q4 * 8;
+    if (j0 < ncols) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = tm * 256 + g * 128 + mi * 16 + r16;
+        Vec<T, 8> o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            o.v[h * 4 + r] = silu_mul_one<T>(from_f32<T>(acc[mi][h][r]), from_f32<T>(acc[mi][2 + h][r]));
+        if (m < p.M) stvec<T, 8>(yg + (int64_t)m * p.ldy + j0, o);
+      }
+    }
+  } else {
+    const int n0 = tn * 256 + wc * 64 + q4 * 16;
+    if (n0 < p.N) {
+      float bv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+      if (bias != nullptr) {
+        const Vec<T, 8> b0 = ldvec<T, 8>(bias + n0), b1 = ldvec<T, 8>(bias + n0 + 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bv[j] = to_f32(b0.v[j]); bv[8 + j] = to_f32(b1.v[j]); }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = tm * 256 + g * 128 + mi * 16 + r16;
+        Vec<T, 8> o0, o1;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o0.v[ni * 4 + r] = from_f32<T>(acc[mi][ni][r] + bv[ni * 4 + r]);
+            o1.v[ni * 4 + r] = from_f32<T>(acc[mi][2 + ni][r] + bv[8 + ni * 4 + r]);
+          }
+        if (m < p.M) {
+          stvec<T, 8>(yg + (int64_t)m * p.ldy + n0, o0);
+          stvec<T, 8>(yg + (int64_t)m * p.ldy + n0 + 8, o1);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int EPI>
+int launch_gemm_tiled(const GemmTiledParams& p, hipStream_t st) {
+  auto kern = gemm_tiled_kernel<T, EPI>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS);
+  const int groups = (p.nsuper + 7) / 8;   // every XCD label gets the same number of 8 x 4 blocks
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * 32)), dim3(512), GT_LDS, st, p);
+  MI355_CHECK_LAUNCH("mi355_linear_tiled");
+  return MI355_OK;
+}
+
+}  // namespace
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" int mi355_linear_tiled_supported(int64_t m, int64_t n, int64_t k, int dtype, int epilogue) {
+  if (dtype != MI355_BF16 && dtype != MI355_F16) return 0;
+  if (m < 1 || n < 16 || k < 128 || (k & 63) != 0 || m > (1 << 24) || n > (1 << 24)) return 0;
+  if (epilogue == 1) return (n % 16 == 0) ? 1 : 0;   // 8 gate + 8 up columns per lane
+  return (epilogue == 0 && n % 16 == 0) ? 1 : 0;
+}
+
+extern "C" int mi355_linear_tiled(void* y, const void* x, const void* w, const void* bias, int64_t m,
+                                  int64_t n, int64_t k, int64_t x_stride, int dtype, int epilogue,
+                                  void* stream) {
+  MI355_REQUIRE(y && x && w, MI355_ERR_INVALID, "mi355_linear_tiled: null pointer");
+  MI355_REQUIRE(mi355_linear_tiled_supported(m, n, k, dtype, epilogue), MI355_ERR_UNSUPPORTED,
+                "mi355_linear_tiled: needs a 16-bit dtype, K %% 64 == 0, K >= 128, N %% 16 == 0 (m=%ld n=%ld k=%ld "
+                "dtype=%d epilogue=%d)", (long)m, (long)n, (long)k, dtype, epilogue);
+  MI355_REQUIRE(x_stride >= k && x_stride % 8 == 0, MI355_ERR_INVALID,
+                "mi355_linear_tiled: x_stride must be >= K and a multiple of 8 elements");
+  MI355_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && (bias == nullptr || aligned16(bias)),
+                MI355_ERR_INVALID, "mi355_linear_tiled: pointers must be 16-byte aligned");
+  MI355_REQUIRE(epilogue == 0 || bias == nullptr, MI355_ERR_UNSUPPORTED,
+                "mi355_linear_tiled: no bias with the SiLU-and-mul epilogue");
+  GemmTiledParams p;
+  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k;
+  p.ldx = x_stride;
+  const int ncols = epilogue == 1 ? (int)(n / 2) : (int)n;
+  p.ldy = ncols;
+  p.mt = cdiv(m, 256);
+  p.nt = epilogue == 1 ? cdiv(ncols, 128) : cdiv(ncols, 256);
+  p.snt = cdiv(p.nt, 4);
+  p.nsuper = cdiv(p.mt, 8) * p.snt;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI355_BF16)
+    return epilogue == 1 ? launch_gemm_tiled<bf16_t, 1>(p, st) : launch_gemm_tiled<bf16_t, 0>(p, st);
+  return epilogue == 1 ? launch_gemm_tiled<f16_t, 1>(p, st) : launch_gemm_tiled<f16_t, 0>(p, st);
+}

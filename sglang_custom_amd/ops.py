@@ -476,6 +476,30 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+def linear_tiled_supported(m: int, n: int, k: int, dtype: torch.dtype, silu_mul: bool = False) -> bool:
+    """Whether linear_tiled serves the shape (16-bit, K % 64 == 0, K >= 128, N % 16 == 0)."""
+    return dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib_().mi355_linear_tiled_supported(m, n, k, _DT[dtype], 1 if silu_mul else 0))
+
+
+def linear_tiled(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 silu_mul: bool = False) -> torch.Tensor:
+    """Prefill-sized F.linear(x, weight, bias) (layers/quantization/unquant.py:110-122) on the
+    256 x 256-tile matrix-core kernel; silu_mul=True applies SiluAndMul (layers/activation.py:55-65)
+    to the [gate; up] output in the epilogue and returns [M, N / 2]."""
+    _gpu(x, weight, bias)
+    assert x.dim() == 2 and x.stride(1) == 1 and weight.is_contiguous() and weight.dtype == x.dtype
+    M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K
+    y = torch.empty((M, N // 2 if silu_mul else N), dtype=x.dtype, device=x.device)
+    if M == 0:
+        return y
+    check(_lib_().mi355_linear_tiled(y.data_ptr(), x.data_ptr(), weight.data_ptr(), _p(bias), M, N, K,
+                                     x.stride(0), _dt(x), 1 if silu_mul else 0, _stream(x)), "linear_tiled")
+    return y
+
+
 def pack_weight(weight: torch.Tensor) -> torch.Tensor:
     """[N, K] 16-bit weight -> MFMA-fragment-ordered copy for linear_packed (decode GEMMs)."""
     _gpu(weight)
