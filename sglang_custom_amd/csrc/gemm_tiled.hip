@@ -73,8 +73,8 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   const int ncols = EPI == 1 ? (p.N >> 1) : p.N;   // output columns
 
   // ---- per-lane source pointers of the eight load instructions a wave issues per K tile -----
-  // half-tile `which`: 0 = x rows 0..127, 1 = W rows 0..127, 2 = W rows 128..255, 3 = x rows 128..255
-  // (the order in which they are requested: H[4 t + which])
+  // half-tile `which`: 0 = x rows 0..127, 1 = W rows 0..127, 2 = W rows 128..255, 3 = x rows 128..255;
+  // a half-tile is 16 pieces of 8 rows x 128 B, wave w issues pieces 2 w and 2 w + 1 of every half-tile
   const T* src[4][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -98,33 +98,44 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
       src[1 + h][i] = wg + (int64_t)n * p.K + c * 8;
     }
   }
-  const int lds_half[4] = {0, 2 * GT_HALF, 3 * GT_HALF, GT_HALF};
+  // LDS image of a K tile: x rows 0..255 (two halves), then W rows 0..255 (two halves)
+  constexpr int LX0 = 0, LX1 = GT_HALF, LW0 = 2 * GT_HALF, LW1 = 3 * GT_HALF;
   char* const lds_w = sm + wave * 2048;   // this wave's two 1-KiB pieces inside a half-tile
 
-  // ---- prologue: H0..H4 = all of tile 0 and x rows 0..127 of tile 1 ---------------------------
+  // Slot schedule (a slot = the time between two barriers; a wave is in a READ slot or a MATRIX slot):
+  //   even slot 2u requests W(u + 1) (both halves); odd slot 2u + 1 requests x rows 128..255 of tile
+  //   u + 1, then x rows 0..127 of tile u + 2.  Group 0 reads tile t in slot 2t and multiplies in slot
+  //   2t + 1; group 1 one slot later.  So per wave and loop tile t:
+  //     group 0: READ slot requests W(t + 1),               MATRIX slot x1(t + 1) and x0(t + 2)
+  //     group 1: READ slot requests x1(t + 1) and x0(t + 2), MATRIX slot W(t + 2)
+  // and at the end of an even slot six of the wave's loads may still be in flight, at the end of an
+  // odd slot four (everything a later slot reads has been waited for by its issuing wave before the
+  // barrier in front of that slot).
+  const T* rdA[2];  const T* rdB[2];   // READ slot: first and second half-tile requested
+  const T* mxA[2];  const T* mxB[2];   // MATRIX slot
 #pragma unroll
-  for (int h = 0; h < 4; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(src[h][i], lds_w + lds_half[h] + i * 1024);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) glds16(src[0][i] + 64, lds_w + GT_STAGE + lds_half[0] + i * 1024);
-
-  // The wave's own request sequence: entry e of loop tile t is H[4 t + 5 + g + e]; `which` and the
-  // tile distance d (1 or 2) of each entry are fixed per group.
-  const T* seq[4][2];
-  int seq_lds[4];   // LDS offset (without the tile-parity term) of the entry's half-tile
-  int seq_d[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int idx = e + 1 + g, which = idx & 3;
-    seq_d[e] = 1 + (idx >> 2);
-    seq_lds[e] = which == 0 ? lds_half[0] : which == 1 ? lds_half[1] : which == 2 ? lds_half[2] : lds_half[3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const T* s = which == 0 ? src[0][i] : which == 1 ? src[1][i] : which == 2 ? src[2][i] : src[3][i];
-      seq[e][i] = s + seq_d[e] * 64;   // at t = 0
-    }
+  for (int i = 0; i < 2; ++i) {
+    rdA[i] = g == 0 ? src[1][i] + 64 : src[3][i] + 64;
+    rdB[i] = g == 0 ? src[2][i] + 64 : src[0][i] + 128;
+    mxA[i] = g == 0 ? src[3][i] + 64 : src[1][i] + 128;
+    mxB[i] = g == 0 ? src[0][i] + 128 : src[2][i] + 128;
   }
+  const int rdA_l = g == 0 ? LW0 : LX1, rdB_l = g == 0 ? LW1 : LX0;
+  const int mxA_l = g == 0 ? LX1 : LW0, mxB_l = g == 0 ? LX0 : LW1;
+  // tile parity of each request relative to the loop tile t: (t + d) & 1
+  const int rdA_d = 1, rdB_d = g == 0 ? 1 : 2, mxA_d = g == 0 ? 1 : 2, mxB_d = 2;
+
+  // ---- prologue: all of tile 0 and x rows 0..127 of tile 1 ------------------------------------
+#pragma unroll
+  for (int i = 0; i < 2; ++i) glds16(src[0][i], lds_w + LX0 + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) glds16(src[1][i], lds_w + LW0 + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) glds16(src[2][i], lds_w + LW1 + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) glds16(src[3][i], lds_w + LX1 + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) glds16(src[0][i] + 64, lds_w + GT_STAGE + LX0 + i * 1024);
 
   // ---- fragment read addresses ----------------------------------------------------------------
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -136,101 +147,98 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  frag af[8], bf[4];
+  frag af[2][8], bf[2][4];
 #ifndef GT_ABL
 #define GT_ABL 0   // development ablations: 1 no loads in the loop, 2 no fragment reads, 3 no MFMA, 4 no vmcnt waits
 #endif
   if (GT_ABL == 2) {
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const frag*>(sm + rd0 + mi * 2048);
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const frag*>(sm + rd0 + ni * 2048 + 32768);
+      for (int mi = 0; mi < 8; ++mi) af[kk][mi] = *reinterpret_cast<const frag*>(sm + rd0 + mi * 2048 + kk * 64);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bf[kk][ni] = *reinterpret_cast<const frag*>(sm + rd0 + ni * 2048 + 32768 + kk * 64);
+    }
   }
 
-#ifndef GT_ABL
-#define GT_ABL 0   // development ablations: 1 no loads in the loop, 2 no fragment reads, 3 no MFMA, 4 no vmcnt waits
-#endif
-#define GT_ISSUE(e, t)                                                                       \
+// two 1-KiB pieces of one half-tile; `t` = loop tile, d = tile distance; TAIL: skip tiles past the end
+#define GT_LOAD2(ptr, ldso, d, t, TAIL)                                                      \
   do {                                                                                       \
-    if (GT_ABL != 1 && (t) + seq_d[e] < T_) {                                                               \
-      char* d_ = lds_w + ((((t) + seq_d[e]) & 1) ? GT_STAGE : 0) + seq_lds[e];               \
-      glds16(seq[e][0] + (int64_t)(t) * 64, d_);                                             \
-      glds16(seq[e][1] + (int64_t)(t) * 64, d_ + 1024);                                      \
+    if (GT_ABL != 1 && (!(TAIL) || (t) + (d) < T_)) {                                        \
+      char* d_ = lds_w + ((((t) + (d)) & 1) ? GT_STAGE : 0) + (ldso);                        \
+      glds16(ptr[0] + (int64_t)(t) * 64, d_);                                                \
+      glds16(ptr[1] + (int64_t)(t) * 64, d_ + 1024);                                         \
     }                                                                                        \
   } while (0)
-// two half-tiles (four loads of this wave) may stay in flight; near the end nothing is assumed
-#define GT_WAIT(t)                                                                           \
+#define GT_WAIT(n_even, TAIL)                                                                \
   do {                                                                                       \
     if (GT_ABL == 4) break;                                                                  \
-    if ((t) + 3 < T_) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                       \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+    if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
+    else if (n_even) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
   } while (0)
-#define GT_READ(kk, cur)                                                                     \
+#define GT_SLOT_END()                                                                        \
   do {                                                                                       \
-    if (GT_ABL == 2) break;                                                                  \
-    const char* ab_ = sm + (cur) + a_off + (rd0 ^ ((kk) << 6));                              \
-    const char* bb_ = sm + (cur) + b_off + (rd0 ^ ((kk) << 6));                              \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                         \
-        bf[ni] = *reinterpret_cast<const frag*>(bb_ + ni * 2048);                            \
-    _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                         \
-        af[mi] = *reinterpret_cast<const frag*>(ab_ + mi * 2048);                            \
-  } while (0)
-#define GT_MFMA()                                                                            \
-  do {                                                                                       \
-    if (GT_ABL == 3) {                                                                       \
-      _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"v"(af[mi]));       \
-      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(bf[ni]));       \
-      break;                                                                                 \
-    }                                                                                        \
-    __builtin_amdgcn_s_setprio(1);                                                           \
-    _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                         \
-      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                       \
-          acc[mi][ni] = Mfma<T>::run(bf[ni], af[mi], acc[mi][ni]);                           \
-    __builtin_amdgcn_s_setprio(0);                                                           \
-  } while (0)
-#define GT_SLOT_END(t)                                                                       \
-  do {                                                                                       \
-    GT_WAIT(t);                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     __builtin_amdgcn_s_barrier();                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                       \
   } while (0)
+#define GT_TILE(t, TAIL)                                                                     \
+  do {                                                                                       \
+    const int cur_ = ((t) & 1) ? GT_STAGE : 0;                                               \
+    /* READ slot: the fragments of both 32-deep k-steps of tile t */                         \
+    GT_LOAD2(rdA, rdA_l, rdA_d, t, TAIL);                                                    \
+    GT_LOAD2(rdB, rdB_l, rdB_d, t, TAIL);                                                    \
+    if (GT_ABL != 2) {                                                                       \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
+        const char* ab_ = sm + cur_ + a_off + (rd0 ^ (kk << 6));                             \
+        const char* bb_ = sm + cur_ + b_off + (rd0 ^ (kk << 6));                             \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                     \
+            bf[kk][ni] = *reinterpret_cast<const frag*>(bb_ + ni * 2048);                    \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                     \
+            af[kk][mi] = *reinterpret_cast<const frag*>(ab_ + mi * 2048);                    \
+      }                                                                                      \
+    }                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+    GT_WAIT(g == 0, TAIL);                                                                   \
+    GT_SLOT_END();                                                                           \
+    /* MATRIX slot */                                                                        \
+    GT_LOAD2(mxA, mxA_l, mxA_d, t, TAIL);                                                    \
+    GT_LOAD2(mxB, mxB_l, mxB_d, t, TAIL);                                                    \
+    if (GT_ABL == 3) {                                                                       \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"v"(af[kk][mi])); \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(bf[kk][ni])); \
+      }                                                                                      \
+    } else {                                                                                 \
+      __builtin_amdgcn_s_setprio(1);                                                         \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                       \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                     \
+          _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
+              acc[mi][ni] = Mfma<T>::run(bf[kk][ni], af[kk][mi], acc[mi][ni]);               \
+      __builtin_amdgcn_s_setprio(0);                                                         \
+    }                                                                                        \
+    GT_WAIT(g != 0, TAIL);                                                                   \
+    GT_SLOT_END();                                                                           \
+  } while (0)
 
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // H0..H2 have landed
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  if (g == 1) {   // the second group runs one slot behind the first
-    GT_ISSUE(3, -1);
-    GT_SLOT_END(-1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // x rows 0..127 and W of tile 0 have landed
+  GT_SLOT_END();
+  if (g == 1) {   // the second group runs one slot behind the first: its slot 0 only requests W(1)
+    GT_LOAD2(mxA, mxA_l, mxA_d, -1, true);
+    GT_LOAD2(mxB, mxB_l, mxB_d, -1, true);
+    if (T_ > 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // x rows 128..255 of tile 0 have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GT_SLOT_END();
   }
-
-  for (int t = 0; t < T_; ++t) {
-    const int cur = (t & 1) ? GT_STAGE : 0;
-    // MEM slot, k-step 0
-    GT_ISSUE(0, t);
-    GT_READ(0, cur);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    GT_SLOT_END(t);
-    // MFMA slot
-    GT_ISSUE(1, t);
-    GT_MFMA();
-    GT_SLOT_END(t);
-    // MEM slot, k-step 1
-    GT_ISSUE(2, t);
-    GT_READ(1, cur);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    GT_SLOT_END(t);
-    // MFMA slot
-    GT_ISSUE(3, t);
-    GT_MFMA();
-    GT_SLOT_END(t);
-  }
+  int t = 0;
+  for (; t + 3 < T_; ++t) GT_TILE(t, false);   // every request exists: no conditions in the loop
+  for (; t < T_; ++t) GT_TILE(t, true);
   if (g == 0) __builtin_amdgcn_s_barrier();
-#undef GT_ISSUE
+#undef GT_LOAD2
 #undef GT_WAIT
-#undef GT_READ
-#undef GT_MFMA
 #undef GT_SLOT_END
+#undef GT_TILE
 
   // ---- epilogue ---------------------------------------------------------------------------------
   // acc[mi][ni][r]: row m = 16 mi + (lane & 15) of the wave's 128 rows; W slot 16 ni + 4 q4 + r, which
