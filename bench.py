@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ttft-repeats", type=int, default=3)
+    ap.add_argument("--prefill-gemm", default=None, choices=["library", "tiled"],
+                    help="prefill (M > 64) 16-bit GEMMs: hipBLASLt (default) or the hand-written 256x256-tile kernel")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous rehearsal without a GPU: every rank joins a gloo group, meets at the "
                          "barriers and rank 0 prints the line's bookkeeping fields (value null)")
@@ -304,6 +306,10 @@ def main():
         dist.init_process_group("nccl", world_size=world, rank=rank,
                                 device_id=torch.device(f"cuda:{local_rank}"))
     cfg = hf_config_dict(args.model, args.dtype)
+    if args.prefill_gemm:
+        from sglang_custom_amd.layers.quantization import unquant
+
+        unquant.PREFILL_GEMM = args.prefill_gemm
     bs, in_len = args.batch_size, args.input_len
     out_len = args.warmup + args.steps + 1
     sa = ServerArgs(dtype=args.dtype, max_total_tokens=bs * (in_len + out_len + 8) + 64,
@@ -392,6 +398,7 @@ def main():
                    "hip_graph": bool(graph_ok)},
         "ttft_p50_ms": round(ttft * 1e3, 2),
         "prefill_tok_s": round(bs * in_len / ttft, 1),
+        "prefill_gemm": args.prefill_gemm or os.environ.get("MI355_PREFILL_GEMM", "library"),
         "step_bytes_algorithmic": int(bytes_step),
         "step_hbm_gbs": round(step_gbs, 1),
         "step_hbm_frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),

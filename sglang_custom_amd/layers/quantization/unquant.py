@@ -2,8 +2,12 @@
 (python/sglang/srt/layers/quantization/unquant.py:110-122).
 
 Decode-sized inputs (M <= 64 rows) and every fp32 input go to the hand-written kernels behind
-mi355_linear (weight-streaming MFMA / exact-fp32 tiled).  Large-M bf16/f16 GEMMs (prefill) are
-plain library GEMMs: torch.nn.functional.linear -> hipBLASLt."""
+mi355_linear (weight-streaming MFMA / exact-fp32 tiled).  Large-M bf16/f16 GEMMs (prefill) have two
+implementations: the library GEMM (torch.nn.functional.linear -> hipBLASLt, the default: it is the
+faster of the two on MI355X) and the hand-written 256 x 256-tile matrix-core kernel behind
+mi355_linear_tiled (PREFILL_GEMM = "tiled", env MI355_PREFILL_GEMM), which also fuses SiLU-and-mul
+into the gate_up projection."""
+import os
 from typing import Optional
 
 import torch
@@ -15,6 +19,17 @@ SKINNY_MAX_M = 64
 # Deferred split-K reduction / fused decode step (bit-identical to the unfused kernels; the switch
 # exists so that tests and profiles can run both).
 DECODE_FUSION = True
+# "library" (hipBLASLt) | "tiled" (mi355_linear_tiled) for 16-bit GEMMs with more than SKINNY_MAX_M rows
+PREFILL_GEMM = os.environ.get("MI355_PREFILL_GEMM", "library")
+# below this many 256 x 256 output tiles the one-tile-per-workgroup kernel leaves most CUs idle
+TILED_MIN_TILES = 192
+
+
+def _use_tiled(m: int, n_out_tiles_cols: int, n: int, k: int, dtype, silu_mul: bool) -> bool:
+    if PREFILL_GEMM != "tiled":
+        return False
+    tiles = ((m + 255) // 256) * ((n_out_tiles_cols + 255) // 256)
+    return tiles >= TILED_MIN_TILES and get_ops().linear_tiled_supported(m, n, k, dtype, silu_mul)
 
 
 def pack_for_decode(layer) -> None:
@@ -57,6 +72,12 @@ def gate_up_silu_mul(layer, act_fn, x: torch.Tensor) -> torch.Tensor:
     wp = getattr(layer, "weight_packed_gate_up", None)
     if wp is not None and x2.shape[0] <= SKINNY_MAX_M and x2.stride(0) % 8 == 0:
         y = get_ops().linear_packed_silu_mul(x2, wp, layer.weight.shape[0])
+        return y.view(*x.shape[:-1], y.shape[-1])
+    w = layer.weight
+    if (x2.is_cuda and isinstance(layer.quant_method, UnquantizedLinearMethod) and getattr(layer, "bias", None) is None
+            and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
+            and _use_tiled(x2.shape[0], w.shape[0], w.shape[0], w.shape[1], x2.dtype, True)):
+        y = get_ops().linear_tiled(x2, w, None, silu_mul=True)
         return y.view(*x.shape[:-1], y.shape[-1])
     gate_up, _ = layer(x)
     return act_fn(gate_up)
@@ -140,6 +161,10 @@ class UnquantizedLinearMethod:
         x2 = x.view(-1, x.shape[-1])
         if x2.shape[0] <= SKINNY_MAX_M or x2.dtype == torch.float32 or not x2.is_cuda:
             y = decode_linear(layer, x2, bias)
+        elif (x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and layer.weight.is_contiguous()
+              and _use_tiled(x2.shape[0], layer.weight.shape[0], layer.weight.shape[0], layer.weight.shape[1],
+                             x2.dtype, False)):
+            y = get_ops().linear_tiled(x2, layer.weight, bias)
         else:
             y = F.linear(x2, layer.weight, bias)
         return y.view(*x.shape[:-1], y.shape[-1])

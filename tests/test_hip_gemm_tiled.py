@@ -1,0 +1,155 @@
+"""The prefill-sized projection kernel (mi355_linear_tiled, through the C ABI) -- the reference's
+UnquantizedLinearMethod.apply = F.linear (python/sglang/srt/layers/quantization/unquant.py:110-122)
+and LlamaMLP's gate_up_proj + SiluAndMul (models/llama.py:94-98, layers/activation.py:55-65).
+
+Small shapes are compared with F.linear on the CPU (the reference's own call) and the oracle's
+silu_and_mul; at the benchmark's shapes the oracle would take minutes, so parity is checked through
+size-independent properties (exact power-of-two scaling, a row's bits do not depend on the rows that
+share the launch, permuting weight rows permutes outputs, fused SiLU-and-mul == the unfused pair bit
+for bit) plus float64 evaluations of sampled rows on the GPU.  Tolerance: one rounding of the output
+dtype on top of fp32 accumulation noise, 2^-7 * max|ref| + 1e-3 for bf16 (8 significand bits)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_custom_amd import ops as _ops
+    from sglang_custom_amd import _lib
+
+    _lib.load()
+    return _ops
+
+
+def _data(m, n, k, dtype, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(m, k, device=DEV, generator=g).to(dtype)
+    w = (torch.randn(n, k, device=DEV, generator=g) * k ** -0.5).to(dtype)
+    return x, w
+
+
+# ragged edges in M and N, the smallest K, K = 64 * odd, one tile, many tiles
+SMALL = [(1, 16, 128), (65, 48, 192), (256, 256, 128), (300, 272, 320), (513, 1040, 256), (100, 4096, 1024)]
+
+
+@pytest.mark.parametrize("m,n,k", SMALL)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_tiled_vs_oracle(ops, m, n, k, dtype):
+    import torch.nn.functional as F   # F.linear on CPU IS the reference's apply (unquant.py:122)
+
+    x, w = _data(m, n, k, dtype, m + n + k)
+    bias = torch.randn(n, device=DEV).to(dtype)
+    for b in (None, bias):
+        y = ops.linear_tiled(x, w, b)
+        ref = F.linear(x.cpu(), w.cpu(), None if b is None else b.cpu())
+        # the oracle accumulates in another order: allow one unit in the last place of the output dtype
+        tol = (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) * ref.float().abs().max().item() + 1e-3
+        assert (y.cpu().float() - ref.float()).abs().max().item() <= tol
+        # and float64 on the GPU: the kernel's fp32 accumulation, rounded once
+        r64 = x.double() @ w.double().t() + (0 if b is None else b.double())
+        assert (y.double() - r64).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 32, 128), (300, 544, 192), (777, 2048, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_tiled_silu_mul_equals_unfused(ops, m, n, k, dtype):
+    """SiLU-and-mul in the epilogue rounds gate and up to the model dtype first: the same bits as
+    the kernel's plain output followed by mi355_silu_and_mul, and the oracle's values."""
+    import torch.nn.functional as F
+
+    from oracle import ops_ref
+
+    x, w = _data(m, n, k, dtype, 7 * m + n)
+    fused = ops.linear_tiled(x, w, None, silu_mul=True)
+    assert fused.shape == (m, n // 2)
+    assert torch.equal(fused, ops.silu_and_mul(ops.linear_tiled(x, w)))
+    ref = ops_ref.silu_and_mul(F.linear(x.cpu(), w.cpu()))
+    tol = (2 ** -6 if dtype == torch.bfloat16 else 2 ** -9) * ref.float().abs().max().item() + 1e-3
+    assert (fused.cpu().float() - ref.float()).abs().max().item() <= tol
+
+
+def test_linear_tiled_refuses_what_it_does_not_serve(ops):
+    from sglang_custom_amd._lib import Mi355Error
+
+    x, w = _data(8, 24, 128, torch.bfloat16, 0)   # N % 16 != 0
+    assert not ops.linear_tiled_supported(8, 24, 128, torch.bfloat16)
+    with pytest.raises(Mi355Error):
+        ops.linear_tiled(x, w)
+    x, w = _data(8, 32, 96, torch.bfloat16, 0)    # K % 64 != 0
+    assert not ops.linear_tiled_supported(8, 32, 96, torch.bfloat16)
+    with pytest.raises(Mi355Error):
+        ops.linear_tiled(x, w)
+    assert not ops.linear_tiled_supported(8, 32, 128, torch.float32)
+
+
+# Llama-3-8B projections (qkv, o, gate_up, down) and the Llama-3-70B TP=8 shard shapes
+FULL = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)]
+
+
+@pytest.mark.parametrize("n,k", FULL)
+def test_linear_tiled_properties_at_full_size(ops, n, k):
+    m = 4096 + 77
+    x, w = _data(m, n, k, torch.bfloat16, n + k)
+    y = ops.linear_tiled(x, w)
+    # exact under power-of-two scaling of the activations
+    assert torch.equal(ops.linear_tiled(x * 2, w), y * 2)
+    assert torch.equal(ops.linear_tiled(x * 0.25, w), y * 0.25)
+    # a row does not see its neighbours: same bits alone, in a ragged batch, at another tile position
+    for rows in ([0], [m - 1], list(range(300, 300 + 65)), list(range(m - 1, m - 600, -1))):
+        idx = torch.tensor(rows, device=DEV)
+        assert torch.equal(ops.linear_tiled(x[idx].contiguous(), w), y[idx]), rows[:2]
+    # a strided activation (a column slice of a wider buffer) reads the same values
+    wide = torch.zeros(m, k + 64, device=DEV, dtype=x.dtype)
+    wide[:, :k] = x
+    assert torch.equal(ops.linear_tiled(wide[:, :k], w), y)
+    # permuting output channels permutes the outputs
+    perm = torch.randperm(n, device=DEV)
+    assert torch.equal(ops.linear_tiled(x, w[perm].contiguous()), y[:, perm])
+    # float64 evaluation of sampled rows
+    rows = torch.randint(0, m, (48,), device=DEV)
+    ref = x[rows].double() @ w.double().t()
+    assert (y[rows].double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-3
+    # the gate_up shapes: fused SiLU-and-mul == unfused, bit for bit
+    if n in (28672, 7168):
+        assert torch.equal(ops.linear_tiled(x, w, None, silu_mul=True), ops.silu_and_mul(y))
+
+
+def test_prefill_through_the_tiled_gemm_matches_the_library_path(ops):
+    """A prefill of the bf16 model with PREFILL_GEMM = "tiled" against the same prefill through the
+    library GEMM: logits within bf16 accumulation-order noise, and the greedy tokens agree wherever
+    the library path's top-2 margin exceeds that noise."""
+    import numpy as np
+
+    from sglang_custom_amd import bench_one_batch as bob
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.layers.quantization import unquant
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+    from sglang_custom_amd.server_args import ServerArgs
+
+    cfg = hf_config_dict("tiny-llama-d128", "bfloat16")
+    w = make_synthetic_llama_weights(cfg, seed=4321, dtype=torch.bfloat16)
+    rng = np.random.RandomState(3)
+    prompts = [rng.randint(0, cfg["vocab_size"], n).tolist() for n in (700, 513, 300, 64)]
+    sa = ServerArgs(dtype="bfloat16", max_total_tokens=4096, max_running_requests=8, disable_cuda_graph=True)
+    mr = ModelRunner(ModelConfig(cfg, dtype="bfloat16"), sa, weights={k: v.cuda() for k, v in w.items()})
+    outs = {}
+    keep, keep_min = unquant.PREFILL_GEMM, unquant.TILED_MIN_TILES
+    try:
+        for mode in ("library", "tiled"):
+            unquant.PREFILL_GEMM, unquant.TILED_MIN_TILES = mode, 1
+            mr.token_to_kv_pool_allocator.clear()
+            mr.req_to_token_pool.clear()
+            nxt, logits, _ = bob.extend([Req(i, p) for i, p in enumerate(prompts)], mr)
+            outs[mode] = (nxt.cpu(), logits.float().cpu())
+    finally:
+        unquant.PREFILL_GEMM, unquant.TILED_MIN_TILES = keep, keep_min
+    (t_lib, l_lib), (t_til, l_til) = outs["library"], outs["tiled"]
+    assert (l_lib - l_til).abs().max().item() < 5e-2
+    top2 = l_lib.topk(2, dim=-1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 1e-1
+    assert torch.equal(t_lib[sure], t_til[sure])
