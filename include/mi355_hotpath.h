@@ -382,6 +382,19 @@ int mi355_fp8_scaled_mm(void* y, const uint8_t* xq, const uint8_t* wq, const flo
                         const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
                         void* workspace, int64_t workspace_bytes, int out_dtype, void* stream);
 
+/* mi355_fp8_scaled_mm at prefill sizes: the 256 x 256-tile kernel of mi355_linear_tiled on fp8 operands
+ * (v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: twice the 16-bit matrix rate), the
+ * per-token / per-channel scales applied to the fp32 accumulator as (acc * x_scale[m]) * w_scale[n],
+ * then bias, one rounding to out_dtype; epilogue 1 = SiLU-and-mul over wq = [gate; up] as in
+ * mi355_linear_tiled.  xq [M, K] and wq [N, K] contiguous e4m3fn bytes.  Needs K % 128 == 0, K >= 256,
+ * N % 16 == 0 (mi355_fp8_scaled_mm_tiled_supported returns 1); no workspace.
+ * replaces: apply_fp8_linear's torch._scaled_mm / fp8_scaled_mm call at prefill sizes
+ *           (layers/quantization/fp8_utils.py:676-749, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu). */
+int mi355_fp8_scaled_mm_tiled_supported(int64_t m, int64_t n, int64_t k, int out_dtype, int epilogue);
+int mi355_fp8_scaled_mm_tiled(void* y, const uint8_t* xq, const uint8_t* wq, const float* x_scale,
+                              const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
+                              int out_dtype, int epilogue, void* stream);
+
 /* ---- K11 sampling --------------------------------------------------------------------------------
  * ids[b] = first index of max(logits[b,:])   (torch.argmax tie rule)
  * replaces: Sampler.forward greedy branch (layers/sampler.py:72-76). */

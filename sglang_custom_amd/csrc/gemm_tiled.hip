@@ -1,24 +1,28 @@
-// Large-M projection GEMM  y[M, N] = x[M, K] @ W[N, K]^T  (16-bit operands, fp32 accumulation) for
-// gfx950: the prefill side of UnquantizedLinearMethod.apply
-// (python/sglang/srt/layers/quantization/unquant.py:110-122), with the MLP's SiLU-and-mul
-// (python/sglang/srt/models/llama.py:94-98, layers/activation.py:55-65) optionally applied in the
-// epilogue.  The decode side (M <= 64) is the weight-streaming kernel in gemm.hip.
+// Large-M projection GEMM  y[M, N] = x[M, K] @ W[N, K]^T  for gfx950, fp32 accumulation on the matrix
+// cores: the prefill side of UnquantizedLinearMethod.apply
+// (python/sglang/srt/layers/quantization/unquant.py:110-122) for 16-bit operands and of
+// apply_fp8_linear (layers/quantization/fp8_utils.py:676-749) for fp8 W8A8 operands with per-token /
+// per-channel scales, with the MLP's SiLU-and-mul (python/sglang/srt/models/llama.py:94-98,
+// layers/activation.py:55-65) optionally applied in the epilogue.  The decode side (M <= 64) is the
+// weight-streaming kernel in gemm.hip.
 //
 // Structure (one 512-thread workgroup per CU, 128 KiB of LDS, one 256 x 256 output tile):
-//   * K is walked in tiles of 64; a tile's operands live in LDS as four HALF-TILES of 128 rows x 128
-//     bytes (x rows 0..127, x rows 128..255, W rows 0..127, W rows 128..255), two tiles resident;
+//   * K is walked in tiles of 128 BYTES per row (64 16-bit or 128 fp8 elements); a tile's operands
+//     live in LDS as four HALF-TILES of 128 rows x 128 bytes (x rows 0..127, x rows 128..255, W rows
+//     0..127, W rows 128..255), two tiles resident;
 //   * the load unit writes LDS itself (global_load_lds_dwordx4, 8 rows x 128 B per wave-instruction:
-//     whole cache lines); every wave issues two such loads per SLOT, i.e. one half-tile per slot for
-//     the workgroup, five half-tiles ahead of the slot that first reads it, and waits with a COUNTED
-//     vmcnt so that two half-tiles stay in flight across every barrier;
+//     whole cache lines); every wave issues four such loads per SLOT (two half-tiles per slot for the
+//     workgroup), requested 2.5 slots or more before the slot that reads them, and waits with a
+//     COUNTED vmcnt so that loads stay in flight across every barrier;
 //   * the eight waves form two groups of four (group = row half of the tile, wave-in-group = 64
-//     output columns).  A wave alternates a MEM slot (12 ds_read_b128: the A/B fragments of one
-//     32-deep k-step) with an MFMA slot (32 x v_mfma_f32_16x16x32 on those fragments); the groups run
-//     one slot apart, so on every SIMD one wave's matrix work covers the other wave's LDS reads
-//     and load issue.  One s_barrier per slot.
-//   * LDS rows are 128 bytes; the 16-byte chunk index is XOR-ed with (row >> 1) & 7 on the SOURCE
-//     address of the load (the load unit writes lane-linear) and again on the fragment read:
-//     conflict-free ds_read_b128.
+//     output columns).  A wave alternates a READ slot (24 ds_read_b128: its A and B fragments of a
+//     whole K tile) with a MATRIX slot (64 x v_mfma_f32_16x16x32 on 16-bit operands, or 32 x
+//     v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales on fp8 operands: twice the 16-bit rate
+//     per byte staged); the groups run one slot apart, so on every SIMD one wave's matrix work covers
+//     the other wave's LDS reads.  One s_barrier per slot.
+//   * LDS rows are 128 bytes; the 16-byte chunk index is XOR-ed with a function of the row on the
+//     SOURCE address of the load (the load unit writes lane-linear) and again on the fragment read:
+//     conflict-free ds_read_b128 for 16-byte (16-bit) and 32-byte (fp8) fragments.
 //   * W rows are assigned to MFMA row slots so that a lane ends up with 16 consecutive output
 //     columns (or, for SiLU-and-mul, 8 gate columns and the 8 matching up columns): the epilogue
 //     writes whole 128-byte lines with 16-byte stores and needs no cross-lane traffic.
@@ -38,6 +42,8 @@ struct GemmTiledParams {
   const void* w;
   const void* bias;
   void* y;
+  const float* x_scale;   // fp8: per-token scales [M]
+  const float* w_scale;   // fp8: per-channel scales [N]
   int M, N, K;      // N = rows of W
   int64_t ldx;      // elements between rows of x
   int ldy;          // elements between rows of y
@@ -50,11 +56,24 @@ __device__ __forceinline__ void glds16(const void* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// EPI 0: y = T(acc (+ bias)); EPI 1: W = [gate; up] (N = 2 I rows), y[m, j] = silu_mul(T(gate_j), T(up_j))
-template <typename T, int EPI>
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// XOR applied to the 16-byte chunk index of LDS row r (depends on r & 15 only).  16-bit fragments
+// are one chunk per lane (chunk 4 kk + (lane >> 4)), fp8 fragments two (chunks 2 (lane >> 4) + {0, 1}):
+// each needs its own function for the 16-lane service groups of ds_read_b128 to hit 16 distinct
+// 16-byte bank groups.
+template <bool FP8> __device__ __forceinline__ int gt_swz(int r) {
+  return FP8 ? (((r >> 1) & 1) | (((r >> 3) & 1) << 2)) : ((r >> 1) & 7);
+}
+
+// T: output dtype and, for 16-bit GEMMs, the operand dtype.  FP8: operands are OCP e4m3fn bytes.
+// EPI 0: y = T(acc (+ bias)); EPI 1: W = [gate; up] (N = 2 I rows), y[m, j] = silu_mul(T(gate_j), T(up_j));
+// fp8: acc is first scaled, (acc * x_scale[m]) * w_scale[n].
+template <typename T, int EPI, bool FP8>
 __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   using frag = typename Mfma<T>::frag;
+  constexpr int ES = FP8 ? 1 : 2;   // operand element bytes
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, wc = wave & 3;
@@ -67,24 +86,24 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   const int tm = sup_m * 8 + (within & 7), tn = sup_n * 4 + (within >> 3);
   if (tm >= p.mt || tn >= p.nt) return;
 
-  const int T_ = p.K >> 6;   // K tiles
-  const T* xg = (const T*)p.x;
-  const T* wg = (const T*)p.w;
+  const int T_ = (p.K * ES) >> 7;   // K tiles of 128 bytes per row
+  const char* xg = (const char*)p.x;
+  const char* wg = (const char*)p.w;
   const int ncols = EPI == 1 ? (p.N >> 1) : p.N;   // output columns
 
   // ---- per-lane source pointers of the eight load instructions a wave issues per K tile -----
   // half-tile `which`: 0 = x rows 0..127, 1 = W rows 0..127, 2 = W rows 128..255, 3 = x rows 128..255;
   // a half-tile is 16 pieces of 8 rows x 128 B, wave w issues pieces 2 w and 2 w + 1 of every half-tile
-  const T* src[4][2];
+  const char* src[4][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rr = (wave * 2 + i) * 8 + (lane >> 3);           // row inside the half-tile
-    const int c = (lane & 7) ^ ((rr >> 1) & 7);                // logical 16-byte chunk this lane fetches
+    const int c = (lane & 7) ^ gt_swz<FP8>(rr);                // logical 16-byte chunk this lane fetches
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int m = tm * 256 + h * 128 + rr;
       m = m < p.M ? m : p.M - 1;
-      src[h == 0 ? 0 : 3][i] = xg + (int64_t)m * p.ldx + c * 8;
+      src[h == 0 ? 0 : 3][i] = xg + ((int64_t)m * p.ldx) * ES + c * 16;
       const int rb = h * 128 + rr, wcb = rb >> 6, sl = rb & 63, ni = sl >> 4, ii = sl & 15;
       int n;
       if (EPI == 1) {
@@ -95,7 +114,7 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
         n = tn * 256 + wcb * 64 + (ii >> 2) * 16 + ni * 4 + (ii & 3);
         n = n < p.N ? n : p.N - 1;
       }
-      src[1 + h][i] = wg + (int64_t)n * p.K + c * 8;
+      src[1 + h][i] = wg + ((int64_t)n * p.K) * ES + c * 16;
     }
   }
   // LDS image of a K tile: x rows 0..255 (two halves), then W rows 0..255 (two halves)
@@ -111,14 +130,14 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   // and at the end of an even slot six of the wave's loads may still be in flight, at the end of an
   // odd slot four (everything a later slot reads has been waited for by its issuing wave before the
   // barrier in front of that slot).
-  const T* rdA[2];  const T* rdB[2];   // READ slot: first and second half-tile requested
-  const T* mxA[2];  const T* mxB[2];   // MATRIX slot
+  const char* rdA[2];  const char* rdB[2];   // READ slot: first and second half-tile requested
+  const char* mxA[2];  const char* mxB[2];   // MATRIX slot
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    rdA[i] = g == 0 ? src[1][i] + 64 : src[3][i] + 64;
-    rdB[i] = g == 0 ? src[2][i] + 64 : src[0][i] + 128;
-    mxA[i] = g == 0 ? src[3][i] + 64 : src[1][i] + 128;
-    mxB[i] = g == 0 ? src[0][i] + 128 : src[2][i] + 128;
+    rdA[i] = g == 0 ? src[1][i] + 128 : src[3][i] + 128;
+    rdB[i] = g == 0 ? src[2][i] + 128 : src[0][i] + 256;
+    mxA[i] = g == 0 ? src[3][i] + 128 : src[1][i] + 256;
+    mxB[i] = g == 0 ? src[0][i] + 256 : src[2][i] + 256;
   }
   const int rdA_l = g == 0 ? LW0 : LX1, rdB_l = g == 0 ? LW1 : LX0;
   const int mxA_l = g == 0 ? LX1 : LW0, mxB_l = g == 0 ? LX0 : LW1;
@@ -135,11 +154,13 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) glds16(src[3][i], lds_w + LX1 + i * 1024);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) glds16(src[0][i] + 64, lds_w + GT_STAGE + LX0 + i * 1024);
+  for (int i = 0; i < 2; ++i) glds16(src[0][i] + 128, lds_w + GT_STAGE + LX0 + i * 1024);
 
   // ---- fragment read addresses ----------------------------------------------------------------
+  // 16-bit: fragment of k-step kk = chunk 4 kk + q4 (k-step 1 is rd0 ^ 64); fp8: the fragment of the
+  // whole 128-deep tile = chunks 2 q4 and 2 q4 + 1 (rd0 and rd0 ^ 16)
   const int r16 = lane & 15, q4 = lane >> 4;
-  const int rd0 = r16 * 128 + ((q4 ^ (r16 >> 1)) << 4);   // k-step 0; k-step 1 is rd0 ^ 64
+  const int rd0 = r16 * 128 + (((FP8 ? 2 * q4 : q4) ^ gt_swz<FP8>(r16)) << 4);
   const int a_off = g * GT_HALF, b_off = 2 * GT_HALF + wc * 8192;
 
   f32x4 acc[8][4];
@@ -147,7 +168,9 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  frag af[2][8], bf[2][4];
+  // two 16-byte registers per fragment slot: k-steps 0 / 1 (16-bit) or the two halves of the 32-byte
+  // fp8 fragment
+  i32x4 af[2][8], bf[2][4];
 #ifndef GT_ABL
 #define GT_ABL 0   // development ablations: 1 no loads in the loop, 2 no fragment reads, 3 no MFMA, 4 no vmcnt waits
 #endif
@@ -155,9 +178,9 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[kk][mi] = *reinterpret_cast<const frag*>(sm + rd0 + mi * 2048 + kk * 64);
+      for (int mi = 0; mi < 8; ++mi) af[kk][mi] = *reinterpret_cast<const i32x4*>(sm + rd0 + mi * 2048 + kk * 64);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bf[kk][ni] = *reinterpret_cast<const frag*>(sm + rd0 + ni * 2048 + 32768 + kk * 64);
+      for (int ni = 0; ni < 4; ++ni) bf[kk][ni] = *reinterpret_cast<const i32x4*>(sm + rd0 + ni * 2048 + 32768 + kk * 64);
     }
   }
 
@@ -166,16 +189,19 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   do {                                                                                       \
     if (GT_ABL != 1 && (!(TAIL) || (t) + (d) < T_)) {                                        \
       char* d_ = lds_w + ((((t) + (d)) & 1) ? GT_STAGE : 0) + (ldso);                        \
-      glds16(ptr[0] + (int64_t)(t) * 64, d_);                                                \
-      glds16(ptr[1] + (int64_t)(t) * 64, d_ + 1024);                                         \
+      glds16(ptr[0] + (int64_t)(t) * 128, d_);                                               \
+      glds16(ptr[1] + (int64_t)(t) * 128, d_ + 1024);                                        \
     }                                                                                        \
   } while (0)
-#define GT_WAIT(n_even, TAIL)                                                                \
+// sel (wave-uniform) == 0: this is the end of an even slot.  The branch lives inside the asm statement
+// so that the compiler sees straight-line code and leaves the MFMA cluster where it is written.
+#define GT_WAIT(sel, TAIL)                                                                   \
   do {                                                                                       \
     if (GT_ABL == 4) break;                                                                  \
     if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
-    else if (n_even) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
+    else asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 .Lgtw_a%=\n\ts_waitcnt vmcnt(6)\n\t"  \
+                      "s_branch .Lgtw_b%=\n.Lgtw_a%=:\n\ts_waitcnt vmcnt(4)\n.Lgtw_b%=:"     \
+                      ::"s"(sel) : "memory", "scc");                                         \
   } while (0)
 #define GT_SLOT_END()                                                                        \
   do {                                                                                       \
@@ -186,21 +212,22 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
 #define GT_TILE(t, TAIL)                                                                     \
   do {                                                                                       \
     const int cur_ = ((t) & 1) ? GT_STAGE : 0;                                               \
-    /* READ slot: the fragments of both 32-deep k-steps of tile t */                         \
+    /* READ slot: the fragments of the whole K tile t */                                     \
     GT_LOAD2(rdA, rdA_l, rdA_d, t, TAIL);                                                    \
     GT_LOAD2(rdB, rdB_l, rdB_d, t, TAIL);                                                    \
     if (GT_ABL != 2) {                                                                       \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
-        const char* ab_ = sm + cur_ + a_off + (rd0 ^ (kk << 6));                             \
-        const char* bb_ = sm + cur_ + b_off + (rd0 ^ (kk << 6));                             \
+        const int ro_ = rd0 ^ (FP8 ? (kk << 4) : (kk << 6));                                 \
+        const char* ab_ = sm + cur_ + a_off + ro_;                                           \
+        const char* bb_ = sm + cur_ + b_off + ro_;                                           \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                     \
-            bf[kk][ni] = *reinterpret_cast<const frag*>(bb_ + ni * 2048);                    \
+            bf[kk][ni] = *reinterpret_cast<const i32x4*>(bb_ + ni * 2048);                   \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                     \
-            af[kk][mi] = *reinterpret_cast<const frag*>(ab_ + mi * 2048);                    \
+            af[kk][mi] = *reinterpret_cast<const i32x4*>(ab_ + mi * 2048);                   \
       }                                                                                      \
     }                                                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-    GT_WAIT(g == 0, TAIL);                                                                   \
+    GT_WAIT(g, TAIL);                                                                   \
     GT_SLOT_END();                                                                           \
     /* MATRIX slot */                                                                        \
     GT_LOAD2(mxA, mxA_l, mxA_d, t, TAIL);                                                    \
@@ -212,13 +239,24 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
       }                                                                                      \
     } else {                                                                                 \
       __builtin_amdgcn_s_setprio(1);                                                         \
-      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                       \
+      if constexpr (FP8) {                                                                   \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                     \
-          _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
-              acc[mi][ni] = Mfma<T>::run(bf[kk][ni], af[kk][mi], acc[mi][ni]);               \
+          _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {                                 \
+            const i32x8 a8_ = __builtin_shufflevector(bf[0][ni], bf[1][ni], 0, 1, 2, 3, 4, 5, 6, 7); \
+            const i32x8 b8_ = __builtin_shufflevector(af[0][mi], af[1][mi], 0, 1, 2, 3, 4, 5, 6, 7); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
+                a8_, b8_, acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                  \
+          }                                                                                  \
+      } else {                                                                               \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                     \
+          _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                   \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                 \
+                acc[mi][ni] = Mfma<T>::run(__builtin_bit_cast(frag, bf[kk][ni]),             \
+                                           __builtin_bit_cast(frag, af[kk][mi]), acc[mi][ni]); \
+      }                                                                                      \
       __builtin_amdgcn_s_setprio(0);                                                         \
     }                                                                                        \
-    GT_WAIT(g != 0, TAIL);                                                                   \
+    GT_WAIT(1 - g, TAIL);                                                                   \
     GT_SLOT_END();                                                                           \
   } while (0)
 
@@ -245,9 +283,21 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   // the load mapping above made output column 16 q4 + 4 ni + r (plain) or gate/up column 8 q4 + 4 (ni & 1) + r.
   T* yg = (T*)p.y;
   const T* bias = (const T*)p.bias;
+  float sxm[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = tm * 256 + g * 128 + mi * 16 + r16;
+    sxm[mi] = FP8 ? p.x_scale[m < p.M ? m : p.M - 1] : 1.f;
+  }
   if (EPI == 1) {
     const int j0 = tn * 128 + wc * 32 + q4 * 8;
     if (j0 < ncols) {
+      float sg[8], su[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sg[j] = FP8 ? p.w_scale[j0 + j] : 1.f;
+        su[j] = FP8 ? p.w_scale[ncols + j0 + j] : 1.f;
+      }
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
         const int m = tm * 256 + g * 128 + mi * 16 + r16;
@@ -255,17 +305,20 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            o.v[h * 4 + r] = silu_mul_one<T>(from_f32<T>(acc[mi][h][r]), from_f32<T>(acc[mi][2 + h][r]));
+          for (int r = 0; r < 4; ++r) {
+            float gv = acc[mi][h][r], uv = acc[mi][2 + h][r];
+            if (FP8) { gv = (gv * sxm[mi]) * sg[h * 4 + r]; uv = (uv * sxm[mi]) * su[h * 4 + r]; }
+            o.v[h * 4 + r] = silu_mul_one<T>(from_f32<T>(gv), from_f32<T>(uv));
+          }
         if (m < p.M) stvec<T, 8>(yg + (int64_t)m * p.ldy + j0, o);
       }
     }
   } else {
     const int n0 = tn * 256 + wc * 64 + q4 * 16;
     if (n0 < p.N) {
-      float bv[16];
+      float bv[16], sw[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+      for (int j = 0; j < 16; ++j) { bv[j] = 0.f; sw[j] = FP8 ? p.w_scale[n0 + j] : 1.f; }
       if (bias != nullptr) {
         const Vec<T, 8> b0 = ldvec<T, 8>(bias + n0), b1 = ldvec<T, 8>(bias + n0 + 8);
 #pragma unroll
@@ -279,8 +332,10 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            o0.v[ni * 4 + r] = from_f32<T>(acc[mi][ni][r] + bv[ni * 4 + r]);
-            o1.v[ni * 4 + r] = from_f32<T>(acc[mi][2 + ni][r] + bv[8 + ni * 4 + r]);
+            float v0 = acc[mi][ni][r], v1 = acc[mi][2 + ni][r];
+            if (FP8) { v0 = (v0 * sxm[mi]) * sw[ni * 4 + r]; v1 = (v1 * sxm[mi]) * sw[8 + ni * 4 + r]; }
+            o0.v[ni * 4 + r] = from_f32<T>(v0 + bv[ni * 4 + r]);
+            o1.v[ni * 4 + r] = from_f32<T>(v1 + bv[8 + ni * 4 + r]);
           }
         if (m < p.M) {
           stvec<T, 8>(yg + (int64_t)m * p.ldy + n0, o0);
@@ -291,14 +346,23 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool FP8>
 int launch_gemm_tiled(const GemmTiledParams& p, hipStream_t st) {
-  auto kern = gemm_tiled_kernel<T, EPI>;
+  auto kern = gemm_tiled_kernel<T, EPI, FP8>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS);
   const int groups = (p.nsuper + 7) / 8;   // every XCD label gets the same number of 8 x 4 blocks
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * 32)), dim3(512), GT_LDS, st, p);
-  MI355_CHECK_LAUNCH("mi355_linear_tiled");
+  MI355_CHECK_LAUNCH(FP8 ? "mi355_fp8_scaled_mm_tiled" : "mi355_linear_tiled");
   return MI355_OK;
+}
+
+void fill_tiles(GemmTiledParams& p, int64_t m, int64_t n, int epilogue) {
+  const int ncols = epilogue == 1 ? (int)(n / 2) : (int)n;
+  p.ldy = ncols;
+  p.mt = cdiv(m, 256);
+  p.nt = epilogue == 1 ? cdiv(ncols, 128) : cdiv(ncols, 256);
+  p.snt = cdiv(p.nt, 4);
+  p.nsuper = cdiv(p.mt, 8) * p.snt;
 }
 
 }  // namespace
@@ -309,8 +373,7 @@ using namespace mi355;
 extern "C" int mi355_linear_tiled_supported(int64_t m, int64_t n, int64_t k, int dtype, int epilogue) {
   if (dtype != MI355_BF16 && dtype != MI355_F16) return 0;
   if (m < 1 || n < 16 || k < 128 || (k & 63) != 0 || m > (1 << 24) || n > (1 << 24)) return 0;
-  if (epilogue == 1) return (n % 16 == 0) ? 1 : 0;   // 8 gate + 8 up columns per lane
-  return (epilogue == 0 && n % 16 == 0) ? 1 : 0;
+  return ((epilogue == 0 || epilogue == 1) && n % 16 == 0) ? 1 : 0;   // silu-mul: 8 gate + 8 up columns per lane
 }
 
 extern "C" int mi355_linear_tiled(void* y, const void* x, const void* w, const void* bias, int64_t m,
@@ -328,16 +391,41 @@ extern "C" int mi355_linear_tiled(void* y, const void* x, const void* w, const v
                 "mi355_linear_tiled: no bias with the SiLU-and-mul epilogue");
   GemmTiledParams p;
   p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.x_scale = nullptr; p.w_scale = nullptr;
   p.M = (int)m; p.N = (int)n; p.K = (int)k;
   p.ldx = x_stride;
-  const int ncols = epilogue == 1 ? (int)(n / 2) : (int)n;
-  p.ldy = ncols;
-  p.mt = cdiv(m, 256);
-  p.nt = epilogue == 1 ? cdiv(ncols, 128) : cdiv(ncols, 256);
-  p.snt = cdiv(p.nt, 4);
-  p.nsuper = cdiv(p.mt, 8) * p.snt;
+  fill_tiles(p, m, n, epilogue);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MI355_BF16)
-    return epilogue == 1 ? launch_gemm_tiled<bf16_t, 1>(p, st) : launch_gemm_tiled<bf16_t, 0>(p, st);
-  return epilogue == 1 ? launch_gemm_tiled<f16_t, 1>(p, st) : launch_gemm_tiled<f16_t, 0>(p, st);
+    return epilogue == 1 ? launch_gemm_tiled<bf16_t, 1, false>(p, st) : launch_gemm_tiled<bf16_t, 0, false>(p, st);
+  return epilogue == 1 ? launch_gemm_tiled<f16_t, 1, false>(p, st) : launch_gemm_tiled<f16_t, 0, false>(p, st);
+}
+
+extern "C" int mi355_fp8_scaled_mm_tiled_supported(int64_t m, int64_t n, int64_t k, int out_dtype, int epilogue) {
+  if (out_dtype != MI355_BF16 && out_dtype != MI355_F16) return 0;
+  if (m < 1 || n < 16 || k < 256 || (k & 127) != 0 || m > (1 << 24) || n > (1 << 24)) return 0;
+  return ((epilogue == 0 || epilogue == 1) && n % 16 == 0) ? 1 : 0;
+}
+
+extern "C" int mi355_fp8_scaled_mm_tiled(void* y, const uint8_t* xq, const uint8_t* wq, const float* x_scale,
+                                         const float* w_scale, const void* bias, int64_t m, int64_t n,
+                                         int64_t k, int out_dtype, int epilogue, void* stream) {
+  MI355_REQUIRE(y && xq && wq && x_scale && w_scale, MI355_ERR_INVALID, "mi355_fp8_scaled_mm_tiled: null pointer");
+  MI355_REQUIRE(mi355_fp8_scaled_mm_tiled_supported(m, n, k, out_dtype, epilogue), MI355_ERR_UNSUPPORTED,
+                "mi355_fp8_scaled_mm_tiled: needs a 16-bit output dtype, K %% 128 == 0, K >= 256, N %% 16 == 0 "
+                "(m=%ld n=%ld k=%ld out_dtype=%d epilogue=%d)", (long)m, (long)n, (long)k, out_dtype, epilogue);
+  MI355_REQUIRE(aligned16(xq) && aligned16(wq) && aligned16(y) && (bias == nullptr || aligned16(bias)),
+                MI355_ERR_INVALID, "mi355_fp8_scaled_mm_tiled: pointers must be 16-byte aligned");
+  MI355_REQUIRE(epilogue == 0 || bias == nullptr, MI355_ERR_UNSUPPORTED,
+                "mi355_fp8_scaled_mm_tiled: no bias with the SiLU-and-mul epilogue");
+  GemmTiledParams p;
+  p.x = xq; p.w = wq; p.bias = bias; p.y = y;
+  p.x_scale = x_scale; p.w_scale = w_scale;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k;
+  p.ldx = k;
+  fill_tiles(p, m, n, epilogue);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == MI355_BF16)
+    return epilogue == 1 ? launch_gemm_tiled<bf16_t, 1, true>(p, st) : launch_gemm_tiled<bf16_t, 0, true>(p, st);
+  return epilogue == 1 ? launch_gemm_tiled<f16_t, 1, true>(p, st) : launch_gemm_tiled<f16_t, 0, true>(p, st);
 }

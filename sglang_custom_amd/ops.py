@@ -694,6 +694,35 @@ def fp8_scaled_mm(xq: torch.Tensor, wq: torch.Tensor, x_scale: torch.Tensor, w_s
     return y
 
 
+def fp8_scaled_mm_tiled_supported(m: int, n: int, k: int, out_dtype: torch.dtype, silu_mul: bool = False) -> bool:
+    """Whether fp8_scaled_mm_tiled serves the shape (16-bit output, K % 128 == 0, K >= 256, N % 16 == 0)."""
+    return out_dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib_().mi355_fp8_scaled_mm_tiled_supported(m, n, k, _DT[out_dtype], 1 if silu_mul else 0))
+
+
+def fp8_scaled_mm_tiled(xq: torch.Tensor, wq: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor,
+                        out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None,
+                        silu_mul: bool = False) -> torch.Tensor:
+    """fp8_scaled_mm at prefill sizes on the 256 x 256-tile matrix-core kernel (wq [N, K]);
+    silu_mul=True applies SiluAndMul to the [gate; up] output in the epilogue and returns [M, N / 2]."""
+    _gpu(xq, wq, x_scale, w_scale, bias)
+    assert xq.is_contiguous() and wq.is_contiguous()
+    assert xq.dtype == torch.float8_e4m3fn and wq.dtype == torch.float8_e4m3fn
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and x_scale.numel() == M and w_scale.numel() == N
+    assert x_scale.dtype == torch.float32 and w_scale.dtype == torch.float32
+    assert x_scale.is_contiguous() and w_scale.is_contiguous()
+    assert bias is None or bias.dtype == out_dtype
+    y = torch.empty((M, N // 2 if silu_mul else N), dtype=out_dtype, device=xq.device)
+    if M == 0:
+        return y
+    check(_lib_().mi355_fp8_scaled_mm_tiled(y.data_ptr(), xq.data_ptr(), wq.data_ptr(), x_scale.data_ptr(),
+                                            w_scale.data_ptr(), _p(bias), M, N, K, _DT[out_dtype],
+                                            1 if silu_mul else 0, _stream(xq)), "fp8_scaled_mm_tiled")
+    return y
+
+
 def pack_weight_fp8(wq: torch.Tensor) -> torch.Tensor:
     """[N, K] e4m3fn weight -> packed copy for fp8_scaled_mm_packed (same 16-byte-fragment layout
     as pack_weight: the bytes are packed as an [N, K/2] 16-bit matrix)."""
