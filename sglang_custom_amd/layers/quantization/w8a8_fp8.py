@@ -7,6 +7,7 @@ non-CUDA branch of apply_fp8_linear (fp8_utils.py:676-749): quantise activations
 The weight stays [N, K] (one contiguous row per output channel), which is the layout the
 weight-streaming kernel wants; the reference stores the transpose for torch._scaled_mm
 (w8a8_fp8.py:115,132)."""
+import os
 from typing import Optional
 
 import torch
@@ -28,6 +29,12 @@ def quantize_weight_per_channel(w: torch.Tensor):
 
 
 SKINNY_MAX_M = 64
+# Large-M fp8 GEMMs: "auto" = the hand-written 256 x 256-tile kernel (mi355_fp8_scaled_mm_tiled) where it
+# is the faster choice on MI355X -- gate_up with SiLU-and-mul fused into its epilogue, 1.15x the library
+# GEMM + activation pair -- and torch._scaled_mm (hipBLASLt, 3-10 % faster on the plain projections)
+# elsewhere; "tiled" = the hand-written kernel for every shape it serves; "library" = never.
+PREFILL_GEMM = os.environ.get("MI355_PREFILL_FP8_GEMM", "auto")
+TILED_MIN_TILES = 192   # below this many 256 x 256 output tiles most CUs would idle
 _SCALED_MM_OK = None   # None = untried; torch._scaled_mm (hipBLASLt) with row-wise scales
 
 
@@ -47,6 +54,29 @@ def _library_scaled_mm(xq, wq, xs, ws, out_dtype, bias):
             raise
         _SCALED_MM_OK = False
         return None
+
+
+def _tiled_ok(m: int, n: int, k: int, out_dtype, silu_mul: bool) -> bool:
+    tiles = ((m + 255) // 256) * ((n + 255) // 256)
+    return tiles >= TILED_MIN_TILES and get_ops().fp8_scaled_mm_tiled_supported(m, n, k, out_dtype, silu_mul)
+
+
+def gate_up_silu_mul_prefill(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """act_fn(gate_up_proj(x)) (models/llama.py:94-98) for a prefill-sized fp8 W8A8 gate_up
+    projection: per-token quantisation, then ONE launch that multiplies, applies the scales and
+    SiLU-and-mul.  None when the shape or the switch says to take the unfused path."""
+    if not isinstance(x, torch.Tensor):   # a QuantizedAct: the decode path, served by the packed kernels
+        return None
+    x2 = x.view(-1, x.shape[-1])
+    w = layer.weight
+    if (PREFILL_GEMM == "library" or not x2.is_cuda or x2.shape[0] <= SKINNY_MAX_M
+            or getattr(layer, "bias", None) is not None or w.dtype != FP8_DTYPE
+            or not _tiled_ok(x2.shape[0], w.shape[0], w.shape[1], x2.dtype, True)):
+        return None
+    ops = get_ops()
+    xq, xs = ops.per_token_quant_fp8(x2)
+    y = ops.fp8_scaled_mm_tiled(xq, w, xs, layer.weight_scale.view(-1), x2.dtype, None, silu_mul=True)
+    return y.view(*x.shape[:-1], y.shape[-1])
 
 
 class W8A8Fp8LinearMethod:
@@ -76,7 +106,11 @@ class W8A8Fp8LinearMethod:
         x2 = x.view(-1, x.shape[-1])
         xq, xs = ops.per_token_quant_fp8(x2)
         y = None
-        if x2.shape[0] > SKINNY_MAX_M and x2.is_cuda and x2.shape[1] % 16 == 0 and layer.weight.shape[0] % 16 == 0:
+        if (PREFILL_GEMM == "tiled" and x2.shape[0] > SKINNY_MAX_M and x2.is_cuda
+                and _tiled_ok(x2.shape[0], layer.weight.shape[0], x2.shape[1], x2.dtype, False)):
+            y = ops.fp8_scaled_mm_tiled(xq, layer.weight, xs, layer.weight_scale.view(-1), x.dtype, bias)
+        if (y is None and x2.shape[0] > SKINNY_MAX_M and x2.is_cuda and x2.shape[1] % 16 == 0
+                and layer.weight.shape[0] % 16 == 0):
             y = _library_scaled_mm(xq, layer.weight, xs, layer.weight_scale, x.dtype, bias)
         wp = getattr(layer, "weight_packed", None)
         if y is None and wp is not None and x2.shape[0] <= SKINNY_MAX_M:

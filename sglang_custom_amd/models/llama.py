@@ -28,6 +28,7 @@ from ..layers.quantization.unquant import (
     pack_gate_up_for_decode,
 )
 from ..layers.quantization.w8a8_fp8 import W8A8Fp8LinearMethod
+from ..layers.quantization.w8a8_fp8 import gate_up_silu_mul_prefill as gate_up_silu_mul_prefill_fp8
 from ..layers.radix_attention import RadixAttention
 from ..ops_backend import get_ops
 from ..layers.rotary_embedding import get_rope
@@ -46,6 +47,8 @@ class LlamaMLP(nn.Module):
     def forward(self, x):
         if isinstance(self.gate_up_proj.quant_method, UnquantizedLinearMethod):
             x = gate_up_silu_mul(self.gate_up_proj, self.act_fn, x)
+        elif (fused := gate_up_silu_mul_prefill_fp8(self.gate_up_proj, x)) is not None:
+            x = fused   # prefill: fp8 GEMM with the scales and SiLU-and-mul in its epilogue
         else:
             gate_up, _ = self.gate_up_proj(x)
             if wants_fp8_input(self.down_proj, gate_up.shape[0]) and gate_up.dim() == 2:

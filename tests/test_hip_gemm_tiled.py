@@ -153,3 +153,92 @@ def test_prefill_through_the_tiled_gemm_matches_the_library_path(ops):
     top2 = l_lib.topk(2, dim=-1).values
     sure = (top2[:, 0] - top2[:, 1]) > 1e-1
     assert torch.equal(t_lib[sure], t_til[sure])
+
+
+# ---------------------------------------------------------------------------------- fp8 W8A8
+def _fp8_data(ops, m, n, k, seed, dtype=torch.bfloat16, with_x=False):
+    from sglang_custom_amd.layers.quantization.w8a8_fp8 import quantize_weight_per_channel
+
+    x, w = _data(m, n, k, dtype, seed)
+    xq, xs = ops.per_token_quant_fp8(x)
+    wq, ws = quantize_weight_per_channel(w)
+    if with_x:
+        return x, xq, xs, wq, ws.contiguous()
+    return xq, xs, wq, ws.contiguous()
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 16, 256), (65, 48, 384), (300, 272, 256), (513, 1040, 512), (100, 4096, 1024)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fp8_tiled_vs_oracle_and_the_row_major_kernel(ops, m, n, k, dtype):
+    """apply_fp8_linear (fp8_utils.py:676-749) at prefill sizes: against the oracle's fp8_linear on the
+    CPU (per-token quantisation, fp32 accumulation of the fp8 products, * x_scale * w_scale, one
+    rounding) and against mi355_fp8_scaled_mm, the library's row-major kernel for the same contract.
+    Tolerance: one rounding of the output dtype (the accumulation orders differ)."""
+    from oracle import ops_ref
+
+    x, xq, xs, wq, ws = _fp8_data(ops, m, n, k, m * 3 + n + k, dtype, with_x=True)
+    bias = torch.randn(n, device=DEV).to(dtype)
+    for b in (None, bias):
+        y = ops.fp8_scaled_mm_tiled(xq, wq, xs, ws, dtype, b)
+        ref = ops_ref.fp8_linear(x.cpu(), wq.cpu(), ws.cpu(), None if b is None else b.cpu().float())
+        tol = (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) * ref.float().abs().max().item() + 1e-3
+        assert (y.cpu().float() - ref.float()).abs().max().item() <= tol
+        other = ops.fp8_scaled_mm(xq, wq, xs, ws, dtype, b)
+        assert (y.float() - other.float()).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 544, 256), (777, 2048, 512)])
+def test_fp8_tiled_silu_mul_equals_unfused(ops, m, n, k):
+    xq, xs, wq, ws = _fp8_data(ops, m, n, k, m + n)
+    fused = ops.fp8_scaled_mm_tiled(xq, wq, xs, ws, torch.bfloat16, None, silu_mul=True)
+    assert torch.equal(fused, ops.silu_and_mul(ops.fp8_scaled_mm_tiled(xq, wq, xs, ws, torch.bfloat16)))
+
+
+@pytest.mark.parametrize("n,k", [(6144, 4096), (28672, 4096), (4096, 14336), (7168, 8192)])
+def test_fp8_tiled_properties_at_full_size(ops, n, k):
+    m = 2048 + 77
+    xq, xs, wq, ws = _fp8_data(ops, m, n, k, n + k)
+    y = ops.fp8_scaled_mm_tiled(xq, wq, xs, ws, torch.bfloat16)
+    # power-of-two scaling of either scale vector is exact
+    assert torch.equal(ops.fp8_scaled_mm_tiled(xq, wq, xs * 2, ws, torch.bfloat16), y * 2)
+    assert torch.equal(ops.fp8_scaled_mm_tiled(xq, wq, xs, ws * 0.25, torch.bfloat16), y * 0.25)
+    # row independence and weight-row permutation
+    for rows in ([0], [m - 1], list(range(300, 365))):
+        idx = torch.tensor(rows, device=DEV)
+        assert torch.equal(ops.fp8_scaled_mm_tiled(xq[idx].contiguous(), wq, xs[idx].contiguous(), ws, torch.bfloat16),
+                           y[idx])
+    perm = torch.randperm(n, device=DEV)
+    assert torch.equal(ops.fp8_scaled_mm_tiled(xq, wq[perm].contiguous(), xs, ws[perm].contiguous(), torch.bfloat16),
+                       y[:, perm])
+    # float64 evaluation of sampled rows: the fp8 products are exact, so this is the same formula
+    rows = torch.randint(0, m, (32,), device=DEV)
+    ref = (xq[rows].double() @ wq.double().t()) * xs[rows].double().view(-1, 1) * ws.double().view(1, -1)
+    assert (y[rows].double() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-3
+    if n in (28672, 7168):
+        assert torch.equal(ops.fp8_scaled_mm_tiled(xq, wq, xs, ws, torch.bfloat16, None, silu_mul=True),
+                           ops.silu_and_mul(y))
+
+
+def test_fp8_prefill_mlp_through_the_fused_gate_up(ops):
+    """LlamaMLP on fp8 W8A8 weights at a prefill size: the fused gate_up launch (quantise -> GEMM with
+    scales and SiLU-and-mul in the epilogue) gives the bits of the unfused sequence on the same kernel."""
+    from sglang_custom_amd.layers.quantization import w8a8_fp8
+    from sglang_custom_amd.models.llama import LlamaMLP
+
+    torch.manual_seed(0)
+    mlp = LlamaMLP(512, 1536, torch.bfloat16, DEV, quant_method_factory=w8a8_fp8.W8A8Fp8LinearMethod)
+    for lin in (mlp.gate_up_proj, mlp.down_proj):
+        lin.weight.data.normal_(0, 0.03)
+        lin.quant_method.process_weights_after_loading(lin)
+    x = torch.randn(700, 512, device=DEV).bfloat16()
+    keep = (w8a8_fp8.PREFILL_GEMM, w8a8_fp8.TILED_MIN_TILES)
+    try:
+        w8a8_fp8.TILED_MIN_TILES = 1
+        w8a8_fp8.PREFILL_GEMM = "auto"
+        fused = mlp(x)
+        w8a8_fp8.PREFILL_GEMM = "library"
+        lib = mlp(x)
+    finally:
+        w8a8_fp8.PREFILL_GEMM, w8a8_fp8.TILED_MIN_TILES = keep
+    assert fused.shape == lib.shape == (700, 512)
+    assert (fused.float() - lib.float()).abs().max().item() <= 2 ** -6 * lib.float().abs().max().item() + 1e-3
