@@ -1358,28 +1358,32 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
     for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(qf[s]));
   }
 
-  for (int t = 0; t < n_steps; ++t) {
-    // this wave's part of step t has landed when at most the loads (10 per step) of the younger steps are out
-    const int younger = min(P - 1, n_steps - 1 - t);
-    if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its reads of step t - 1 have returned
-    __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's tiles are free
-    if (t + P < n_steps) issue_step(t + P, s_nxt);
-    s_nxt = slots_of(t + P + 1);
-
-    const char* tile = sm_raw + 2 * (t % NSB) * MLR_TILE;
+  // one step (32 keys = two tiles at `tile`): scores, online softmax, this wave's quarter of P.V
+  auto step_compute = [&](int t, const char* tile) {
     f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = f32x4{0.f, 0.f, 0.f, 0.f};
+    // key fragments are read MLR_AHEAD k-steps before the MFMAs that use them (a ring of registers; the
+    // fences keep the order): left alone the compiler puts each read next to its MFMA, and the score
+    // phase then runs at one LDS round trip per k-step instead of at the matrix rate
+    constexpr int MLR_AHEAD = 4;
+    auto k_off = [&](int s) { return s < 16 ? k_rd + 64 * s : (s == 16 ? kt_rd0 : kt_rd1); };
+    frag ka[MLR_AHEAD], kb[MLR_AHEAD];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      sa = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + k_rd + 64 * s), qf[s], sa);
-      sb = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + MLR_TILE + k_rd + 64 * s), qf[s], sb);
+    for (int s = 0; s < MLR_AHEAD; ++s) {
+      ka[s] = *reinterpret_cast<const frag*>(tile + k_off(s));
+      kb[s] = *reinterpret_cast<const frag*>(tile + MLR_TILE + k_off(s));
     }
-    sa = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + kt_rd0), qf[16], sa);
-    sb = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + MLR_TILE + kt_rd0), qf[16], sb);
-    sa = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + kt_rd1), qf[17], sa);
-    sb = Mfma<T>::run(*reinterpret_cast<const frag*>(tile + MLR_TILE + kt_rd1), qf[17], sb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      sa = Mfma<T>::run(ka[s % MLR_AHEAD], qf[s], sa);
+      sb = Mfma<T>::run(kb[s % MLR_AHEAD], qf[s], sb);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + MLR_AHEAD < NS) {
+        ka[s % MLR_AHEAD] = *reinterpret_cast<const frag*>(tile + k_off(s + MLR_AHEAD));
+        kb[s % MLR_AHEAD] = *reinterpret_cast<const frag*>(tile + MLR_TILE + k_off(s + MLR_AHEAD));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 
     const int64_t kb0 = k0 + (int64_t)t * 32 + 4 * c4;
     float x[8], mx = -INFINITY;
@@ -1420,6 +1424,21 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
       const auto vb = TrRead<T>::run(reinterpret_cast<const T*>(tile + MLR_TILE + v_rd + 32 * dt));
       acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, va), pa, acc[dt]);
       acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, vb), pb, acc[dt]);
+    }
+  };
+
+  {
+    for (int t = 0; t < n_steps; ++t) {
+      // this wave's part of step t has landed when at most the loads (10 per step) of the younger steps are out
+      const int younger = min(P - 1, n_steps - 1 - t);
+      if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its reads of step t - 1 have returned
+      __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's tiles are free
+      if (t + P < n_steps) issue_step(t + P, s_nxt);
+      s_nxt = slots_of(t + P + 1);
+      step_compute(t, sm_raw + 2 * (t % NSB) * MLR_TILE);
     }
   }
 

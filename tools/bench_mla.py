@@ -35,7 +35,7 @@ K = kv[0][r2t[:nb].long(), 0].float()
 s = torch.einsum('bhd,bkd->bhk', q[:nb].float(), K) * D ** -0.5
 ref = torch.einsum('bhk,bkd->bhd', s.softmax(-1), K[..., :rank])
 nbytes = bs * ctx * D * 2
-for dbg in (1, 2, 5, 0):
+for dbg in ((0,) if os.environ.get("MLA_AB") else (1, 2, 5, 0)):
     lib.mi355_debug_set(6, dbg)   # 1 = generic wave-per-head kernel, 2 = MFMA kernel with rows in registers, 0 = rows through the LDS ring (product)
     for ns in (1, 2, 4, 8):
         if dbg == 1 and ns not in (1, 4): continue
