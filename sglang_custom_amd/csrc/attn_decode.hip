@@ -797,11 +797,14 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) acc[dt] *= alpha;
     }
+    // all eight transposed reads first, then the MFMAs: written read-MFMA-read-MFMA the reads stay in
+    // that order and every MFMA waits one LDS round trip
+    typename TrRead<T>::v4 vt[8];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const auto va = TrRead<T>::run(v_rd + 16 * dt);
-      acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, va), pb, acc[dt]);
-    }
+    for (int dt = 0; dt < 8; ++dt) vt[dt] = TrRead<T>::run(v_rd + 16 * dt);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, vt[dt]), pb, acc[dt]);
     __builtin_amdgcn_wave_barrier();
   };
 
@@ -1418,12 +1421,22 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
     }
     l += psum;
     const frag4 pa = __builtin_bit_cast(frag4, pa4), pb = __builtin_bit_cast(frag4, pb4);
+    // transposed value reads in two batches of eight ahead of their MFMAs (see the score phase above)
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const auto va = TrRead<T>::run(reinterpret_cast<const T*>(tile + v_rd + 32 * dt));
-      const auto vb = TrRead<T>::run(reinterpret_cast<const T*>(tile + MLR_TILE + v_rd + 32 * dt));
-      acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, va), pa, acc[dt]);
-      acc[dt] = Mfma16<T>::run(__builtin_bit_cast(frag4, vb), pb, acc[dt]);
+    for (int h = 0; h < 2; ++h) {
+      typename TrRead<T>::v4 va[4], vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        va[i] = TrRead<T>::run(reinterpret_cast<const T*>(tile + v_rd + 32 * (4 * h + i)));
+        vb[i] = TrRead<T>::run(reinterpret_cast<const T*>(tile + MLR_TILE + v_rd + 32 * (4 * h + i)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[4 * h + i] = Mfma16<T>::run(__builtin_bit_cast(frag4, va[i]), pa, acc[4 * h + i]);
+        acc[4 * h + i] = Mfma16<T>::run(__builtin_bit_cast(frag4, vb[i]), pb, acc[4 * h + i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
