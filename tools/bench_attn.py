@@ -11,6 +11,7 @@ if len(sys.argv) > 3: bs, hq, hkv = int(sys.argv[1]), int(sys.argv[2]), int(sys.
 if len(sys.argv) > 4: ctx = int(sys.argv[4])
 SP = int(sys.argv[5]) if len(sys.argv) > 5 else 1024   # slot spacing between sequences' prompt regions
 NL = 3
+SP = max(SP, ctx)
 slots = bs * max(1100, SP + 80) + 16
 torch.manual_seed(0)
 kb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
@@ -21,10 +22,11 @@ if os.environ.get('KV8'):
 q = torch.randn(bs, hq, D, device='cuda').bfloat16()
 o = torch.empty_like(q)
 # prompt tokens contiguous per request, decode tokens interleaved across requests (as the allocator hands them out)
-r2t = torch.zeros(bs, 1200, dtype=torch.int32, device='cuda')
+r2t = torch.zeros(bs, max(1200, ctx + 16), dtype=torch.int32, device='cuda')
 for b in range(bs):
-    r2t[b, :min(ctx, 1024)] = torch.arange(1 + b * SP, 1 + b * SP + min(ctx, 1024))
-    if ctx > 1024: r2t[b, 1024:ctx] = 1 + bs * SP + torch.arange(ctx - 1024) * bs + b
+    PL = min(ctx, max(1024, ctx - 40))   # prompt length: the last few tokens are decode tokens
+    r2t[b, :PL] = torch.arange(1 + b * SP, 1 + b * SP + PL)
+    if ctx > PL: r2t[b, PL:ctx] = 1 + bs * SP + torch.arange(ctx - PL, device='cuda') * bs + b
 rpi = torch.arange(bs, dtype=torch.int64, device='cuda')
 sl = torch.full((bs,), ctx, dtype=torch.int64, device='cuda')
 MAXS = 16
@@ -47,7 +49,7 @@ qg = q.float().view(bs, hkv, hq // hkv, D)
 s = torch.einsum('bhgd,bkhd->bhgk', qg, K) * D ** -0.5
 ref = torch.einsum('bhgk,bkhd->bhgd', s.softmax(-1), V).reshape(bs, hq, D)
 nbytes = bs * ctx * hkv * D * 2 * kb[0].element_size()
-for dbg in (3, 0):
+for dbg in ((0,) if os.environ.get('ONLY0') else (3, 0)):
     lib.mi355_debug_set(6, dbg)   # 3 = K rows straight into fragments (ablation), 0 = whole K rows staged through LDS (product)
     for ns in [int(x) for x in os.environ.get('SPLITS', '1,2,3,4').split(',')]:
         ops.decode_attention_paged(q, kb[0], vb[0], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5)
