@@ -671,13 +671,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int i = 0; i < 16; ++i) st[hf][i] = 0.f;
+    // LDS fragment reads run AHEAD of the MFMAs that use them (register rings, fenced): written
+    // read-MFMA-read-MFMA, hipcc keeps that order and every MFMA waits a full LDS round trip
+    // (>= 64 cycles against the MFMA's 32).
+    frag kr[3][2];   // K fragments of k-steps s, s + 1, s + 2
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int co = 16 * ((2 * s) ^ kcx);
+      kr[s][0] = *reinterpret_cast<const frag*>(k_rd + co);
+      kr[s][1] = *reinterpret_cast<const frag*>(k_rd + 8192 + co);
+    }
+    // the first V^T fragments too: the tile is already in LDS, and the softmax below covers their latency
+    typename TrRead<T>::v4 vlo[4], vhi[4];   // ring of four (u, dt) fragments
+    auto v_read = [&](int i, int slot_) {
+      const int u = i >> 2, dt = i & 3;
+      const int ch = 4 * dt + vch;
+      vlo[slot_] = TrRead<T>::run(reinterpret_cast<const T*>(v_rd + 256 * (16 * u) + 16 * (ch ^ vf_lo)));
+      vhi[slot_] = TrRead<T>::run(reinterpret_cast<const T*>(v_rd + 256 * (16 * u + 8) + 16 * (ch ^ vf_hi)));
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const int co = 16 * ((2 * s) ^ kcx);
-      const frag k0 = *reinterpret_cast<const frag*>(k_rd + co);
-      const frag k1 = *reinterpret_cast<const frag*>(k_rd + 8192 + co);
-      st[0] = Mfma32<T>::run(k0, qf[s], st[0]);
-      st[1] = Mfma32<T>::run(k1, qf[s], st[1]);
+      if (s + 2 < 8) {
+        const int co = 16 * ((2 * (s + 2)) ^ kcx);
+        kr[(s + 2) % 3][0] = *reinterpret_cast<const frag*>(k_rd + co);
+        kr[(s + 2) % 3][1] = *reinterpret_cast<const frag*>(k_rd + 8192 + co);
+      } else if (s == 6) {
+        v_read(0, 0);
+        v_read(1, 1);
+      } else {
+        v_read(2, 2);
+        v_read(3, 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      st[0] = Mfma32<T>::run(kr[s % 3][0], qf[s], st[0]);
+      st[1] = Mfma32<T>::run(kr[s % 3][1], qf[s], st[1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // Softmax on the raw scores: the scale (sm_scale * log2 e > 0, checked by the launcher) commutes with
     // the maximum and folds into the exponent's multiply-add.  Only tiles that cross the wave's diagonal
@@ -720,21 +749,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) ot[dt] *= alpha;
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int i = 0; i < 16; ++i) {   // (u, dt) = (i >> 2, i & 3); fragment i + 4 is requested right behind MFMA i
+      frag va;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int ch = 4 * dt + vch;
-        const auto lo = TrRead<T>::run(reinterpret_cast<const T*>(v_rd + 256 * (16 * u) + 16 * (ch ^ vf_lo)));
-        const auto hi = TrRead<T>::run(reinterpret_cast<const T*>(v_rd + 256 * (16 * u + 8) + 16 * (ch ^ vf_hi)));
-        frag va;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          va[e] = lo[e];
-          va[4 + e] = hi[e];
-        }
-        ot[dt] = Mfma32<T>::run(va, pb[u], ot[dt]);
+      for (int e = 0; e < 4; ++e) {
+        va[e] = vlo[i & 3][e];
+        va[4 + e] = vhi[i & 3][e];
       }
+      ot[i & 3] = Mfma32<T>::run(va, pb[i >> 2], ot[i & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 4 < 16) {
+        v_read(i + 4, i & 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 
   lsum += __shfl_xor(lsum, 32, 64);
