@@ -92,18 +92,29 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   const int ncols = EPI == 1 ? (p.N >> 1) : p.N;   // output columns
 
   // ---- per-lane source pointers of the eight load instructions a wave issues per K tile -----
-  // half-tile `which`: 0 = x rows 0..127, 1 = W rows 0..127, 2 = W rows 128..255, 3 = x rows 128..255;
-  // a half-tile is 16 pieces of 8 rows x 128 B, wave w issues pieces 2 w and 2 w + 1 of every half-tile
-  const char* src[4][2];
+  // A wave requests data only in its READ slot (a load-to-LDS holds the issuing wave ~40 cycles: in
+  // front of or between the MFMAs of a matrix slot that time is lost to the matrix pipe, next to the
+  // LDS reads of a READ slot it is covered by the other group's MFMAs).  Group 0 (READ slot 2t) requests
+  // W of tile t + 1, both halves; group 1 (READ slot 2t + 1) requests x rows 128..255 of tile t + 1 and
+  // x rows 0..127 of tile t + 2: each is free when requested (its last reader finished a slot earlier)
+  // and is waited for -- by the waves that requested it, at the end of their MATRIX slot -- before
+  // the barrier in front of the first slot that reads it.  A half-tile is 16 pieces of 8 rows x 128
+  // bytes; wave wc of the group requests pieces 4 wc .. 4 wc + 3 of its group's two half-tiles:
+  //   ldA: group 0 W rows 0..127 (tile t + 1), group 1 x rows 128..255 (tile t + 1)
+  //   ldB: group 0 W rows 128..255 (tile t + 1), group 1 x rows 0..127 (tile t + 2)
+  const char* ldA[4];
+  const char* ldB[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rr = (wave * 2 + i) * 8 + (lane >> 3);           // row inside the half-tile
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (wc * 4 + i) * 8 + (lane >> 3);             // row inside the half-tile
     const int c = (lane & 7) ^ gt_swz<FP8>(rr);                // logical 16-byte chunk this lane fetches
+    const char* xs[2];
+    const char* ws[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int m = tm * 256 + h * 128 + rr;
       m = m < p.M ? m : p.M - 1;
-      src[h == 0 ? 0 : 3][i] = xg + ((int64_t)m * p.ldx) * ES + c * 16;
+      xs[h] = xg + ((int64_t)m * p.ldx) * ES + c * 16;
       const int rb = h * 128 + rr, wcb = rb >> 6, sl = rb & 63, ni = sl >> 4, ii = sl & 15;
       int n;
       if (EPI == 1) {
@@ -114,47 +125,26 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
         n = tn * 256 + wcb * 64 + (ii >> 2) * 16 + ni * 4 + (ii & 3);
         n = n < p.N ? n : p.N - 1;
       }
-      src[1 + h][i] = wg + ((int64_t)n * p.K) * ES + c * 16;
+      ws[h] = wg + ((int64_t)n * p.K) * ES + c * 16;
     }
+    ldA[i] = g == 0 ? ws[0] : xs[1];
+    ldB[i] = g == 0 ? ws[1] : xs[0];
   }
   // LDS image of a K tile: x rows 0..255 (two halves), then W rows 0..255 (two halves)
   constexpr int LX0 = 0, LX1 = GT_HALF, LW0 = 2 * GT_HALF, LW1 = 3 * GT_HALF;
-  char* const lds_w = sm + wave * 2048;   // this wave's two 1-KiB pieces inside a half-tile
-
-  // Slot schedule (a slot = the time between two barriers; a wave is in a READ slot or a MATRIX slot):
-  //   even slot 2u requests W(u + 1) (both halves); odd slot 2u + 1 requests x rows 128..255 of tile
-  //   u + 1, then x rows 0..127 of tile u + 2.  Group 0 reads tile t in slot 2t and multiplies in slot
-  //   2t + 1; group 1 one slot later.  So per wave and loop tile t:
-  //     group 0: READ slot requests W(t + 1),               MATRIX slot x1(t + 1) and x0(t + 2)
-  //     group 1: READ slot requests x1(t + 1) and x0(t + 2), MATRIX slot W(t + 2)
-  // and at the end of an even slot six of the wave's loads may still be in flight, at the end of an
-  // odd slot four (everything a later slot reads has been waited for by its issuing wave before the
-  // barrier in front of that slot).
-  const char* rdA[2];  const char* rdB[2];   // READ slot: first and second half-tile requested
-  const char* mxA[2];  const char* mxB[2];   // MATRIX slot
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    rdA[i] = g == 0 ? src[1][i] + 128 : src[3][i] + 128;
-    rdB[i] = g == 0 ? src[2][i] + 128 : src[0][i] + 256;
-    mxA[i] = g == 0 ? src[3][i] + 128 : src[1][i] + 256;
-    mxB[i] = g == 0 ? src[0][i] + 256 : src[2][i] + 256;
-  }
-  const int rdA_l = g == 0 ? LW0 : LX1, rdB_l = g == 0 ? LW1 : LX0;
-  const int mxA_l = g == 0 ? LX1 : LW0, mxB_l = g == 0 ? LX0 : LW1;
-  // tile parity of each request relative to the loop tile t: (t + d) & 1
-  const int rdA_d = 1, rdB_d = g == 0 ? 1 : 2, mxA_d = g == 0 ? 1 : 2, mxB_d = 2;
+  char* const lds_w = sm + wc * 4096;   // this wave's four 1-KiB pieces inside a half-tile
+  const int ldA_l = g == 0 ? LW0 : LX1, ldB_l = g == 0 ? LW1 : LX0;
+  const int ldB_d = g == 0 ? 1 : 2;     // tile distance of the second request (the first is always t + 1)
 
   // ---- prologue: all of tile 0 and x rows 0..127 of tile 1 ------------------------------------
 #pragma unroll
-  for (int i = 0; i < 2; ++i) glds16(src[0][i], lds_w + LX0 + i * 1024);
+  for (int i = 0; i < 4; ++i) glds16(ldA[i], lds_w + ldA_l + i * 1024);            // W0(0) | x1(0)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) glds16(src[1][i], lds_w + LW0 + i * 1024);
+  for (int i = 0; i < 4; ++i) glds16(ldB[i], lds_w + ldB_l + i * 1024);            // W1(0) | x0(0)
+  if (g == 1) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) glds16(src[2][i], lds_w + LW1 + i * 1024);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) glds16(src[3][i], lds_w + LX1 + i * 1024);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) glds16(src[0][i] + 128, lds_w + GT_STAGE + LX0 + i * 1024);
+    for (int i = 0; i < 4; ++i) glds16(ldB[i] + 128, lds_w + GT_STAGE + ldB_l + i * 1024);   // x0(1)
+  }
 
   // ---- fragment read addresses ----------------------------------------------------------------
   // 16-bit: fragment of k-step kk = chunk 4 kk + q4 (k-step 1 is rd0 ^ 64); fp8: the fragment of the
@@ -184,24 +174,14 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
     }
   }
 
-// two 1-KiB pieces of one half-tile; `t` = loop tile, d = tile distance; TAIL: skip tiles past the end
-#define GT_LOAD2(ptr, ldso, d, t, TAIL)                                                      \
+// four 1-KiB pieces of one half-tile of tile `tl`; TAIL: nothing past the last tile
+#define GT_LOAD4(ptr, ldso, tl, TAIL)                                                        \
   do {                                                                                       \
-    if (GT_ABL != 1 && (!(TAIL) || (t) + (d) < T_)) {                                        \
-      char* d_ = lds_w + ((((t) + (d)) & 1) ? GT_STAGE : 0) + (ldso);                        \
-      glds16(ptr[0] + (int64_t)(t) * 128, d_);                                               \
-      glds16(ptr[1] + (int64_t)(t) * 128, d_ + 1024);                                        \
+    if (GT_ABL != 1 && (!(TAIL) || (tl) < T_)) {                                             \
+      char* d_ = lds_w + (((tl) & 1) ? GT_STAGE : 0) + (ldso);                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+          glds16(ptr[i] + (int64_t)(tl) * 128, d_ + i * 1024);                               \
     }                                                                                        \
-  } while (0)
-// sel (wave-uniform) == 0: this is the end of an even slot.  The branch lives inside the asm statement
-// so that the compiler sees straight-line code and leaves the MFMA cluster where it is written.
-#define GT_WAIT(sel, TAIL)                                                                   \
-  do {                                                                                       \
-    if (GT_ABL == 4) break;                                                                  \
-    if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
-    else asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 .Lgtw_a%=\n\ts_waitcnt vmcnt(6)\n\t"  \
-                      "s_branch .Lgtw_b%=\n.Lgtw_a%=:\n\ts_waitcnt vmcnt(4)\n.Lgtw_b%=:"     \
-                      ::"s"(sel) : "memory", "scc");                                         \
   } while (0)
 #define GT_SLOT_END()                                                                        \
   do {                                                                                       \
@@ -212,9 +192,9 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
 #define GT_TILE(t, TAIL)                                                                     \
   do {                                                                                       \
     const int cur_ = ((t) & 1) ? GT_STAGE : 0;                                               \
-    /* READ slot: the fragments of the whole K tile t */                                     \
-    GT_LOAD2(rdA, rdA_l, rdA_d, t, TAIL);                                                    \
-    GT_LOAD2(rdB, rdB_l, rdB_d, t, TAIL);                                                    \
+    /* READ slot: request the group's two half-tiles, read the fragments of the whole K tile t */ \
+    GT_LOAD4(ldA, ldA_l, (t) + 1, TAIL);                                                     \
+    GT_LOAD4(ldB, ldB_l, (t) + ldB_d, TAIL);                                                 \
     if (GT_ABL != 2) {                                                                       \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
         const int ro_ = rd0 ^ (FP8 ? (kk << 4) : (kk << 6));                                 \
@@ -227,11 +207,8 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
       }                                                                                      \
     }                                                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-    GT_WAIT(g, TAIL);                                                                   \
     GT_SLOT_END();                                                                           \
-    /* MATRIX slot */                                                                        \
-    GT_LOAD2(mxA, mxA_l, mxA_d, t, TAIL);                                                    \
-    GT_LOAD2(mxB, mxB_l, mxB_d, t, TAIL);                                                    \
+    /* MATRIX slot: nothing but MFMAs, then the wave's requests of its READ slot must have landed */ \
     if (GT_ABL == 3) {                                                                       \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"v"(af[kk][mi])); \
@@ -256,25 +233,18 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
       }                                                                                      \
       __builtin_amdgcn_s_setprio(0);                                                         \
     }                                                                                        \
-    GT_WAIT(1 - g, TAIL);                                                                   \
+    if (GT_ABL != 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
     GT_SLOT_END();                                                                           \
   } while (0)
 
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // x rows 0..127 and W of tile 0 have landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 (and x rows 0..127 of tile 1) have landed
   GT_SLOT_END();
-  if (g == 1) {   // the second group runs one slot behind the first: its slot 0 only requests W(1)
-    GT_LOAD2(mxA, mxA_l, mxA_d, -1, true);
-    GT_LOAD2(mxB, mxB_l, mxB_d, -1, true);
-    if (T_ > 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // x rows 128..255 of tile 0 have landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GT_SLOT_END();
-  }
+  if (g == 1) GT_SLOT_END();   // the second group runs one slot behind the first
   int t = 0;
-  for (; t + 3 < T_; ++t) GT_TILE(t, false);   // every request exists: no conditions in the loop
+  for (; t + 2 < T_; ++t) GT_TILE(t, false);   // every request exists: no conditions in the loop
   for (; t < T_; ++t) GT_TILE(t, true);
   if (g == 0) __builtin_amdgcn_s_barrier();
-#undef GT_LOAD2
-#undef GT_WAIT
+#undef GT_LOAD4
 #undef GT_SLOT_END
 #undef GT_TILE
 
