@@ -62,8 +62,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--ttft-repeats", type=int, default=3)
-    ap.add_argument("--prefill-gemm", default=None, choices=["library", "tiled"],
-                    help="prefill (M > 64) 16-bit GEMMs: hipBLASLt (default) or the hand-written 256x256-tile kernel")
+    ap.add_argument("--prefill-gemm", default=None, choices=["auto", "library", "tiled"],
+                    help="prefill (M > 64) 16-bit GEMMs: auto (default: hand-written gate_up with fused SiLU-mul, "
+                         "hipBLASLt elsewhere), the hand-written 256x256-tile kernel everywhere, or hipBLASLt everywhere")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous rehearsal without a GPU: every rank joins a gloo group, meets at the "
                          "barriers and rank 0 prints the line's bookkeeping fields (value null)")
@@ -398,7 +399,7 @@ def main():
                    "hip_graph": bool(graph_ok)},
         "ttft_p50_ms": round(ttft * 1e3, 2),
         "prefill_tok_s": round(bs * in_len / ttft, 1),
-        "prefill_gemm": args.prefill_gemm or os.environ.get("MI355_PREFILL_GEMM", "library"),
+        "prefill_gemm": args.prefill_gemm or os.environ.get("MI355_PREFILL_GEMM", "auto"),
         "step_bytes_algorithmic": int(bytes_step),
         "step_hbm_gbs": round(step_gbs, 1),
         "step_hbm_frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),

@@ -3,10 +3,12 @@
 
 Decode-sized inputs (M <= 64 rows) and every fp32 input go to the hand-written kernels behind
 mi355_linear (weight-streaming MFMA / exact-fp32 tiled).  Large-M bf16/f16 GEMMs (prefill) have two
-implementations: the library GEMM (torch.nn.functional.linear -> hipBLASLt, the default: it is the
-faster of the two on MI355X) and the hand-written 256 x 256-tile matrix-core kernel behind
-mi355_linear_tiled (PREFILL_GEMM = "tiled", env MI355_PREFILL_GEMM), which also fuses SiLU-and-mul
-into the gate_up projection."""
+implementations: the library GEMM (torch.nn.functional.linear -> hipBLASLt) and the hand-written
+256 x 256-tile matrix-core kernel behind mi355_linear_tiled, which can apply SiLU-and-mul in its
+epilogue.  PREFILL_GEMM (env MI355_PREFILL_GEMM) picks: "auto" (default) = the hand-written kernel
+where it is the faster choice on MI355X -- gate_up with the fused activation, 1.02x the library GEMM +
+activation pair -- and the library for the plain projections (where it is 4-6 % faster); "tiled" =
+the hand-written kernel for every shape it serves; "library" = never."""
 import os
 from typing import Optional
 
@@ -19,14 +21,14 @@ SKINNY_MAX_M = 64
 # Deferred split-K reduction / fused decode step (bit-identical to the unfused kernels; the switch
 # exists so that tests and profiles can run both).
 DECODE_FUSION = True
-# "library" (hipBLASLt) | "tiled" (mi355_linear_tiled) for 16-bit GEMMs with more than SKINNY_MAX_M rows
-PREFILL_GEMM = os.environ.get("MI355_PREFILL_GEMM", "library")
+# "auto" | "tiled" | "library" for 16-bit GEMMs with more than SKINNY_MAX_M rows (see the module docstring)
+PREFILL_GEMM = os.environ.get("MI355_PREFILL_GEMM", "auto")
 # below this many 256 x 256 output tiles the one-tile-per-workgroup kernel leaves most CUs idle
 TILED_MIN_TILES = 192
 
 
 def _use_tiled(m: int, n_out_tiles_cols: int, n: int, k: int, dtype, silu_mul: bool) -> bool:
-    if PREFILL_GEMM != "tiled":
+    if PREFILL_GEMM == "library" or (PREFILL_GEMM == "auto" and not silu_mul):
         return False
     tiles = ((m + 255) // 256) * ((n_out_tiles_cols + 255) // 256)
     return tiles >= TILED_MIN_TILES and get_ops().linear_tiled_supported(m, n, k, dtype, silu_mul)

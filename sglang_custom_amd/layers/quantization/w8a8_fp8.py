@@ -29,10 +29,10 @@ def quantize_weight_per_channel(w: torch.Tensor):
 
 
 SKINNY_MAX_M = 64
-# Large-M fp8 GEMMs: "auto" = the hand-written 256 x 256-tile kernel (mi355_fp8_scaled_mm_tiled) where it
-# is the faster choice on MI355X -- gate_up with SiLU-and-mul fused into its epilogue, 1.15x the library
-# GEMM + activation pair -- and torch._scaled_mm (hipBLASLt, 3-10 % faster on the plain projections)
-# elsewhere; "tiled" = the hand-written kernel for every shape it serves; "library" = never.
+# Large-M fp8 GEMMs: "auto" (default) and "tiled" = the hand-written 256 x 256-tile kernel
+# (mi355_fp8_scaled_mm_tiled) for every shape it serves -- on MI355X it is 1.00-1.10x torch._scaled_mm
+# (hipBLASLt) on the plain projections and 1.23x on gate_up, whose scales and SiLU-and-mul run in its
+# epilogue; "library" = torch._scaled_mm everywhere.
 PREFILL_GEMM = os.environ.get("MI355_PREFILL_FP8_GEMM", "auto")
 TILED_MIN_TILES = 192   # below this many 256 x 256 output tiles most CUs would idle
 _SCALED_MM_OK = None   # None = untried; torch._scaled_mm (hipBLASLt) with row-wise scales
@@ -106,7 +106,7 @@ class W8A8Fp8LinearMethod:
         x2 = x.view(-1, x.shape[-1])
         xq, xs = ops.per_token_quant_fp8(x2)
         y = None
-        if (PREFILL_GEMM == "tiled" and x2.shape[0] > SKINNY_MAX_M and x2.is_cuda
+        if (PREFILL_GEMM != "library" and x2.shape[0] > SKINNY_MAX_M and x2.is_cuda
                 and _tiled_ok(x2.shape[0], layer.weight.shape[0], x2.shape[1], x2.dtype, False)):
             y = ops.fp8_scaled_mm_tiled(xq, layer.weight, xs, layer.weight_scale.view(-1), x.dtype, bias)
         if (y is None and x2.shape[0] > SKINNY_MAX_M and x2.is_cuda and x2.shape[1] % 16 == 0

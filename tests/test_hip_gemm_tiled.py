@@ -236,6 +236,8 @@ def test_fp8_prefill_mlp_through_the_fused_gate_up(ops):
         w8a8_fp8.TILED_MIN_TILES = 1
         w8a8_fp8.PREFILL_GEMM = "auto"
         fused = mlp(x)
+        w8a8_fp8.PREFILL_GEMM = "tiled"
+        assert torch.equal(mlp(x), fused)
         w8a8_fp8.PREFILL_GEMM = "library"
         lib = mlp(x)
     finally:
