@@ -11,15 +11,18 @@
 //     live in LDS as four HALF-TILES of 128 rows x 128 bytes (x rows 0..127, x rows 128..255, W rows
 //     0..127, W rows 128..255), two tiles resident;
 //   * the load unit writes LDS itself (global_load_lds_dwordx4, 8 rows x 128 B per wave-instruction:
-//     whole cache lines); every wave issues four such loads per SLOT (two half-tiles per slot for the
-//     workgroup), requested 2.5 slots or more before the slot that reads them, and waits with a
-//     COUNTED vmcnt so that loads stay in flight across every barrier;
+//     whole cache lines);
 //   * the eight waves form two groups of four (group = row half of the tile, wave-in-group = 64
-//     output columns).  A wave alternates a READ slot (24 ds_read_b128: its A and B fragments of a
-//     whole K tile) with a MATRIX slot (64 x v_mfma_f32_16x16x32 on 16-bit operands, or 32 x
-//     v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales on fp8 operands: twice the 16-bit rate
-//     per byte staged); the groups run one slot apart, so on every SIMD one wave's matrix work covers
-//     the other wave's LDS reads.  One s_barrier per slot.
+//     output columns).  A wave alternates a READ slot (its 8 load requests, then 24 ds_read_b128: its A
+//     and B fragments of a whole K tile) with a MATRIX slot (nothing but 64 x v_mfma_f32_16x16x32 on
+//     16-bit operands, or 32 x v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales on fp8
+//     operands: twice the 16-bit rate per byte staged); the groups run one slot apart, so on every
+//     SIMD one wave's matrix work covers the other wave's LDS reads and load issue (a load-to-LDS
+//     holds the issuing wave for ~40 cycles: anywhere in a matrix slot that time is lost to the
+//     matrix pipe).  One s_barrier per slot;
+//   * a half-tile is requested by the group that owns it, one to two tiles ahead, as soon as its LDS
+//     region is free, and is waited for (vmcnt(0)) by the requesting waves at the end of their next
+//     MATRIX slot: at least one slot in flight, one barrier before its first reader;
 //   * LDS rows are 128 bytes; the 16-byte chunk index is XOR-ed with a function of the row on the
 //     SOURCE address of the load (the load unit writes lane-linear) and again on the fragment read:
 //     conflict-free ds_read_b128 for 16-byte (16-bit) and 32-byte (fp8) fragments.
