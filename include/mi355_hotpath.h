@@ -395,6 +395,26 @@ int mi355_fp8_scaled_mm_tiled(void* y, const uint8_t* xq, const uint8_t* wq, con
                               const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
                               int out_dtype, int epilogue, void* stream);
 
+/* The qkv projection of a prefill batch with RoPE and the KV-cache write in the GEMM's epilogue:
+ *   qkv = x @ w^T (w [(hq + 2 hkv) * 128, K], rows q | k | v), rounded to the dtype;
+ *   neox RoPE at positions[m] over the whole head on the q and k heads, with the rounding points of
+ *   mi355_rope_inplace (so the result is bit-identical to mi355_linear_tiled followed by
+ *   mi355_rope_inplace with its cache write); qkv [M, (hq + 2 hkv) * 128] receives rotated q, rotated k
+ *   and v; k_buffer[loc[m]] / v_buffer[loc[m]] ([slots, hkv, 128]) receive the rotated k and v rows.
+ * x_scale != NULL selects the fp8 form: x, w are e4m3fn bytes with per-token x_scale[M] and per-channel
+ * w_scale[N] applied as in mi355_fp8_scaled_mm_tiled (x_stride must then equal k).
+ * Needs head_dim = rotary_dim = 128, is_neox, an even hq + 2 hkv, a 16-bit dtype, K % 64 == 0 and K >= 128
+ * (fp8: K % 128 == 0, K >= 256), no bias; cos_sin_cache [max_pos, 128] fp32 or the dtype; loc int32 / int64.
+ * replaces: LlamaAttention.forward's qkv_proj -> rotary_emb -> set_kv_buffer sequence at prefill
+ *           (models/llama.py:187-199, layers/rotary_embedding.py:222-246, mem_cache/memory_pool.py:425-458). */
+int mi355_qkv_proj_rope_tiled_supported(int64_t m, int64_t k, int hq, int hkv, int head_dim, int rotary_dim,
+                                        int is_neox, int dtype, int fp8);
+int mi355_qkv_proj_rope_tiled(void* qkv, const void* x, const void* w, const float* x_scale,
+                              const float* w_scale, int64_t m, int64_t k, int64_t x_stride, int hq, int hkv,
+                              int head_dim, const int64_t* positions, const void* cos_sin_cache,
+                              int cache_dtype, int rotary_dim, int is_neox, void* k_buffer, void* v_buffer,
+                              const void* loc, int loc_itype, int64_t num_slots, int dtype, void* stream);
+
 /* ---- K11 sampling --------------------------------------------------------------------------------
  * ids[b] = first index of max(logits[b,:])   (torch.argmax tie rule)
  * replaces: Sampler.forward greedy branch (layers/sampler.py:72-76). */

@@ -47,6 +47,8 @@ _SIGNATURES = {
     "mi355_linear_tiled": (I, [P, P, P, P, L, L, L, L, I, I, P]),
     "mi355_fp8_scaled_mm_tiled_supported": (I, [L, L, L, I, I]),
     "mi355_fp8_scaled_mm_tiled": (I, [P, P, P, P, P, P, L, L, L, I, I, P]),
+    "mi355_qkv_proj_rope_tiled_supported": (I, [L, L, I, I, I, I, I, I, I]),
+    "mi355_qkv_proj_rope_tiled": (I, [P, P, P, P, P, L, L, L, I, I, I, P, P, I, I, I, P, P, P, I, L, I, P]),
     "mi355_fp8_packed_workspace_bytes": (L, [L, L, L]),
     "mi355_fp8_scaled_mm_packed": (I, [P, P, P, P, P, P, L, L, L, P, L, I, P]),
     "mi355_prefetch_next": (I, [P, L, L, L, I, L]),

@@ -191,6 +191,22 @@ template <typename T> __device__ __forceinline__ T silu_mul_one(T a, T b) {
   return from_f32<T>(s * to_f32(b));
 }
 
+// round_to<T> on two values at once.  For bf16 this is one v_cvt_pk_bf16_f32 (round to nearest even, the
+// rounding round_to<bf16_t> does on the bits) and two bit operations; going through the integer view keeps
+// the compiler from treating the round trip as a no-op.
+typedef float rt_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rt_bf16x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ void round2_to(float a, float b, float& ra, float& rb) {
+  ra = round_to<T>(a);
+  rb = round_to<T>(b);
+}
+template <> __device__ __forceinline__ void round2_to<bf16_t>(float a, float b, float& ra, float& rb) {
+  const rt_bf16x2 h = __builtin_convertvector(rt_f32x2{a, b}, rt_bf16x2);
+  const uint32_t u = __builtin_bit_cast(uint32_t, h);
+  ra = __uint_as_float(u << 16);
+  rb = __uint_as_float(u & 0xffff0000u);
+}
+
 // v_mfma_f32_16x16x32 on 16-bit operands.  Lane l holds A[i = l & 15][k = 8 * (l >> 4) + 0..7] and
 // B[k = 8 * (l >> 4) + 0..7][j = l & 15]; the result lane holds D[i = 4 * (l >> 4) + r][j = l & 15].
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -52,6 +52,15 @@ struct GemmTiledParams {
   int ldy;          // elements between rows of y
   int mt, nt;       // output tiles along M and N
   int snt, nsuper;  // 8 x 4 blocks of tiles: count along N, total
+  // EPI 2 (qkv projection + RoPE + KV-cache write)
+  const int64_t* positions;   // [M]
+  const void* cos_sin;        // [max_pos, 128]: cos | sin, fp32 or the tensor dtype
+  int cs_f32;
+  int hq, hkv;                // local query / kv heads (head_dim 128)
+  void* k_buffer;             // [slots, hkv, 128]
+  void* v_buffer;
+  const void* loc;            // [M] cache slot of each row, int64 or int32
+  int loc_i32;
 };
 
 __device__ __forceinline__ void glds16(const void* g, char* l) {
@@ -72,6 +81,118 @@ template <bool FP8> __device__ __forceinline__ int gt_swz(int r) {
 // T: output dtype and, for 16-bit GEMMs, the operand dtype.  FP8: operands are OCP e4m3fn bytes.
 // EPI 0: y = T(acc (+ bias)); EPI 1: W = [gate; up] (N = 2 I rows), y[m, j] = silu_mul(T(gate_j), T(up_j));
 // fp8: acc is first scaled, (acc * x_scale[m]) * w_scale[n].
+// Epilogue of the qkv projection (EPI 2): neox RoPE over the whole 128-wide head on the q and k heads with
+// the rounding points of mi355_rope_inplace (cos / sin -> T; every product and sum rounds to T on its own, so
+// no contraction here); rotated q / k and plain v go to y, the k and v rows also to the KV cache.
+// The lane holds, for each of its 8 rows, columns d0 .. d0 + 7 of one head (acc[mi][0..1]) and their rotation
+// partners d0 + 64 .. d0 + 71 (acc[mi][2..3]).  Every load (positions, cache slots, cos / sin rows) is
+// requested before the arithmetic of the rows it belongs to: nothing else runs on the CU during an epilogue,
+// so a chain of dependent loads per row would be paid in full.
+template <typename T, bool FP8, bool CSF32>
+__device__ __forceinline__ void qkv_rope_epilogue(const GemmTiledParams& p, f32x4 (&acc)[8][4], const float (&sxm)[8],
+                                                  int tm, int tn, int g, int wc, int q4, int r16) {
+#pragma clang fp contract(off)
+  T* yg = (T*)p.y;
+  const int head = 2 * tn + (wc >> 1), d0 = (wc & 1) * 32 + q4 * 8;
+  const int col0 = head * 128 + d0;
+  const int mbase = tm * 256 + g * 128 + r16;
+  const bool rot = head < p.hq + p.hkv;
+  T* cache_dst = nullptr;
+  if (head >= p.hq + p.hkv) cache_dst = (T*)p.v_buffer + (int64_t)(head - p.hq - p.hkv) * 128 + d0;
+  else if (head >= p.hq) cache_dst = (T*)p.k_buffer + (int64_t)(head - p.hq) * 128 + d0;
+  float slo[8], shi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    slo[j] = FP8 ? p.w_scale[col0 + j] : 1.f;
+    shi[j] = FP8 ? p.w_scale[col0 + 64 + j] : 1.f;
+  }
+  int posv[8], slotv[8];   // positions and slot numbers fit 31 bits (the host checks the slot count)
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = mbase + mi * 16;
+    posv[mi] = (int)p.positions[m < p.M ? m : p.M - 1];
+    slotv[mi] = 0;
+  }
+  if (cache_dst != nullptr) {
+    if (p.loc_i32) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = mbase + mi * 16;
+        slotv[mi] = ((const int32_t*)p.loc)[m < p.M ? m : p.M - 1];
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = mbase + mi * 16;
+        slotv[mi] = (int)((const int64_t*)p.loc)[m < p.M ? m : p.M - 1];
+      }
+    }
+  }
+  constexpr int G = (CSF32 || FP8) ? 2 : 4;   // rows whose cos / sin are in flight together (register budget)
+#pragma unroll
+  for (int half = 0; half < 8 / G; ++half) {
+    // cos / sin of G rows (v heads read them too and ignore them: the branch below is wave-uniform)
+    float c[G][8], sn[G][8];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int64_t pos = posv[half * G + i];
+      if constexpr (CSF32) {
+        const float* cs = (const float*)p.cos_sin + pos * 128 + d0;
+        const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(cs + 64), s1 = *reinterpret_cast<const float4*>(cs + 68);
+        c[i][0] = c0.x; c[i][1] = c0.y; c[i][2] = c0.z; c[i][3] = c0.w;
+        c[i][4] = c1.x; c[i][5] = c1.y; c[i][6] = c1.z; c[i][7] = c1.w;
+        sn[i][0] = s0.x; sn[i][1] = s0.y; sn[i][2] = s0.z; sn[i][3] = s0.w;
+        sn[i][4] = s1.x; sn[i][5] = s1.y; sn[i][6] = s1.z; sn[i][7] = s1.w;
+      } else {
+        const T* cs = (const T*)p.cos_sin + pos * 128 + d0;
+        const Vec<T, 8> cv = ldvec<T, 8>(cs), sv = ldvec<T, 8>(cs + 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { c[i][j] = to_f32(cv.v[j]); sn[i][j] = to_f32(sv.v[j]); }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int mi = half * G + i;
+      const int m = mbase + mi * 16;
+      float x1[8], x2[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float lo = acc[mi][h][r], hi = acc[mi][2 + h][r];
+          if (FP8) { lo = (lo * sxm[mi]) * slo[h * 4 + r]; hi = (hi * sxm[mi]) * shi[h * 4 + r]; }
+          round2_to<T>(lo, hi, x1[h * 4 + r], x2[h * 4 + r]);   // the projection's own result, rounded to T
+        }
+      Vec<T, 8> o1, o2;
+      if (rot) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float cj = c[i][j], sj = sn[i][j];
+          if constexpr (CSF32) round2_to<T>(cj, sj, cj, sj);   // a table of dtype T holds rounded values already
+          float a1, a2, b1, b2;
+          round2_to<T>(x1[j] * cj, x2[j] * sj, a1, a2);
+          round2_to<T>(x2[j] * cj, x1[j] * sj, b1, b2);
+          o1.v[j] = from_f32<T>(a1 - a2);
+          o2.v[j] = from_f32<T>(b1 + b2);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o1.v[j] = from_f32<T>(x1[j]); o2.v[j] = from_f32<T>(x2[j]); }
+      }
+      if (m < p.M) {
+        stvec<T, 8>(yg + (int64_t)m * p.ldy + col0, o1);
+        stvec<T, 8>(yg + (int64_t)m * p.ldy + col0 + 64, o2);
+        if (cache_dst != nullptr) {
+          T* dst = cache_dst + (int64_t)slotv[mi] * p.hkv * 128;
+          stvec<T, 8>(dst, o1);
+          stvec<T, 8>(dst + 64, o2);
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int EPI, bool FP8>
 __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -124,6 +245,10 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
         int j = tn * 128 + wcb * 32 + (ii >> 2) * 8 + (ni & 1) * 4 + (ii & 3);
         j = j < ncols ? j : ncols - 1;
         n = j + (ni >> 1) * ncols;
+      } else if (EPI == 2) {
+        // a tile is two heads; wave wcb serves head 2 tn + (wcb >> 1), rotation pairs d and d + 64 with
+        // d = 32 (wcb & 1) + 8 (ii >> 2) + 4 (ni & 1) + (ii & 3): a lane ends with 8 d's and their partners
+        n = (2 * tn + (wcb >> 1)) * 128 + (wcb & 1) * 32 + (ii >> 2) * 8 + (ni & 1) * 4 + (ii & 3) + (ni >> 1) * 64;
       } else {
         n = tn * 256 + wcb * 64 + (ii >> 2) * 16 + ni * 4 + (ii & 3);
         n = n < p.N ? n : p.N - 1;
@@ -262,7 +387,10 @@ __global__ __launch_bounds__(512) void gemm_tiled_kernel(GemmTiledParams p) {
     const int m = tm * 256 + g * 128 + mi * 16 + r16;
     sxm[mi] = FP8 ? p.x_scale[m < p.M ? m : p.M - 1] : 1.f;
   }
-  if (EPI == 1) {
+  if constexpr (EPI == 2) {
+    if (p.cs_f32) qkv_rope_epilogue<T, FP8, true>(p, acc, sxm, tm, tn, g, wc, q4, r16);
+    else qkv_rope_epilogue<T, FP8, false>(p, acc, sxm, tm, tn, g, wc, q4, r16);
+  } else if (EPI == 1) {
     const int j0 = tn * 128 + wc * 32 + q4 * 8;
     if (j0 < ncols) {
       float sg[8], su[8];
@@ -325,11 +453,13 @@ int launch_gemm_tiled(const GemmTiledParams& p, hipStream_t st) {
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS);
   const int groups = (p.nsuper + 7) / 8;   // every XCD label gets the same number of 8 x 4 blocks
   hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * 32)), dim3(512), GT_LDS, st, p);
-  MI355_CHECK_LAUNCH(FP8 ? "mi355_fp8_scaled_mm_tiled" : "mi355_linear_tiled");
+  MI355_CHECK_LAUNCH(EPI == 2 ? "mi355_qkv_proj_rope_tiled" : FP8 ? "mi355_fp8_scaled_mm_tiled" : "mi355_linear_tiled");
   return MI355_OK;
 }
 
 void fill_tiles(GemmTiledParams& p, int64_t m, int64_t n, int epilogue) {
+  p.positions = nullptr; p.cos_sin = nullptr; p.cs_f32 = 0; p.hq = p.hkv = 0;
+  p.k_buffer = p.v_buffer = nullptr; p.loc = nullptr; p.loc_i32 = 0;
   const int ncols = epilogue == 1 ? (int)(n / 2) : (int)n;
   p.ldy = ncols;
   p.mt = cdiv(m, 256);
@@ -401,4 +531,52 @@ extern "C" int mi355_fp8_scaled_mm_tiled(void* y, const uint8_t* xq, const uint8
   if (out_dtype == MI355_BF16)
     return epilogue == 1 ? launch_gemm_tiled<bf16_t, 1, true>(p, st) : launch_gemm_tiled<bf16_t, 0, true>(p, st);
   return epilogue == 1 ? launch_gemm_tiled<f16_t, 1, true>(p, st) : launch_gemm_tiled<f16_t, 0, true>(p, st);
+}
+
+extern "C" int mi355_qkv_proj_rope_tiled_supported(int64_t m, int64_t k, int hq, int hkv, int head_dim,
+                                                   int rotary_dim, int is_neox, int dtype, int fp8) {
+  if (dtype != MI355_BF16 && dtype != MI355_F16) return 0;
+  if (head_dim != 128 || rotary_dim != 128 || !is_neox || hq < 1 || hkv < 1 || ((hq + 2 * hkv) & 1)) return 0;
+  if (m < 1 || m > (1 << 24)) return 0;
+  return fp8 ? (k >= 256 && (k & 127) == 0) : (k >= 128 && (k & 63) == 0);
+}
+
+extern "C" int mi355_qkv_proj_rope_tiled(void* qkv, const void* x, const void* w, const float* x_scale,
+                                         const float* w_scale, int64_t m, int64_t k, int64_t x_stride,
+                                         int hq, int hkv, int head_dim, const int64_t* positions,
+                                         const void* cos_sin_cache, int cache_dtype, int rotary_dim, int is_neox,
+                                         void* k_buffer, void* v_buffer, const void* loc, int loc_itype,
+                                         int64_t num_slots, int dtype, void* stream) {
+  const bool fp8 = x_scale != nullptr;
+  MI355_REQUIRE(qkv && x && w && positions && cos_sin_cache && k_buffer && v_buffer && loc, MI355_ERR_INVALID,
+                "mi355_qkv_proj_rope_tiled: null pointer");
+  MI355_REQUIRE(!fp8 || w_scale, MI355_ERR_INVALID, "mi355_qkv_proj_rope_tiled: x_scale without w_scale");
+  MI355_REQUIRE(mi355_qkv_proj_rope_tiled_supported(m, k, hq, hkv, head_dim, rotary_dim, is_neox, dtype, fp8),
+                MI355_ERR_UNSUPPORTED,
+                "mi355_qkv_proj_rope_tiled: needs a 16-bit dtype, head_dim = rotary_dim = 128, neox style, an even "
+                "number of heads, K %% 64 == 0 (fp8: %% 128) (m=%ld k=%ld hq=%d hkv=%d head_dim=%d rotary_dim=%d)",
+                (long)m, (long)k, hq, hkv, head_dim, rotary_dim);
+  MI355_REQUIRE(cache_dtype == MI355_F32 || cache_dtype == dtype, MI355_ERR_UNSUPPORTED,
+                "mi355_qkv_proj_rope_tiled: cos_sin_cache must be fp32 or the tensor dtype");
+  MI355_REQUIRE(loc_itype == MI355_I32 || loc_itype == MI355_I64, MI355_ERR_INVALID,
+                "mi355_qkv_proj_rope_tiled: loc must be int32 or int64");
+  MI355_REQUIRE(fp8 ? x_stride == k : (x_stride >= k && x_stride % 8 == 0), MI355_ERR_INVALID,
+                "mi355_qkv_proj_rope_tiled: bad x_stride");
+  MI355_REQUIRE(aligned16(x) && aligned16(w) && aligned16(qkv) && aligned16(cos_sin_cache) && aligned16(k_buffer) &&
+                    aligned16(v_buffer) && num_slots > 0 && num_slots < (1ll << 31),
+                MI355_ERR_INVALID, "mi355_qkv_proj_rope_tiled: pointers must be 16-byte aligned");
+  const int64_t n = (int64_t)(hq + 2 * hkv) * 128;
+  GemmTiledParams p;
+  p.x = x; p.w = w; p.bias = nullptr; p.y = qkv;
+  p.x_scale = x_scale; p.w_scale = w_scale;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k;
+  p.ldx = x_stride;
+  fill_tiles(p, m, n, 0);
+  p.positions = positions; p.cos_sin = cos_sin_cache; p.cs_f32 = cache_dtype == MI355_F32;
+  p.hq = hq; p.hkv = hkv; p.k_buffer = k_buffer; p.v_buffer = v_buffer; p.loc = loc;
+  p.loc_i32 = loc_itype == MI355_I32;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI355_BF16)
+    return fp8 ? launch_gemm_tiled<bf16_t, 2, true>(p, st) : launch_gemm_tiled<bf16_t, 2, false>(p, st);
+  return fp8 ? launch_gemm_tiled<f16_t, 2, true>(p, st) : launch_gemm_tiled<f16_t, 2, false>(p, st);
 }

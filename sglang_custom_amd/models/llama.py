@@ -8,6 +8,7 @@ same op sequence per layer:
 One fusion is applied where it removes launches without changing results: RoPE and the KV-cache
 write of the new tokens are one kernel (the backend is then called with save_kv_cache=False).
 """
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -33,6 +34,11 @@ from ..layers.radix_attention import RadixAttention
 from ..ops_backend import get_ops
 from ..layers.rotary_embedding import get_rope
 from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
+
+# Prefill: qkv projection + RoPE + KV-cache write as one launch ("auto"), or the separate projection and
+# rope kernels ("off").  Below PREFILL_QKV_MIN_TILES 256 x 256 output tiles the unfused path is taken.
+PREFILL_QKV_ROPE = os.environ.get("MI355_PREFILL_QKV_ROPE", "auto")
+PREFILL_QKV_MIN_TILES = 192
 
 
 class LlamaMLP(nn.Module):
@@ -113,6 +119,38 @@ class LlamaAttention(nn.Module):
                                                 forward_batch, part.x_scale, part.w_scale,
                                                 out_dtype=hidden_states.dtype)
 
+    def _fused_prefill_qkv(self, positions, hidden_states, forward_batch):
+        """Prefill fast path: ONE launch computes the qkv projection, rotates q and k and writes the new
+        k / v rows into the KV cache (the rotation and the cache write run in the GEMM's epilogue).
+        Returns the qkv tensor (q, k rotated) or None when it does not apply."""
+        if (PREFILL_QKV_ROPE == "off" or not isinstance(hidden_states, torch.Tensor) or not hidden_states.is_cuda
+                or forward_batch.forward_mode.is_decode() or getattr(self.qkv_proj, "bias", None) is not None):
+            return None
+        x = hidden_states.view(-1, hidden_states.shape[-1])
+        m, k = x.shape
+        qm = self.qkv_proj.quant_method
+        fp8 = isinstance(qm, W8A8Fp8LinearMethod)
+        w = self.qkv_proj.weight
+        if not fp8 and (type(qm) is not UnquantizedLinearMethod or w.dtype != x.dtype):
+            return None
+        if fp8 and w.dtype != torch.float8_e4m3fn:
+            return None
+        kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(self.attn.layer_id)
+        rope = self.rotary_emb
+        ops = get_ops()
+        n_tiles = ((m + 255) // 256) * (w.shape[0] // 256)
+        if (kb.dtype != x.dtype or n_tiles < PREFILL_QKV_MIN_TILES or not hasattr(ops, "qkv_proj_rope_tiled")
+                or not ops.qkv_proj_rope_tiled_supported(m, k, self.num_heads, self.num_kv_heads, self.head_dim,
+                                                         rope.cos_sin_cache.shape[1], rope.is_neox_style, x.dtype, fp8)):
+            return None
+        xs = ws = None
+        if fp8:
+            x, xs = ops.per_token_quant_fp8(x)
+            ws = self.qkv_proj.weight_scale.view(-1)
+        return ops.qkv_proj_rope_tiled(x, w, self.num_heads, self.num_kv_heads, self.head_dim, positions.flatten(),
+                                       rope.cos_sin_cache, rope.is_neox_style, kb, vb, forward_batch.out_cache_loc,
+                                       x_scale=xs, w_scale=ws, out_dtype=hidden_states.dtype)
+
     def forward(self, positions, hidden_states, forward_batch):
         attn_output = self._fused_decode(positions, hidden_states, forward_batch)
         if attn_output is not None:
@@ -120,11 +158,16 @@ class LlamaAttention(nn.Module):
             if deferred is not None:
                 return deferred
             return self.o_proj(attn_output, defer_all_reduce=True)[0]
-        qkv, _ = self.qkv_proj(hidden_states)
+        qkv = self._fused_prefill_qkv(positions, hidden_states, forward_batch)
+        fused = qkv is not None
+        if not fused:
+            qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         pool = forward_batch.token_to_kv_pool
         kb, vb = pool.get_kv_buffer(self.attn.layer_id)
-        if kb.dtype == q.dtype:
+        if fused:
+            attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        elif kb.dtype == q.dtype:
             self.rotary_emb.forward_with_kv_write(positions, q, k, v, kb, vb, forward_batch.out_cache_loc)
             attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
         else:   # fp8 KV cache: the attention backend's own (quantising) KV write

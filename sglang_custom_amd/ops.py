@@ -500,6 +500,49 @@ def linear_tiled(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return y
 
 
+def qkv_proj_rope_tiled_supported(m: int, k: int, hq: int, hkv: int, head_dim: int, rotary_dim: int,
+                                  is_neox: bool, dtype: torch.dtype, fp8: bool = False) -> bool:
+    """Whether qkv_proj_rope_tiled serves the layer (head_dim = rotary_dim = 128, neox, 16-bit)."""
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib_().mi355_qkv_proj_rope_tiled_supported(
+        m, k, hq, hkv, head_dim, rotary_dim, 1 if is_neox else 0, _DT[dtype], 1 if fp8 else 0))
+
+
+def qkv_proj_rope_tiled(x: torch.Tensor, weight: torch.Tensor, hq: int, hkv: int, head_dim: int,
+                        positions: torch.Tensor, cos_sin_cache: torch.Tensor, is_neox: bool,
+                        k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor,
+                        x_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None,
+                        out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """qkv_proj -> rotary_emb -> set_kv_buffer of a prefill batch (models/llama.py:187-199) as one
+    kernel: the 256 x 256-tile projection with neox RoPE and the cache write in its epilogue.
+    Returns qkv [M, (hq + 2 hkv) * head_dim] holding rotated q, rotated k and v.  With x_scale / w_scale
+    x and weight are e4m3fn (per-token / per-channel scales) and out_dtype names the result dtype."""
+    _gpu(x, weight, positions, cos_sin_cache, k_buffer, v_buffer, loc)
+    fp8 = x_scale is not None
+    dtype = out_dtype if fp8 else x.dtype
+    assert x.dim() == 2 and x.stride(1) == 1 and weight.is_contiguous() and weight.dtype == x.dtype
+    M, K = x.shape
+    N = (hq + 2 * hkv) * head_dim
+    assert weight.shape == (N, K)
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == M
+    assert cos_sin_cache.is_contiguous() and cos_sin_cache.dim() == 2
+    assert k_buffer.is_contiguous() and v_buffer.is_contiguous() and k_buffer.dtype == dtype and v_buffer.dtype == dtype
+    assert k_buffer[0].numel() == hkv * head_dim and v_buffer[0].numel() == hkv * head_dim
+    assert loc.is_contiguous() and loc.numel() == M
+    if fp8:
+        assert x.dtype == torch.float8_e4m3fn and x.is_contiguous()
+        assert x_scale.dtype == torch.float32 and x_scale.is_contiguous() and x_scale.numel() == M
+        assert w_scale.dtype == torch.float32 and w_scale.is_contiguous() and w_scale.numel() == N
+    qkv = torch.empty((M, N), dtype=dtype, device=x.device)
+    if M == 0:
+        return qkv
+    check(_lib_().mi355_qkv_proj_rope_tiled(
+        qkv.data_ptr(), x.data_ptr(), weight.data_ptr(), _p(x_scale), _p(w_scale), M, K, x.stride(0), hq, hkv,
+        head_dim, positions.data_ptr(), cos_sin_cache.data_ptr(), _dt(cos_sin_cache), cos_sin_cache.shape[1],
+        1 if is_neox else 0, k_buffer.data_ptr(), v_buffer.data_ptr(), loc.data_ptr(), _IT[loc.dtype],
+        k_buffer.shape[0], _DT[dtype], _stream(x)), "qkv_proj_rope_tiled")
+    return qkv
+
+
 def pack_weight(weight: torch.Tensor) -> torch.Tensor:
     """[N, K] 16-bit weight -> MFMA-fragment-ordered copy for linear_packed (decode GEMMs)."""
     _gpu(weight)

@@ -244,3 +244,144 @@ def test_fp8_prefill_mlp_through_the_fused_gate_up(ops):
         w8a8_fp8.PREFILL_GEMM, w8a8_fp8.TILED_MIN_TILES = keep
     assert fused.shape == lib.shape == (700, 512)
     assert (fused.float() - lib.float()).abs().max().item() <= 2 ** -6 * lib.float().abs().max().item() + 1e-3
+
+
+# ------------------------------------------------------- qkv projection + RoPE + KV-cache write
+def _qkv_case(m, k, hq, hkv, dtype, seed, cache_f32, loc_dtype=torch.int64, slots=None):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    n = (hq + 2 * hkv) * 128
+    x = torch.randn(m, k, device=DEV, generator=g).to(dtype)
+    w = (torch.randn(n, k, device=DEV, generator=g) * k ** -0.5).to(dtype)
+    max_pos = 4096
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, device=DEV).float() / 128))
+    fr = torch.arange(max_pos, device=DEV).float()[:, None] * inv[None]
+    cs = torch.cat([fr.cos(), fr.sin()], dim=-1)
+    cs = cs if cache_f32 else cs.to(dtype)
+    pos = torch.randint(0, max_pos, (m,), device=DEV, generator=g)
+    slots = slots or m + 37
+    loc = torch.randperm(slots, device=DEV, generator=g)[:m].to(loc_dtype)
+    return x, w, cs.contiguous(), pos, loc, slots
+
+
+@pytest.mark.parametrize("m,k,hq,hkv", [(1, 128, 2, 1), (300, 192, 4, 1), (513, 512, 6, 2), (1000, 1024, 32, 8),
+                                        (257, 256, 5, 1)])
+@pytest.mark.parametrize("dtype,cache_f32", [(torch.bfloat16, True), (torch.bfloat16, False), (torch.float16, True)])
+def test_qkv_proj_rope_tiled_equals_the_unfused_sequence(ops, m, k, hq, hkv, dtype, cache_f32):
+    """LlamaAttention.forward's qkv_proj -> rotary_emb -> set_kv_buffer (models/llama.py:187-199) as one
+    launch gives the bits of mi355_linear_tiled followed by mi355_rope_inplace with its cache write: the
+    qkv tensor, and every slot of both cache buffers (slots no token maps to keep their old contents)."""
+    if (hq + 2 * hkv) % 2:
+        assert not ops.qkv_proj_rope_tiled_supported(m, k, hq, hkv, 128, 128, True, dtype)
+        return
+    x, w, cs, pos, loc, slots = _qkv_case(m, k, hq, hkv, dtype, m + k + hq, cache_f32,
+                                          torch.int32 if m % 2 else torch.int64)
+    assert ops.qkv_proj_rope_tiled_supported(m, k, hq, hkv, 128, 128, True, dtype)
+    kb = torch.full((slots, hkv, 128), 7.0, device=DEV, dtype=dtype)
+    vb = torch.full((slots, hkv, 128), -3.0, device=DEV, dtype=dtype)
+    kb2, vb2 = kb.clone(), vb.clone()
+    qkv = ops.qkv_proj_rope_tiled(x, w, hq, hkv, 128, pos, cs, True, kb, vb, loc)
+    ref = ops.linear_tiled(x, w)
+    q, kk, v = ref.split([hq * 128, hkv * 128, hkv * 128], dim=-1)
+    ops.rope_inplace(pos, q, kk, 128, cs, True, v=v, k_buffer=kb2, v_buffer=vb2, loc=loc)
+    assert torch.equal(qkv, ref)
+    assert torch.equal(kb, kb2) and torch.equal(vb, vb2)
+    # and the cache rows are the rotated k / plain v rows of the result
+    assert torch.equal(kb[loc.long()].view(m, -1), qkv[:, hq * 128:(hq + hkv) * 128])
+    assert torch.equal(vb[loc.long()].view(m, -1), qkv[:, (hq + hkv) * 128:])
+
+
+def test_qkv_proj_rope_tiled_vs_oracle(ops):
+    """Against the CPU oracle: F.linear, then the oracle's neox rotation (rounding at the dtype like
+    apply_rope_with_cos_sin_cache_inplace), within one rounding of the GEMM's accumulation order."""
+    import torch.nn.functional as F
+
+    from oracle import ops_ref
+
+    m, k, hq, hkv, dtype = 200, 256, 4, 2, torch.bfloat16
+    x, w, cs, pos, loc, slots = _qkv_case(m, k, hq, hkv, dtype, 99, True)
+    kb = torch.zeros((slots, hkv, 128), device=DEV, dtype=dtype)
+    vb = torch.zeros_like(kb)
+    qkv = ops.qkv_proj_rope_tiled(x, w, hq, hkv, 128, pos, cs, True, kb, vb, loc).cpu()
+    ref = F.linear(x.cpu(), w.cpu())
+    q, kk, v = ref.split([hq * 128, hkv * 128, hkv * 128], dim=-1)
+    q, kk = ops_ref.apply_rope(pos.cpu(), q.contiguous(), kk.contiguous(), 128, cs.cpu(), True)
+    want = torch.cat([q, kk, v], dim=-1).float()
+    assert (qkv.float() - want).abs().max().item() <= 2 ** -6 * want.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("m,k,hq,hkv", [(300, 256, 4, 1), (1000, 1024, 32, 8)])
+def test_qkv_proj_rope_tiled_fp8_equals_the_unfused_sequence(ops, m, k, hq, hkv):
+    from sglang_custom_amd.layers.quantization.w8a8_fp8 import quantize_weight_per_channel
+
+    dtype = torch.bfloat16
+    x, w, cs, pos, loc, slots = _qkv_case(m, k, hq, hkv, dtype, m + k, True)
+    xq, xs = ops.per_token_quant_fp8(x)
+    wq, ws = quantize_weight_per_channel(w)
+    ws = ws.contiguous().view(-1)
+    kb = torch.zeros((slots, hkv, 128), device=DEV, dtype=dtype)
+    vb = torch.zeros_like(kb)
+    kb2, vb2 = kb.clone(), vb.clone()
+    qkv = ops.qkv_proj_rope_tiled(xq, wq, hq, hkv, 128, pos, cs, True, kb, vb, loc, x_scale=xs, w_scale=ws,
+                                  out_dtype=dtype)
+    ref = ops.fp8_scaled_mm_tiled(xq, wq, xs, ws, dtype)
+    q, kk, v = ref.split([hq * 128, hkv * 128, hkv * 128], dim=-1)
+    ops.rope_inplace(pos, q, kk, 128, cs, True, v=v, k_buffer=kb2, v_buffer=vb2, loc=loc)
+    assert torch.equal(qkv, ref) and torch.equal(kb, kb2) and torch.equal(vb, vb2)
+
+
+def test_qkv_proj_rope_tiled_refuses_what_it_does_not_serve(ops):
+    from sglang_custom_amd._lib import Mi355Error
+
+    assert not ops.qkv_proj_rope_tiled_supported(512, 4096, 32, 8, 64, 64, True, torch.bfloat16)     # head_dim
+    assert not ops.qkv_proj_rope_tiled_supported(512, 4096, 32, 8, 128, 64, True, torch.bfloat16)    # partial rotary
+    assert not ops.qkv_proj_rope_tiled_supported(512, 4096, 32, 8, 128, 128, False, torch.bfloat16)  # GPT-J style
+    assert not ops.qkv_proj_rope_tiled_supported(512, 4096, 3, 1, 128, 128, True, torch.bfloat16)    # odd head count
+    assert not ops.qkv_proj_rope_tiled_supported(512, 4096, 32, 8, 128, 128, True, torch.float32)
+    x, w, cs, pos, loc, slots = _qkv_case(64, 128, 2, 1, torch.bfloat16, 5, True)
+    kb = torch.zeros((slots, 1, 128), device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(Mi355Error):
+        ops.qkv_proj_rope_tiled(x, w, 2, 1, 128, pos, cs[:, :64].contiguous(), True, kb, kb.clone(), loc)
+
+
+def test_prefill_through_the_fused_qkv_rope_matches_the_unfused_path(ops):
+    """A prefill (bf16 and fp8 W8A8 models) with the fused qkv + RoPE + cache-write launch against the same
+    prefill through the separate kernels: bit-identical logits and KV-cache contents."""
+    import numpy as np
+
+    from sglang_custom_amd import bench_one_batch as bob
+    from sglang_custom_amd.configs.model_config import ModelConfig
+    from sglang_custom_amd.layers.quantization import unquant, w8a8_fp8
+    from sglang_custom_amd.managers.schedule_batch import Req
+    from sglang_custom_amd.model_executor.model_runner import ModelRunner
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+    from sglang_custom_amd.models import llama
+    from sglang_custom_amd.server_args import ServerArgs
+
+    cfg = hf_config_dict("tiny-llama-d128", "bfloat16")
+    w = make_synthetic_llama_weights(cfg, seed=4321, dtype=torch.bfloat16)
+    rng = np.random.RandomState(3)
+    prompts = [rng.randint(0, cfg["vocab_size"], n).tolist() for n in (700, 513, 300, 64)]
+    keep = (llama.PREFILL_QKV_ROPE, llama.PREFILL_QKV_MIN_TILES, unquant.PREFILL_GEMM, unquant.TILED_MIN_TILES)
+    keep8 = (w8a8_fp8.PREFILL_GEMM, w8a8_fp8.TILED_MIN_TILES)
+    try:
+        unquant.PREFILL_GEMM, unquant.TILED_MIN_TILES = "tiled", 1   # both legs multiply on the same kernel
+        w8a8_fp8.PREFILL_GEMM, w8a8_fp8.TILED_MIN_TILES = "tiled", 1
+        llama.PREFILL_QKV_MIN_TILES = 1
+        for quant in (None, "w8a8_fp8"):
+            sa = ServerArgs(dtype="bfloat16", max_total_tokens=4096, max_running_requests=8,
+                            disable_cuda_graph=True, quantization=quant)
+            mr = ModelRunner(ModelConfig(cfg, dtype="bfloat16"), sa, weights={k: v.cuda() for k, v in w.items()})
+            outs = {}
+            for mode in ("off", "auto"):
+                llama.PREFILL_QKV_ROPE = mode
+                mr.token_to_kv_pool_allocator.clear()
+                mr.req_to_token_pool.clear()
+                nxt, logits, _ = bob.extend([Req(i, p) for i, p in enumerate(prompts)], mr)
+                kv = [t.clone() for t in mr.token_to_kv_pool.get_kv_buffer(0)]
+                outs[mode] = (nxt.cpu(), logits.float().cpu(), kv)
+            assert torch.equal(outs["off"][1], outs["auto"][1])
+            assert torch.equal(outs["off"][0], outs["auto"][0])
+            assert all(torch.equal(a, b) for a, b in zip(outs["off"][2], outs["auto"][2]))
+    finally:
+        llama.PREFILL_QKV_ROPE, llama.PREFILL_QKV_MIN_TILES, unquant.PREFILL_GEMM, unquant.TILED_MIN_TILES = keep
+        w8a8_fp8.PREFILL_GEMM, w8a8_fp8.TILED_MIN_TILES = keep8
