@@ -277,6 +277,24 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                                int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
                                float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* The same attention for an EXTEND batch over cached rows: request b's new tokens are rows
+ * qo_indptr[b] .. qo_indptr[b + 1] - 1 of q [T, hq, rank + rope] / o [T, hq, rank]; token i of the request
+ * attends to the first (seq_lens[b] - n_new_b) + i + 1 rows of the request's req_to_token row (causal; the
+ * new tokens' latent rows are in kv_buffer already).  Four consecutive tokens of a request share one pass
+ * over the rows (64 query rows per fetched row instead of the 16 of a per-token decode pass).
+ * max_extend_len = max_b n_new_b (host knowledge, sizes the grid).  Needs rank 512 + rope 64 and a 16-bit
+ * dtype (mi355_extend_attention_mla_supported returns 1); other shapes: one mi355_decode_attention_mla item
+ * per new token gives the same result.
+ * replaces: attn_mqa's forward_extend in DeepseekV2AttentionMLA.forward_absorb
+ *           (python/sglang/srt/models/deepseek_v2.py:1264-1335, layers/attention/triton_backend.py:632-685). */
+int mi355_extend_attention_mla_supported(int hq, int kv_lora_rank, int rope_dim, int dtype);
+int mi355_extend_attention_mla(const void* q, const void* kv_buffer, void* o, const int32_t* req_to_token,
+                               const int64_t* req_pool_indices, const int64_t* seq_lens,
+                               const int32_t* qo_indptr, int64_t table_stride, int64_t bs,
+                               int64_t max_extend_len, int hq, int kv_lora_rank, int rope_dim,
+                               int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap,
+                               int dtype, void* stream);
+
 /* ---- K12/K13 dense projection y = x @ W^T ------------------------------------------------------
  * x [M, K] (row stride x_stride), W [N, K] contiguous (nn.Linear layout), y [M, N] contiguous.
  * M <= 64 uses the weight-streaming MFMA kernel (bf16/f16); fp32 uses an exact-fp32 tiled kernel

@@ -1480,6 +1480,208 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MLA extend in the absorbed form over cached rows: the new tokens of a request attend to the request's
+// cached prefix and, causally, to each other (their latent rows are in the cache already).  The ring of the
+// decode kernel above, shared by FOUR consecutive new tokens of one request: wave w owns token 4 ty + w,
+// computes that token's 16 heads x 32 keys of scores per step (nothing is computed twice) and accumulates all
+// 512 value features for it (128 accumulator registers), so every latent row fetched into LDS serves 64
+// query rows instead of 16 and the score MFMAs are not repeated per wave.  Rows are requested up to the
+// LAST token's length; a wave masks keys at or beyond its own token's length and skips steps wholly beyond it.
+// A deep ring (4 step buffers, 148 KiB) and up to 512 registers per lane: one workgroup per CU.
+// grid (ceil(hq / 16), ceil(max new tokens / 4), B), block 256; qo_indptr[b] = first row of request b in q / o.
+// ------------------------------------------------------------------------------------------
+constexpr int MLX_TOKENS = 4;
+template <typename T, bool CAP>
+__global__ __launch_bounds__(256) void extend_attn_mla_tile_kernel(
+    const T* __restrict__ q, const T* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p,
+    const int32_t* __restrict__ qo_indptr) {
+  constexpr int NS = MLA_D / 32;   // 18 score k-steps
+  constexpr int NSB = 4, P = NSB - 1;
+  using frag = typename Mfma<T>::frag;
+  using frag4 = typename Mfma16<T>::frag;
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // mlr_lds_bytes(NSB)
+
+  // the last tokens of a request see the most keys: their tiles are dispatched first
+  const int head0 = blockIdx.x * 16, ty = gridDim.y - 1 - blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, c4 = lane >> 4;
+
+  const int q0 = qo_indptr[b], n_new = qo_indptr[b + 1] - q0;
+  if (ty * MLX_TOKENS >= n_new) return;
+  const int64_t page_off = p.req_pool_indices[b] * p.table_stride;
+  const int64_t prefix = p.seq_lens[b] - n_new;
+  const bool valid = ty * MLX_TOKENS + wave < n_new;                      // wave-uniform
+  const int tok = valid ? ty * MLX_TOKENS + wave : n_new - 1;            // a spare wave repeats the last token and stores nothing
+  const int64_t len_w = prefix + tok + 1;                                 // keys this wave's token sees
+  const int last_tok = min(ty * MLX_TOKENS + MLX_TOKENS, n_new) - 1;
+  const int64_t len = prefix + last_tok + 1;                              // keys the workgroup fetches
+  const int n_steps = (int)((len + 31) / 32);
+  const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  const int32_t __attribute__((address_space(4)))* pt =
+      (const int32_t __attribute__((address_space(4)))*)(p.page_table + page_off);
+  const int64_t last_key = len - 1;
+  struct Slots { int32_t a0, a1, a2, a3, b0, b1, b2, b3; };
+  auto slot_of = [&](int64_t key) -> int32_t { return pt[key < last_key ? key : last_key]; };
+  auto slots_of = [&](int step) -> Slots {
+    const int64_t key = (int64_t)step * 32 + 4 * wave;
+    return Slots{slot_of(key), slot_of(key + 1), slot_of(key + 2), slot_of(key + 3),
+                 slot_of(key + 16), slot_of(key + 17), slot_of(key + 18), slot_of(key + 19)};
+  };
+  const unsigned ring = lds_byte_address(sm_raw);
+  const uint64_t kv_base = (uint64_t)(uintptr_t)kvbuf;
+  const uint64_t row_bytes = (uint64_t)p.k_slot_stride * sizeof(T);
+  const unsigned lane16 = 16u * lane;
+  const int trow = lane >> 3, tch = lane & 7;
+  const unsigned tsw = MLA_RANK * sizeof(T) + 16 * (tch ^ (((4 * wave + trow) >> 1) & 7));
+  const int tm0 = -(int)(trow == 0), tm1 = -(int)(trow == 1), tm2 = -(int)(trow == 2), tm3 = -(int)(trow == 3);
+  auto issue_tile = [&](int buf, int32_t s0, int32_t s1, int32_t s2, int32_t s3) {
+    const unsigned base = ring + (unsigned)buf * MLR_TILE + (unsigned)(4 * wave) * MLR_ROWB;
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s0 * row_bytes, lane16, base);
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s1 * row_bytes, lane16, base + MLR_ROWB);
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s2 * row_bytes, lane16, base + 2 * MLR_ROWB);
+    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s3 * row_bytes, lane16, base + 3 * MLR_ROWB);
+    const uint32_t ts = (uint32_t)((s0 & tm0) | (s1 & tm1) | (s2 & tm2) | (s3 & tm3));
+    if (lane < 32)
+      load_to_lds_16_v(reinterpret_cast<const char*>(kvbuf) + (uint64_t)ts * row_bytes + tsw,
+                       ring + (unsigned)buf * MLR_TILE + MLR_TAIL + (unsigned)(4 * wave) * 128);
+  };
+  auto issue_step = [&](int step, const Slots& sl) {
+    const int buf = 2 * (step % NSB);
+    issue_tile(buf, sl.a0, sl.a1, sl.a2, sl.a3);
+    issue_tile(buf + 1, sl.b0, sl.b1, sl.b2, sl.b3);
+  };
+
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc[32];
+#pragma unroll
+  for (int dt = 0; dt < 32; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int k_rd = MLR_ROWB * r16 + 16 * c4;
+  const int kt_rd0 = MLR_TAIL + 128 * r16 + 16 * (c4 ^ ((r16 >> 1) & 7));
+  const int kt_rd1 = MLR_TAIL + 128 * r16 + 16 * ((4 + c4) ^ ((r16 >> 1) & 7));
+  const int v_rd = MLR_ROWB * (4 * c4 + (r16 >> 2)) + 8 * (r16 & 3);   // + 32 (feature block of 16)
+
+  Slots s_nxt{};
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    s_nxt = slots_of(i);
+    if (i < n_steps) issue_step(i, s_nxt);
+  }
+  s_nxt = slots_of(P);
+
+  frag qf[NS];
+  {
+    const int hq_c = head0 + r16 < p.hq ? head0 + r16 : p.hq - 1;
+    const T* qp = q + (int64_t)(q0 + tok) * p.q_stride + (int64_t)hq_c * MLA_D + 8 * c4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 32 * s);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(qf[s]));
+  }
+
+  auto step_compute = [&](int t, const char* tile) {
+    f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int AHEAD = 4;
+    auto k_off = [&](int s) { return s < 16 ? k_rd + 64 * s : (s == 16 ? kt_rd0 : kt_rd1); };
+    frag ka[AHEAD], kb[AHEAD];
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) {
+      ka[s] = *reinterpret_cast<const frag*>(tile + k_off(s));
+      kb[s] = *reinterpret_cast<const frag*>(tile + MLR_TILE + k_off(s));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      sa = Mfma<T>::run(ka[s % AHEAD], qf[s], sa);
+      sb = Mfma<T>::run(kb[s % AHEAD], qf[s], sb);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + AHEAD < NS) {
+        ka[s % AHEAD] = *reinterpret_cast<const frag*>(tile + k_off(s + AHEAD));
+        kb[s % AHEAD] = *reinterpret_cast<const frag*>(tile + MLR_TILE + k_off(s + AHEAD));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const int64_t kb0 = (int64_t)t * 32 + 4 * c4;
+    float x[8], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float v = (r < 4 ? sa[r & 3] : sb[r & 3]) * qmul;
+      if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
+      x[r] = kb0 + (r & 3) + 16 * (r >> 2) < len_w ? v : -INFINITY;
+      mx = fmaxf(mx, x[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const bool need = mx > m + 8.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+      const float mnew = need ? mx : m;
+      const float alpha = exp2f(m - safe_m(mnew));
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 32; ++dt) acc[dt] *= alpha;
+      m = mnew;
+    }
+    const float ms = safe_m(m);
+    float psum = 0.f;
+    T pa4[4], pb4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pa = exp2f(x[r] - ms), pb = exp2f(x[4 + r] - ms);
+      psum += pa + pb;
+      pa4[r] = from_f32<T>(pa);
+      pb4[r] = from_f32<T>(pb);
+    }
+    l += psum;
+    const frag4 pa = __builtin_bit_cast(frag4, pa4), pb = __builtin_bit_cast(frag4, pb4);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {   // 8 batches of 4 feature blocks
+      typename TrRead<T>::v4 va[4], vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        va[i] = TrRead<T>::run(reinterpret_cast<const T*>(tile + v_rd + 32 * (4 * h + i)));
+        vb[i] = TrRead<T>::run(reinterpret_cast<const T*>(tile + MLR_TILE + v_rd + 32 * (4 * h + i)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[4 * h + i] = Mfma16<T>::run(__builtin_bit_cast(frag4, va[i]), pa, acc[4 * h + i]);
+        acc[4 * h + i] = Mfma16<T>::run(__builtin_bit_cast(frag4, vb[i]), pb, acc[4 * h + i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  for (int t = 0; t < n_steps; ++t) {
+    const int younger = min(P - 1, n_steps - 1 - t);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + P < n_steps) issue_step(t + P, s_nxt);
+    s_nxt = slots_of(t + P + 1);
+    if ((int64_t)t * 32 < len_w) step_compute(t, sm_raw + 2 * (t % NSB) * MLR_TILE);
+  }
+
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (valid && head0 + r16 < p.hq) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    // lane (head r16, c4) holds features 16 dt + 4 c4 .. + 3
+    T* dst = o + ((int64_t)(q0 + tok) * p.hq + head0 + r16) * MLA_RANK + 4 * c4;
+#pragma unroll
+    for (int dt = 0; dt < 32; ++dt) {
+      Vec<T, 4> w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.v[r] = from_f32<T>(acc[dt][r] * inv);
+      stvec<T, 4>(dst + 16 * dt, w);
+    }
+  }
+}
+
 // Stage 2: o[b,h,:] = sum_s w_s * part_o[b,h,s,:], w_s = exp(lse_s - lse_total).
 // grid (B*Hq), block 128.
 template <typename T>
@@ -1941,6 +2143,58 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                          p.part_lse, (T*)o, num_splits, kv_lora_rank);
   });
   MI355_CHECK_LAUNCH("decode_attention_mla");
+  return MI355_OK;
+}
+
+int mi355_extend_attention_mla_supported(int hq, int kv_lora_rank, int rope_dim, int dtype) {
+  return hq > 0 && kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16);
+}
+
+int mi355_extend_attention_mla(const void* q, const void* kv_buffer, void* o, const int32_t* req_to_token,
+                               const int64_t* req_pool_indices, const int64_t* seq_lens,
+                               const int32_t* qo_indptr, int64_t table_stride, int64_t bs,
+                               int64_t max_extend_len, int hq, int kv_lora_rank, int rope_dim,
+                               int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap,
+                               int dtype, void* stream) {
+  MI355_REQUIRE(q && kv_buffer && o && req_to_token && req_pool_indices && seq_lens && qo_indptr, MI355_ERR_INVALID,
+                "extend_attention_mla: null pointer");
+  MI355_REQUIRE(mi355_extend_attention_mla_supported(hq, kv_lora_rank, rope_dim, dtype), MI355_ERR_UNSUPPORTED,
+                "extend_attention_mla: needs a latent row of 512 + 64 features and a 16-bit dtype (rank=%d rope=%d)",
+                kv_lora_rank, rope_dim);
+  MI355_REQUIRE(bs >= 0 && bs <= 65535 && max_extend_len >= 0 && max_extend_len <= 4 * 65535 && table_stride > 0 &&
+                    num_slots > 0 && q_stride >= (int64_t)hq * MLA_D && q_stride % 8 == 0,
+                MI355_ERR_INVALID, "extend_attention_mla: bad shape bs=%ld max_extend_len=%ld hq=%d", (long)bs,
+                (long)max_extend_len, hq);
+  MI355_REQUIRE(aligned16(q) && aligned16(kv_buffer) && aligned16(o), MI355_ERR_INVALID,
+                "extend_attention_mla: pointers must be 16-byte aligned");
+  if (bs == 0 || max_extend_len == 0) return MI355_OK;
+  DecodeParams p{};
+  p.page_table = req_to_token;
+  p.req_pool_indices = req_pool_indices;
+  p.seq_lens = seq_lens;
+  p.table_stride = table_stride;
+  p.q_stride = q_stride;
+  p.mode = 0;
+  p.num_splits = 1;
+  p.hq = hq;
+  p.hkv = 1;
+  p.sm_scale = sm_scale;
+  p.logit_cap = logit_cap;
+  p.k_slot_stride = MLA_D;
+  p.v_slot_stride = MLA_D;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)((max_extend_len + MLX_TOKENS - 1) / MLX_TOKENS), (unsigned)bs);
+  constexpr int lds = mlr_lds_bytes(4);
+#define MLX_LAUNCH(T_, CAP_)                                                                                  \
+  do {                                                                                                        \
+    auto kern = extend_attn_mla_tile_kernel<T_, CAP_>;                                                        \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);            \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p, qo_indptr); \
+  } while (0)
+  if (dtype == MI355_BF16) { if (logit_cap > 0.f) MLX_LAUNCH(bf16_t, true); else MLX_LAUNCH(bf16_t, false); }
+  else { if (logit_cap > 0.f) MLX_LAUNCH(f16_t, true); else MLX_LAUNCH(f16_t, false); }
+#undef MLX_LAUNCH
+  MI355_CHECK_LAUNCH("extend_attention_mla");
   return MI355_OK;
 }
 

@@ -15,6 +15,7 @@ decode); the extend kernel additionally masks the prefix phase with q_index <= k
 Called once per layer; the backend owns the KV write when save_kv_cache is set.
 """
 import dataclasses
+import os
 from typing import Optional
 
 import torch
@@ -23,6 +24,11 @@ from ...ops_backend import get_ops
 from .base_attn_backend import AttentionBackend
 
 MAX_KV_SPLITS = 64
+# MLA extend over cached rows: the kernel in which four tokens share a pass over the rows ("tiled"), or one
+# decode-style item per new token ("per_token").  The tiled kernel is launched with a quarter of the
+# workgroups, so batches too small to fill the chip with it stay on the per-token pass.
+MLA_EXTEND_TILED = os.environ.get("MI355_MLA_EXTEND", "tiled") == "tiled"
+MLA_EXTEND_TILED_MIN_WGS = 256
 
 
 @dataclasses.dataclass
@@ -257,6 +263,18 @@ class Mi355AttnBackend(AttentionBackend):
             # request's first position(t) + 1 rows -- the multi-query kernel of the decode path
             # serves it with per-token table rows and lengths.  Causal by construction.
             assert save_kv_cache, "the absorbed MLA extend reads the new tokens from the cache"
+            q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+            if (MLA_EXTEND_TILED
+                    and (q3.shape[0] // 4) * ((layer.tp_q_head_num + 15) // 16) >= MLA_EXTEND_TILED_MIN_WGS
+                    and ops.extend_attention_mla_supported(layer.tp_q_head_num, pool.kv_lora_rank,
+                                                           pool.qk_rope_head_dim, q.dtype)):
+                # four consecutive tokens of a request share one pass over the rows
+                ops.extend_attention_mla(
+                    q3, pool.get_key_buffer(layer.layer_id), o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+                    forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
+                    forward_batch.seq_lens, md.qo_indptr, md.max_extend_len, pool.kv_lora_rank, layer.scaling,
+                    layer.logit_cap)
+                return o
             tok_req = torch.repeat_interleave(forward_batch.req_pool_indices, forward_batch.extend_seq_lens.to(torch.int64))
             tok_len = (forward_batch.positions + 1).to(torch.int64)
             ops.decode_attention_mla(

@@ -402,6 +402,33 @@ def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_le
         "decode_attention_mla")
 
 
+def extend_attention_mla_supported(hq: int, kv_lora_rank: int, rope_dim: int, dtype: torch.dtype) -> bool:
+    """Whether extend_attention_mla serves the shape (latent row of 512 + 64 features, 16-bit)."""
+    return dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib_().mi355_extend_attention_mla_supported(hq, kv_lora_rank, rope_dim, _DT[dtype]))
+
+
+def extend_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, qo_indptr,
+                         max_extend_len: int, kv_lora_rank: int, sm_scale: float, logit_cap: float = 0.0) -> None:
+    """attn_mqa (deepseek_v2.py:866-875) of an extend batch in the absorbed form: request b's new tokens
+    (rows qo_indptr[b] .. qo_indptr[b + 1] of q [T, H, rank + rope] and o [T, H, rank]) attend to the
+    request's first seq_lens[b] cache rows causally; the new tokens' latent rows are in kv_buffer
+    [slots, 1, rank + rope] already.  Four consecutive tokens share one pass over the rows."""
+    _gpu(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, qo_indptr)
+    T, Hq, D = q.shape
+    B = req_pool_indices.numel()
+    assert kv_buffer.is_contiguous() and kv_buffer.shape[1] == 1 and kv_buffer.shape[2] == D
+    assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous() and o.shape == (T, Hq, kv_lora_rank)
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64 and seq_lens.numel() == B
+    assert qo_indptr.dtype == torch.int32 and qo_indptr.is_contiguous() and qo_indptr.numel() == B + 1
+    check(_lib_().mi355_extend_attention_mla(
+        q.data_ptr(), kv_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), req_pool_indices.data_ptr(),
+        seq_lens.data_ptr(), qo_indptr.data_ptr(), req_to_token.stride(0), B, int(max_extend_len), Hq, kv_lora_rank,
+        D - kv_lora_rank, q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap), _dt(q), _stream(q)),
+        "extend_attention_mla")
+
+
 def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
                          kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr,
                          max_len_extend, sm_scale=None, logit_cap=0.0,

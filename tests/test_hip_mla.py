@@ -87,7 +87,19 @@ def test_mla_module_prefill_then_absorbed_decode(dtn, H, qr, tol):
         assert (out - ref).abs().max().item() <= tol * scale, f"decode step {t}"
 
 
-def test_mla_module_chunked_prefill_over_cached_latent_rows():
+@pytest.fixture(params=["per_token", "tiled"])
+def mla_extend_mode(request):
+    """Both forms of the absorbed extend over cached rows: one decode-style item per new token, and the
+    kernel in which four tokens share a pass over the rows (forced on whatever the batch size)."""
+    from sglang_custom_amd.layers.attention import mi355_backend as be
+
+    keep = (be.MLA_EXTEND_TILED, be.MLA_EXTEND_TILED_MIN_WGS)
+    be.MLA_EXTEND_TILED, be.MLA_EXTEND_TILED_MIN_WGS = request.param == "tiled", 0
+    yield request.param
+    be.MLA_EXTEND_TILED, be.MLA_EXTEND_TILED_MIN_WGS = keep
+
+
+def test_mla_module_chunked_prefill_over_cached_latent_rows(mla_extend_mode):
     """A prompt prefilled in two chunks: the first through the multi-head path, the second as an
     extend over the cached latent rows in the absorbed form; then one decode step.  Every position
     equals the oracle's causal attention over the whole sequence."""
@@ -199,7 +211,7 @@ def _mla_world(dt, H, slots=1024):
 
 
 @pytest.mark.parametrize("name,dtn,qr,scaling", _CASES.MLA_MODULE_CASES)
-def test_mla_module_matches_reference_vectors(golden_mla, name, dtn, qr, scaling):
+def test_mla_module_matches_reference_vectors(golden_mla, mla_extend_mode, name, dtn, qr, scaling):
     """The attention module on the GPU against the outputs of the reference's DeepseekV2AttentionMLA on
     the same weights and hidden states: prefill (multi-head form and absorbed form), the latent rows
     written to the cache, three decode steps, and a two-chunk prefill; with and without q_lora, with
@@ -327,3 +339,72 @@ def test_mla_module_with_fp8_kv_b_proj_matches_reference_vectors(golden_mla):
         batch.prepare_for_decode()
         out = run(torch.stack([s[n + step] for s, n in zip(seqs, lens)]))
         assert (out - g(f"decode_{step}")).abs().max().item() <= 4e-2 * scale, step
+
+
+# ---- the tiled extend kernel on its own ---------------------------------------------------------------
+@pytest.mark.parametrize("H", [16, 20, 128])
+@pytest.mark.parametrize("dt,cap", [(torch.bfloat16, 0.0), (torch.float16, 0.0), (torch.bfloat16, 30.0)])
+def test_mla_extend_tiled_kernel_vs_per_token_pass_and_fp64(H, dt, cap):
+    """mi355_extend_attention_mla on a ragged extend batch (new-token counts that are not multiples of the
+    4-token tile, a request without a prefix, a one-token request, prefixes that end inside a 32-key step)
+    against one mi355_decode_attention_mla item per new token (the form the reference-vector tests pin) to one
+    output rounding, and against float64 softmax math on every token of the shortest requests."""
+    from sglang_custom_amd import ops
+
+    R, P = 512, 64
+    D = R + P
+    new = [37, 1, 130, 4, 63]
+    prefix = [0, 77, 300, 1, 33]
+    B, width = len(new), 512
+    g = torch.Generator(device=DEV).manual_seed(H + int(cap))
+    slots = sum(n + p for n, p in zip(new, prefix)) + 1
+    kv = torch.randn(slots, 1, D, device=DEV, generator=g).to(dt)
+    perm = (1 + torch.randperm(slots - 1, device=DEV, generator=g)).to(torch.int32)
+    r2t = torch.zeros(B + 3, width, dtype=torch.int32, device=DEV)
+    rpi = torch.tensor([4, 0, 6, 2, 1], dtype=torch.int64, device=DEV)
+    off = 0
+    for b in range(B):
+        n = new[b] + prefix[b]
+        r2t[rpi[b], :n] = perm[off:off + n]
+        off += n
+    T = sum(new)
+    q = (torch.randn(T, H, D, device=DEV, generator=g) * 0.5).to(dt)
+    seq_lens = torch.tensor([n + p for n, p in zip(new, prefix)], dtype=torch.int64, device=DEV)
+    qo = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    qo[1:] = torch.cumsum(torch.tensor(new, device=DEV), 0)
+    o = torch.full((T, H, R), 7.0, dtype=dt, device=DEV)
+    assert ops.extend_attention_mla_supported(H, R, P, dt)
+    ops.extend_attention_mla(q, kv, o, r2t, rpi, seq_lens, qo, max(new), R, D ** -0.5, cap)
+    # the per-token pass
+    tok_req = torch.repeat_interleave(rpi, torch.tensor(new, device=DEV))
+    tok_len = torch.cat([p + 1 + torch.arange(n) for n, p in zip(new, prefix)]).to(torch.int64).to(DEV)
+    o2 = torch.empty_like(o)
+    ops.decode_attention_mla(q, kv, o2, r2t, tok_req, tok_len, None, None, 1, R, D ** -0.5, cap)
+    tol = 1.6e-2 if dt == torch.bfloat16 else 2e-3
+    assert (o.float() - o2.float()).abs().max().item() <= tol
+    # float64 on the requests with few keys
+    for b in (0, 1, 3, 4):
+        rows = kv[r2t[rpi[b], :new[b] + prefix[b]].long(), 0].double()
+        for i in range(new[b]):
+            t = int(qo[b]) + i
+            s = (q[t].double() @ rows[:prefix[b] + i + 1].t()) * D ** -0.5
+            if cap:
+                s = cap * torch.tanh(s / cap)
+            want = s.softmax(-1) @ rows[:prefix[b] + i + 1, :R]
+            assert (o[t].double() - want).abs().max().item() <= tol, (b, i)
+
+
+def test_mla_extend_tiled_refuses_other_latent_shapes():
+    from sglang_custom_amd import ops
+    from sglang_custom_amd._lib import Mi355Error
+
+    assert not ops.extend_attention_mla_supported(16, 256, 64, torch.bfloat16)
+    assert not ops.extend_attention_mla_supported(16, 512, 64, torch.float32)
+    q = torch.zeros(4, 2, 320, device=DEV, dtype=torch.bfloat16)
+    kv = torch.zeros(8, 1, 320, device=DEV, dtype=torch.bfloat16)
+    o = torch.zeros(4, 2, 256, device=DEV, dtype=torch.bfloat16)
+    r2t = torch.zeros(1, 8, dtype=torch.int32, device=DEV)
+    with pytest.raises(Mi355Error):
+        ops.extend_attention_mla(q, kv, o, r2t, torch.zeros(1, dtype=torch.int64, device=DEV),
+                                 torch.full((1,), 4, dtype=torch.int64, device=DEV),
+                                 torch.tensor([0, 4], dtype=torch.int32, device=DEV), 4, 256, 0.1)

@@ -50,11 +50,11 @@ for (B, n_new, prefix, H) in cases:
     line = f"B={B} new={n_new} prefix={prefix} H={H}: per-token {t0:9.1f} us ({flops / t0 / 1e6:6.1f} TFLOP/s)"
     if hasattr(ops, "extend_attention_mla"):
         o2 = torch.empty_like(o)
-        ext = torch.full((B,), n_new, dtype=torch.int64)
-        pre = torch.full((B,), prefix, dtype=torch.int64)
+        sl = torch.full((B,), ctx, dtype=torch.int64, device="cuda")
+        qo = (torch.arange(B + 1, device="cuda") * n_new).to(torch.int32)
 
         def tiled():
-            ops.extend_attention_mla(q, kv, o2, r2t, rpi, ext, pre, rank, D ** -0.5)
+            ops.extend_attention_mla(q, kv, o2, r2t, rpi, sl, qo, n_new, rank, D ** -0.5)
 
         t1 = timeit(tiled)
         err = (o.float() - o2.float()).abs().max().item()
