@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 #define MI355_OK 0
+#define MI355_MAX_KV_SPLITS 4096 /* upper bound of num_splits in the decode attention entry points */
 #define MI355_ERR_INVALID (-1)     /* bad argument: null pointer, negative size, misaligned */
 #define MI355_ERR_UNSUPPORTED (-2) /* dtype / head_dim / shape outside what the kernels cover */
 #define MI355_ERR_LAUNCH (-3)      /* hipGetLastError() after the launch was not hipSuccess */
@@ -181,8 +182,14 @@ int mi355_prepare_decode(int32_t* req_to_token, const int64_t* req_pool_indices,
  *          len = seq_lens[b]   (indptr unused)
  *   mode 1 (kv_indices, as decode_attention_fwd):   page_off = kv_indptr[b],
  *          len = kv_indptr[b+1]-kv_indptr[b]         (req_pool_indices/seq_lens unused)
- * scratch: attn_logits fp32 [B, Hq, max_splits, Dv], attn_lse fp32 [B, Hq, max_splits]
- * (unused when num_splits == 1).  logit_cap > 0 applies cap*tanh(s/cap).
+ * scratch: attn_logits fp32 [B, Hq, num_splits, Dv], attn_lse fp32 [B, Hq, num_splits]
+ * (unused when num_splits == 1; num_splits <= MI355_MAX_KV_SPLITS).  logit_cap > 0 applies cap*tanh(s/cap).
+ * split_tickets (may be NULL): B * Hq uint32 arrival counters, ZERO when the call is made and zero
+ * again when its kernels have finished (hipMemset them once, then hand the same array to every call on
+ * one stream).  With them the head_dim-128 16-bit kernel merges the KV splits itself -- the last split
+ * workgroup of a (sequence, head group) to finish does it -- and no second launch follows; without them,
+ * above 64 splits, and for every other shape, a merge kernel is launched behind the first.  Same bits
+ * either way.  Calls that may overlap on the GPU need arrays of their own.
  * replaces: decode_attention_fwd (layers/attention/triton_ops/decode_attention.py:677-728),
  *           decode_attention_cpu (sgl-kernel/csrc/cpu/decode.cpp:1375-1575),
  *           TorchNativeAttnBackend._run_sdpa_forward_decode (torch_native_backend.py:112-180). */
@@ -190,9 +197,9 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
                            const int32_t* page_table, int mode, const int64_t* req_pool_indices,
                            const int64_t* seq_lens, const int32_t* kv_indptr,
                            int64_t table_stride, float* attn_logits, float* attn_lse,
-                           int num_splits, int64_t bs, int hq, int hkv, int head_dim,
-                           int v_head_dim, int64_t q_stride, int64_t num_slots, float sm_scale,
-                           float logit_cap, int dtype, void* stream);
+                           uint32_t* split_tickets, int num_splits, int64_t bs, int hq, int hkv,
+                           int head_dim, int v_head_dim, int64_t q_stride, int64_t num_slots,
+                           float sm_scale, float logit_cap, int dtype, void* stream);
 
 /* Number of KV splits mi355_decode_attention should be given for this batch (host-side
  * planner; never exceeds max_splits).
@@ -249,7 +256,7 @@ int mi355_decode_attention_static(const void* q, const void* k_buffer, const voi
  * slot out_cache_loc[b] (which the page table must name for position seq_len - 1, except for padding
  * rows, whose writes go to the sink slot they name), and runs mi355_decode_attention.  Output and
  * cache contents are bit-identical to mi355_linear_packed -> mi355_rope_inplace (fused KV write) ->
- * mi355_decode_attention.  Needs head_dim 128, a 16-bit dtype, hq / hkv in {1, 2, 4, 8}, no logit cap.
+ * mi355_decode_attention (split_tickets as there).  Needs head_dim 128, a 16-bit dtype, hq / hkv in {1, 2, 4, 8}, no logit cap.
  * replaces: LlamaAttention.forward's rotary_emb + attn sequence (models/llama.py:180-191) on the
  *           decode path; the reference has no fused counterpart. */
 int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const float* part_x_scale,
@@ -258,14 +265,15 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
                                      void* v_buffer, void* o, const int32_t* page_table, int mode,
                                      const int64_t* req_pool_indices, const int64_t* seq_lens,
                                      const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                                     float* attn_lse, int num_splits, int64_t bs, int hq, int hkv,
-                                     int head_dim, int64_t num_slots, float sm_scale, int dtype,
-                                     void* stream);
+                                     float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs,
+                                     int hq, int hkv, int head_dim, int64_t num_slots, float sm_scale,
+                                     int dtype, void* stream);
 
 /* MLA (compressed-KV) decode: every query head attends over ONE latent row per token,
  * kv_buffer [num_slots, 1, kv_lora_rank + rope_dim]; the key is the whole row, the value its first
  * kv_lora_rank features (read from the same buffer, never materialised).  q [B, hq, rank + rope],
- * o [B, hq, kv_lora_rank]; addressing modes and split scratch as mi355_decode_attention.
+ * o [B, hq, kv_lora_rank]; addressing modes, split scratch and split_tickets as mi355_decode_attention
+ * (the rank-512 + rope-64 16-bit kernel merges the splits itself when given tickets).
  * replaces: attn_mqa = RadixAttention(H, 576, scaling, num_kv_heads=1, v_head_dim=512) on
  *           MLATokenToKVPool (python/sglang/srt/models/deepseek_v2.py:866-875,
  *           mem_cache/memory_pool.py:769-970: get_value_buffer = kv_buffer[..., :kv_lora_rank]). */
@@ -273,7 +281,7 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                                const int32_t* page_table, int mode,
                                const int64_t* req_pool_indices, const int64_t* seq_lens,
                                const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                               float* attn_lse, int num_splits, int64_t bs, int hq,
+                               float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs, int hq,
                                int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
                                float sm_scale, float logit_cap, int dtype, void* stream);
 

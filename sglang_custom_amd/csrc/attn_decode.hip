@@ -31,6 +31,9 @@ struct DecodeParams {
   int mode, num_splits, hq, hkv;
   float sm_scale, logit_cap;
   int64_t k_slot_stride, v_slot_stride;  // elements between consecutive slots (generic kernel)
+  // Arrival counters of the in-kernel merge, one per (sequence, blockIdx.x), zero between launches; null:
+  // the splits are merged by decode_merge_kernel in a second launch.  Only the kernels that say so use them.
+  unsigned* tickets = nullptr;
 };
 
 // Inputs of the fused decode step: the qkv projection is still fp32 split-K partials, RoPE has
@@ -59,6 +62,124 @@ __device__ __forceinline__ void seq_range(const DecodeParams& p, int b, int64_t&
 }
 
 __device__ __forceinline__ float safe_m(float m) { return m == -INFINITY ? 0.f : m; }
+
+// ---- stage 2 of split-KV decoding: o[b, h, :] = sum_s w_s part_o[b, h, s, :] / sum_s w_s with
+// w_s = exp(lse_s - max lse).  ONE statement of the arithmetic, shared by the merge launch and by the
+// in-kernel merge below, so that both give the same bits.
+__device__ __forceinline__ float merge_weights(const float* lse, int num_splits, float* w) {
+  float mx = -INFINITY;
+  for (int s = 0; s < num_splits; ++s) mx = fmaxf(mx, lse[s]);
+  const float ms = safe_m(mx);
+  float tot = 0.f;
+  for (int s = 0; s < num_splits; ++s) {
+    const float e = expf(lse[s] - ms);
+    if (w) w[s] = e;
+    tot += e;
+  }
+  return tot;
+}
+__device__ __forceinline__ float merge_step(float w, float part, float a) { return __builtin_fmaf(w, part, a); }
+__device__ __forceinline__ float merge_finish(float a, float tot) { return tot > 0.f ? a / tot : 0.f; }
+
+// Buffer resource over `bytes` at `ptr`; aux = 16 (sc1) on a store writes through to memory, on a load
+// never returns a line that another XCD's store has made stale.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ auto wt_rsrc(const void* ptr, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+constexpr int MERGE_MAX_SPLITS = 64;   // the in-kernel merge stages (heads of a workgroup) x (splits) weights in LDS
+
+// In-kernel merge of the KV splits (split-KV decoding without the second launch).  Every workgroup of
+// a (sequence, blockIdx.x) pair calls this after storing its partial outputs and log-sum-exp WRITE-THROUGH
+// (sc1); the stores are drained, the workgroup takes a ticket, and the workgroup that draws the last
+// ticket reads all splits back (sc1 loads), merges its `nheads` heads x Dv features with the arithmetic
+// of decode_merge_kernel, writes o and puts the ticket back to zero for the next launch.
+// ticket_idx: one counter per (sequence, head group of the workgroup).
+// lds: >= 8 + nheads * (num_splits + 1) floats that no thread of the workgroup still reads.
+template <typename T, int IT>
+__device__ __forceinline__ void merge_splits_if_last(const DecodeParams& p, T* __restrict__ o, int b, int head0,
+                                                     int nheads, int Dv, int ticket_idx, float* lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // every wave's partial stores have reached memory; `lds` is free
+  int* flag = reinterpret_cast<int*>(lds);
+  unsigned* ticket = p.tickets + ticket_idx;
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = old == (unsigned)(p.num_splits - 1);
+  }
+  __syncthreads();
+  if (!*flag) return;
+  const int S = p.num_splits;
+  float* w = lds + 8;             // [nheads][S]
+  float* tot = w + nheads * S;    // [nheads]
+  const int64_t bh0 = (int64_t)b * p.hq + head0;
+  const auto ro = wt_rsrc(p.part_o + bh0 * S * Dv, nheads * S * Dv * 4);
+  const int per_head = Dv >> 2, n_items = nheads * per_head;
+  // A thread merges IT four-feature items at a time, eight splits each: IT x 8 loads per memory round
+  // trip.  The first round's loads do not depend on the weights and are issued ahead of them.
+  int gi[IT], di[IT];
+  f32x4 v[IT][8];   // (whole vectors are cast: a bit_cast of ONE element of the integer vector reads element 0 for all four)
+  auto place = [&](int first) {
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      const int at = first + t * (int)blockDim.x;
+      const int item = at < n_items ? at : 0;   // (a clamped item is loaded, never stored)
+      gi[t] = item / per_head;
+      di[t] = 4 * (item - gi[t] * per_head);
+    }
+  };
+  auto load_round = [&](int s0) {
+#pragma unroll
+    for (int t = 0; t < IT; ++t)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sp = s0 + u < S ? s0 + u : S - 1;
+        v[t][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, ((gi[t] * S + sp) * Dv + di[t]) * 4, 0, 16));
+      }
+  };
+  place(threadIdx.x);
+  load_round(0);
+  const auto rl = wt_rsrc(p.part_lse + bh0 * S, nheads * S * 4);
+  for (int i = threadIdx.x; i < nheads * S; i += blockDim.x)
+    w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, i * 4, 0, 16));
+  __syncthreads();
+  for (int g = threadIdx.x; g < nheads; g += blockDim.x) tot[g] = merge_weights(w + g * S, S, w + g * S);   // in place
+  __syncthreads();
+  for (int first = threadIdx.x; first < n_items; first += IT * blockDim.x) {
+    float a[IT][4];
+#pragma unroll
+    for (int t = 0; t < IT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[t][j] = 0.f;
+    if (first != (int)threadIdx.x) {
+      place(first);
+      load_round(0);
+    }
+    for (int s0 = 0; s0 < S; s0 += 8) {
+      if (s0 > 0) load_round(s0);
+#pragma unroll
+      for (int t = 0; t < IT; ++t)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s0 + u < S) {
+            const float ws = w[gi[t] * S + s0 + u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[t][j] = merge_step(ws, v[t][u][j], a[t][j]);
+          }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      if (first + t * (int)blockDim.x < n_items) {
+        Vec<T, 4> out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out.v[j] = from_f32<T>(merge_finish(a[t][j], tot[gi[t]]));
+        stvec<T, 4>(o + (bh0 + gi[t]) * Dv + di[t], out);
+      }
+    }
+  }
+  if (threadIdx.x == 0) *ticket = 0u;   // zero again for the next launch (published by the kernel boundary)
+}
 
 // Sum over the LPR consecutive lanes that hold one K row.  Up to 16 lanes the exchange is done
 // with DPP row operations (no LDS crossbar traffic); wider groups finish with xor-shuffles.
@@ -944,11 +1065,19 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
     if (p.num_splits == 1) {
       o[((int64_t)b * p.hq + head) * D + d] = from_f32<T>(val);
     } else {
-      const int64_t ph = ((int64_t)b * p.hq + head) * p.num_splits + split;
-      p.part_o[ph * D + d] = val;
-      if (d == 0) p.part_lse[ph] = lt > 0.f ? mx * kLn2 + logf(lt) : -INFINITY;
+      // write-through, so that the workgroup that merges the splits (below) sees them without a fence;
+      // the resources start at the workgroup's first head (wave-uniform), the lane adds its head and feature
+      const int64_t ph0 = ((int64_t)b * p.hq + head0) * p.num_splits;
+      const int cell = g * p.num_splits + split;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val),
+                                            wt_rsrc(p.part_o + ph0 * D, G * p.num_splits * D * 4), (cell * D + d) * 4, 0, 16);
+      if (d == 0)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lt > 0.f ? mx * kLn2 + logf(lt) : -INFINITY),
+                                              wt_rsrc(p.part_lse + ph0, G * p.num_splits * 4), cell * 4, 0, 16);
     }
   }
+  // (one counter per sequence and head group: blockIdx.x is rotated, xrot names the group)
+  if (p.num_splits > 1 && p.tickets) merge_splits_if_last<T, 1>(p, o, b, head0, G, D, b * (int)gridDim.x + xrot, &sm_acc[0][0][0]);
 }
 
 // Any head_dim / v_head_dim (<= 1024): one wave per (head, split, sequence); lanes stride the
@@ -1471,12 +1600,23 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
         stvec<T, 4>(dst + 16 * dt, w);
       }
     } else {
-      const int64_t ph = ((int64_t)b * p.hq + head) * p.num_splits + split;
-      float* dst = p.part_o + ph * MLA_RANK + 128 * wave + 4 * c4;
+      // write-through, so that the workgroup that merges the splits (below) sees them without a fence
+      // (the resources start at the workgroup's first head: wave-uniform; the lane adds its head and features)
+      const int64_t ph0 = ((int64_t)b * p.hq + head0) * p.num_splits;
+      const int cell = r16 * p.num_splits + split;
+      const auto rs = wt_rsrc(p.part_o + ph0 * MLA_RANK, 16 * p.num_splits * MLA_RANK * 4);
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(dst + 16 * dt) = acc[dt] * inv;
-      if (c4 == 0 && wave == 0) p.part_lse[ph] = l > 0.f ? m * kLn2 + logf(l) : -INFINITY;
+      for (int dt = 0; dt < 8; ++dt)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[dt] * inv), rs,
+                                               (cell * MLA_RANK + 128 * wave + 4 * c4 + 16 * dt) * 4, 0, 16);
+      if (c4 == 0 && wave == 0)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l > 0.f ? m * kLn2 + logf(l) : -INFINITY),
+                                              wt_rsrc(p.part_lse + ph0, 16 * p.num_splits * 4), cell * 4, 0, 16);
     }
+  }
+  if (p.num_splits > 1 && p.tickets) {
+    const int nheads = p.hq - head0 < 16 ? p.hq - head0 : 16;
+    merge_splits_if_last<T, 4>(p, o, b, head0, nheads, MLA_RANK, b * (int)gridDim.x + (int)blockIdx.x, reinterpret_cast<float*>(sm_raw));
   }
 }
 
@@ -1691,16 +1831,15 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const float* __restri
                                                            int Dv) {
   const int64_t bh = blockIdx.x;
   const float* lse = part_lse + bh * num_splits;
+  const float tot = merge_weights(lse, num_splits, nullptr);
   float mx = -INFINITY;
   for (int s = 0; s < num_splits; ++s) mx = fmaxf(mx, lse[s]);
   const float ms = safe_m(mx);
-  float tot = 0.f;
-  for (int s = 0; s < num_splits; ++s) tot += expf(lse[s] - ms);
   for (int d = threadIdx.x; d < Dv; d += 128) {
     float a = 0.f;
     for (int s = 0; s < num_splits; ++s)
-      a += expf(lse[s] - ms) * part_o[(bh * num_splits + s) * Dv + d];
-    o[bh * Dv + d] = from_f32<T>(tot > 0.f ? a / tot : 0.f);
+      a = merge_step(expf(lse[s] - ms), part_o[(bh * num_splits + s) * Dv + d], a);
+    o[bh * Dv + d] = from_f32<T>(merge_finish(a, tot));
   }
 }
 
@@ -1778,7 +1917,8 @@ static bool launch_decode_d(const T* q, const T* kb, const T* vb, T* o, const De
 
 template <typename T>
 static int launch_decode(const void* q_, const void* kb_, const void* vb_, void* o_,
-                         const DecodeParams& p, int64_t bs, int D, int Dv, hipStream_t st) {
+                         const DecodeParams& p_in, int64_t bs, int D, int Dv, hipStream_t st) {
+  DecodeParams p = p_in;
   const T* q = (const T*)q_;
   const T* kb = (const T*)kb_;
   const T* vb = (const T*)vb_;
@@ -1786,6 +1926,10 @@ static int launch_decode(const void* q_, const void* kb_, const void* vb_, void*
   const bool vec = D == Dv && aligned16(q) && aligned16(kb) && aligned16(vb) &&
                    p.q_stride % V16<T>::n == 0;
   constexpr int VE = V16<T>::n;
+  // only the matrix-core kernel (head_dim 128, 16-bit) merges the splits itself
+  if (!(vec && D == 128 && !std::is_same<T, float>::value && (g_kv8 || g_decode_variant == 0) &&
+        p.num_splits > 1 && p.num_splits <= MERGE_MAX_SPLITS))
+    p.tickets = nullptr;
   if (g_kv8 && !(vec && D == 128 && !std::is_same<T, float>::value)) {
     set_error("decode_attention: an fp8 KV cache needs head_dim 128, a 16-bit dtype and 16-B aligned pointers");
     return MI355_ERR_UNSUPPORTED;
@@ -1801,15 +1945,17 @@ static int launch_decode(const void* q_, const void* kb_, const void* vb_, void*
     hipLaunchKernelGGL((decode_attn_generic_kernel<T>), dim3((unsigned)p.hq, (unsigned)p.num_splits, (unsigned)bs),
                        dim3(64), 0, st, q, kb, vb, o, p, D, Dv);
   }
-  if (p.num_splits > 1)
+  if (p.num_splits > 1 && !p.tickets)
     hipLaunchKernelGGL((decode_merge_kernel<T>), dim3((unsigned)(bs * p.hq)), dim3(128), 0, st,
                        p.part_o, p.part_lse, o, p.num_splits, Dv);
   return MI355_OK;
 }
 
 template <typename T>
-static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParams& p, const FusedQkv& fz,
+static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParams& p_in, const FusedQkv& fz,
                                int64_t bs, hipStream_t st) {
+  DecodeParams p = p_in;
+  if (p.num_splits <= 1 || p.num_splits > MERGE_MAX_SPLITS) p.tickets = nullptr;
   const int G = p.hq / p.hkv;
   const dim3 grid((unsigned)p.hkv, (unsigned)p.num_splits, (unsigned)bs), block(256);
   if (g_kv8) {
@@ -1822,7 +1968,7 @@ static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParam
         set_error("decode_attention_fused_qkv: %d query heads per kv head (needs 1, 2, 4 or 8)", G);
         return MI355_ERR_UNSUPPORTED;
     }
-    if (p.num_splits > 1)
+    if (p.num_splits > 1 && !p.tickets)
       hipLaunchKernelGGL((decode_merge_kernel<T>), dim3((unsigned)(bs * p.hq)), dim3(128), 0, st,
                          p.part_o, p.part_lse, o, p.num_splits, 128);
     return MI355_OK;
@@ -1836,7 +1982,7 @@ static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParam
       set_error("decode_attention_fused_qkv: %d query heads per kv head (needs 1, 2, 4 or 8)", G);
       return MI355_ERR_UNSUPPORTED;
   }
-  if (p.num_splits > 1)
+  if (p.num_splits > 1 && !p.tickets)
     hipLaunchKernelGGL((decode_merge_kernel<T>), dim3((unsigned)(bs * p.hq)), dim3(128), 0, st,
                        p.part_o, p.part_lse, o, p.num_splits, 128);
   return MI355_OK;
@@ -1855,8 +2001,11 @@ int mi355_decode_num_splits(int64_t bs, int hkv, int64_t max_seq_len, int max_sp
   // and every extra split costs fp32 partial traffic plus ~1 us of the merge launch.  Measured at
   // 1064 keys, head_dim 128 (microseconds, best in brackets): 8 workgroups unsplit 17.6 [6-8 splits:
   // 11.6]; 64: 19.9 [3: 14.4; 8: 19.1]; 128: 20.5 [2: 19.7; 4: 22.3]; 256: 31.7 [1; 2: 34.4].
+  // Long contexts (>= 1024 keys per split left) are split until every CU has a workgroup: 64 sequences x
+  // one kv head x 4136 keys took 35.2 / 33.4 / 33.5 us at 3 / 4 / 8 splits with the merge inside the launch.
   const int64_t wgs = bs * hkv;
   int64_t want = wgs >= 112 ? 1 : (160 + wgs - 1) / wgs;
+  if (want > 1 && wgs * want < 256 && max_seq_len / ((256 + wgs - 1) / wgs) >= 1024) want = (256 + wgs - 1) / wgs;
   const int64_t by_len = max_seq_len / 128 > 0 ? max_seq_len / 128 : 1;
   if (want > by_len) want = by_len;
   if (want > max_splits) want = max_splits;
@@ -1868,9 +2017,9 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
                            const int32_t* page_table, int mode, const int64_t* req_pool_indices,
                            const int64_t* seq_lens, const int32_t* kv_indptr,
                            int64_t table_stride, float* attn_logits, float* attn_lse,
-                           int num_splits, int64_t bs, int hq, int hkv, int head_dim,
-                           int v_head_dim, int64_t q_stride, int64_t num_slots, float sm_scale,
-                           float logit_cap, int dtype, void* stream) {
+                           uint32_t* split_tickets, int num_splits, int64_t bs, int hq, int hkv,
+                           int head_dim, int v_head_dim, int64_t q_stride, int64_t num_slots,
+                           float sm_scale, float logit_cap, int dtype, void* stream) {
   MI355_REQUIRE(q && k_buffer && v_buffer && o && page_table, MI355_ERR_INVALID,
                 "decode_attention: null pointer");
   MI355_REQUIRE(mode == 0 || mode == 1, MI355_ERR_INVALID, "decode_attention: mode must be 0|1");
@@ -1885,7 +2034,7 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
                 head_dim, v_head_dim);
   MI355_REQUIRE(q_stride >= (int64_t)hq * head_dim, MI355_ERR_INVALID,
                 "decode_attention: q_stride smaller than a row");
-  MI355_REQUIRE(num_splits >= 1 && num_splits <= 65535, MI355_ERR_INVALID,
+  MI355_REQUIRE(num_splits >= 1 && num_splits <= MI355_MAX_KV_SPLITS, MI355_ERR_INVALID,
                 "decode_attention: num_splits %d out of range", num_splits);
   MI355_REQUIRE(num_splits == 1 || (attn_logits && attn_lse), MI355_ERR_INVALID,
                 "decode_attention: split-KV needs attn_logits and attn_lse scratch");
@@ -1900,6 +2049,7 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   p.q_stride = q_stride;
   p.part_o = attn_logits;
   p.part_lse = attn_lse;
+  p.tickets = split_tickets;
   p.mode = mode;
   p.num_splits = num_splits;
   p.hq = hq;
@@ -1981,7 +2131,7 @@ int mi355_decode_attention_static(const void* q, const void* k_buffer, const voi
   // Every (sequence, head, split) cell is written by stage 1 before stage 2 reads it (an empty
   // split stores lse = -inf), so nothing in the array has to start at zero.
   return mi355_decode_attention(q, k_buffer, v_buffer, o, page_table, mode, req_pool_indices, seq_lens, kv_indptr,
-                                table_stride, base, base ? base + n_o_pad : nullptr, num_splits, bs, hq, hkv,
+                                table_stride, base, base ? base + n_o_pad : nullptr, nullptr, num_splits, bs, hq, hkv,
                                 head_dim, v_head_dim, q_stride, num_slots, sm_scale, logit_cap, dtype, stream);
 }
 
@@ -1991,9 +2141,9 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
                                      void* v_buffer, void* o, const int32_t* page_table, int mode,
                                      const int64_t* req_pool_indices, const int64_t* seq_lens,
                                      const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                                     float* attn_lse, int num_splits, int64_t bs, int hq, int hkv,
-                                     int head_dim, int64_t num_slots, float sm_scale, int dtype,
-                                     void* stream) {
+                                     float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs,
+                                     int hq, int hkv, int head_dim, int64_t num_slots, float sm_scale,
+                                     int dtype, void* stream) {
   MI355_REQUIRE(qkv_part && positions && out_cache_loc && cos_sin_cache && k_buffer && v_buffer && o && page_table,
                 MI355_ERR_INVALID, "decode_attention_fused_qkv: null pointer");
   MI355_REQUIRE(mode == 0 || mode == 1, MI355_ERR_INVALID, "decode_attention_fused_qkv: mode must be 0|1");
@@ -2011,7 +2161,7 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
                 "decode_attention_fused_qkv: needs head_dim 128 and a 16-bit dtype");
   MI355_REQUIRE(cache_dtype == MI355_F32 || cache_dtype == dtype, MI355_ERR_UNSUPPORTED,
                 "decode_attention_fused_qkv: cos_sin_cache must be fp32 or the tensor dtype");
-  MI355_REQUIRE(num_splits >= 1 && num_splits <= 65535 && (num_splits == 1 || (attn_logits && attn_lse)),
+  MI355_REQUIRE(num_splits >= 1 && num_splits <= MI355_MAX_KV_SPLITS && (num_splits == 1 || (attn_logits && attn_lse)),
                 MI355_ERR_INVALID, "decode_attention_fused_qkv: bad num_splits / missing scratch");
   MI355_REQUIRE(aligned16(qkv_part) && aligned16(k_buffer) && aligned16(v_buffer) && aligned16(part_w_scale),
                 MI355_ERR_INVALID, "decode_attention_fused_qkv: misaligned pointer");
@@ -2027,6 +2177,7 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
   p.q_stride = (int64_t)hq * head_dim;
   p.part_o = attn_logits;
   p.part_lse = attn_lse;
+  p.tickets = split_tickets;
   p.mode = mode;
   p.num_splits = num_splits;
   p.hq = hq;
@@ -2061,7 +2212,7 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                                const int32_t* page_table, int mode,
                                const int64_t* req_pool_indices, const int64_t* seq_lens,
                                const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                               float* attn_lse, int num_splits, int64_t bs, int hq,
+                               float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs, int hq,
                                int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
                                float sm_scale, float logit_cap, int dtype, void* stream) {
   MI355_REQUIRE(q && kv_buffer && o && page_table, MI355_ERR_INVALID, "decode_attention_mla: null pointer");
@@ -2076,7 +2227,7 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                     q_stride >= (int64_t)hq * D,
                 MI355_ERR_INVALID, "decode_attention_mla: bad shape hq=%d rank=%d rope=%d", hq, kv_lora_rank, rope_dim);
   MI355_REQUIRE(D <= 1024, MI355_ERR_UNSUPPORTED, "decode_attention_mla: latent row of %d > 1024", D);
-  MI355_REQUIRE(num_splits >= 1 && num_splits <= 65535 && (num_splits == 1 || (attn_logits && attn_lse)),
+  MI355_REQUIRE(num_splits >= 1 && num_splits <= MI355_MAX_KV_SPLITS && (num_splits == 1 || (attn_logits && attn_lse)),
                 MI355_ERR_INVALID, "decode_attention_mla: bad num_splits / missing scratch");
   if (bs == 0) return MI355_OK;
   DecodeParams p;
@@ -2103,13 +2254,14 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
     if ((g_decode_variant == 0 || g_decode_variant == 5) && aligned16(attn_logits)) {   // rows through the LDS ring (2 = the register kernel, 5 = the deep ring, for ablation)
       constexpr int NSB_ = 2;
       const bool deep = g_decode_variant == 5;
+      if (num_splits > 1 && num_splits <= MERGE_MAX_SPLITS && aligned16(o)) p.tickets = split_tickets;   // this kernel merges the splits itself
 #define MLR_LAUNCH(T_, CAP_)                                                                                   \
   do {                                                                                                         \
     auto kern = deep ? decode_attn_mla_ring_kernel<T_, CAP_, 4> : decode_attn_mla_ring_kernel<T_, CAP_, NSB_>; \
     const int lds_ = deep ? mlr_lds_bytes(4) : mlr_lds_bytes(NSB_);                                            \
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p);        \
-    if (num_splits > 1)                                                                                        \
+    if (num_splits > 1 && !p.tickets)                                                                          \
       hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
                          p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
   } while (0)

@@ -34,6 +34,7 @@ MLA_EXTEND_TILED_MIN_WGS = 256
 @dataclasses.dataclass
 class ForwardMetadata:
     num_kv_splits: int = 1
+    tickets: Optional[torch.Tensor] = None   # arrival counters of the in-kernel split merge (zero between launches)
     attn_logits: Optional[torch.Tensor] = None
     attn_lse: Optional[torch.Tensor] = None
     qo_indptr: Optional[torch.Tensor] = None
@@ -67,6 +68,7 @@ class Mi355AttnBackend(AttentionBackend):
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._logits = None
         self._lse = None
+        self._tickets = None
         self._retired = []      # outgrown scratch: captured graphs may still point into it
         self._dummy_idx = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.graph_num_splits = {}
@@ -81,6 +83,11 @@ class Mi355AttnBackend(AttentionBackend):
                 self._retired.append((self._logits, self._lse))
             self._logits = torch.empty(need * self.v_head_dim, dtype=torch.float32, device=self.device)
             self._lse = torch.empty(need, dtype=torch.float32, device=self.device)
+        if self._tickets is None or self._tickets.numel() < bs * self.num_head:
+            # one counter per (sequence, head); the kernels hand them back zeroed.  An outgrown array
+            # stays alive: captured graphs may still point into it.
+            self._retired.append(self._tickets)
+            self._tickets = torch.zeros(max(bs * self.num_head, 1024), dtype=torch.int32, device=self.device)
         return self._logits, self._lse
 
     def _window(self, lens: torch.Tensor, lens_cpu, req_pool_indices, bs: int, indptr=None, indices=None):
@@ -118,7 +125,8 @@ class Mi355AttnBackend(AttentionBackend):
             splits = self._plan_splits(bs, max_len)
             wsplits = self._plan_splits(bs, min(max_len, self.sliding_window_size + 1)) if self.sliding_window_size else 1
             logits, lse = self._scratch(bs, max(splits, wsplits)) if max(splits, wsplits) > 1 else (None, None)
-            md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits)
+            md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits,
+                                 tickets=self._tickets if logits is not None else None)
             if self.sliding_window_size:
                 cpu = forward_batch.seq_lens_cpu.tolist() if forward_batch.seq_lens_cpu is not None else None
                 md.window_kv_indptr, md.window_kv_indices = self._window(
@@ -161,7 +169,8 @@ class Mi355AttnBackend(AttentionBackend):
         self.graph_num_splits[bs] = splits
         wsplits = self._plan_splits(bs, self.sliding_window_size + 1) if self.sliding_window_size else 1
         logits, lse = self._scratch(bs, max(splits, wsplits)) if max(splits, wsplits) > 1 else (None, None)
-        md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits)
+        md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits,
+                             tickets=self._tickets if logits is not None else None)
         if self.sliding_window_size:
             md.window_kv_indptr, md.window_kv_indices = self._window(
                 seq_lens[:bs], None, req_pool_indices[:bs], bs, self.graph_window_indptr, self.graph_window_indices)
@@ -194,14 +203,15 @@ class Mi355AttnBackend(AttentionBackend):
                 o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
                 forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
                 forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, pool.kv_lora_rank,
-                layer.scaling, layer.logit_cap)
+                layer.scaling, layer.logit_cap, tickets=md.tickets)
             return o
         if self._windowed(layer):
             ops.decode_attention_fwd(
                 q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
                 pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id),
                 o.view(-1, layer.tp_q_head_num, layer.v_head_dim), md.window_kv_indptr, md.window_kv_indices,
-                md.attn_logits, md.attn_lse, md.window_num_kv_splits, MAX_KV_SPLITS, layer.scaling, layer.logit_cap)
+                md.attn_logits, md.attn_lse, md.window_num_kv_splits, MAX_KV_SPLITS, layer.scaling, layer.logit_cap,
+                tickets=md.tickets)
             return o
         ops.decode_attention_paged(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
@@ -209,7 +219,7 @@ class Mi355AttnBackend(AttentionBackend):
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
             forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits,
-            layer.scaling, layer.logit_cap)
+            layer.scaling, layer.logit_cap, tickets=md.tickets)
         return o
 
     def _windowed(self, layer) -> bool:
@@ -238,7 +248,7 @@ class Mi355AttnBackend(AttentionBackend):
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
             forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, layer.scaling,
-            part_x_scale=part_x_scale, part_w_scale=part_w_scale)
+            part_x_scale=part_x_scale, part_w_scale=part_w_scale, tickets=md.tickets)
         return o
 
     @staticmethod

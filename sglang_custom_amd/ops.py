@@ -286,15 +286,24 @@ def alloc_decode_pages(seq_lens: torch.Tensor, last_loc: torch.Tensor, free_page
 
 
 # ---------------------------------------------------------------------------------- attention
+def _tickets(t, need: int):
+    """Device pointer of the split-merge arrival counters (None: the splits are merged by a second launch)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() >= need
+    return t.data_ptr()
+
+
 def decode_num_splits(bs: int, hkv: int, max_seq_len: int, max_splits: int) -> int:
     return _lib_().mi355_decode_num_splits(bs, hkv, max_seq_len, max_splits)
 
 
 def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
                          num_kv_splits: int, max_kv_splits: int, sm_scale: float,
-                         logit_cap: float = 0.0) -> None:
+                         logit_cap: float = 0.0, tickets=None) -> None:
     """decode_attention_fwd(...) of the Triton backend (triton_ops/decode_attention.py:677-728),
-    kv_indptr/kv_indices addressing.  num_kv_splits is one int for the whole batch."""
+    kv_indptr/kv_indices addressing.  num_kv_splits is one int for the whole batch.
+    tickets: see decode_attention_paged."""
     _gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices)
     B, Hq, D = q.shape
     Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
@@ -308,15 +317,17 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     check(_lib_().mi355_decode_attention(
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         kv_indices.data_ptr(), 1, None, None, kv_indptr.data_ptr(), 0, _p(attn_logits),
-        _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), k_buffer.shape[0], float(sm_scale),
+        _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), k_buffer.shape[0], float(sm_scale),
         float(logit_cap), _dt(q), _stream(q)), "decode_attention")
 
 
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
                            attn_logits, attn_lse, num_kv_splits: int, sm_scale: float,
-                           logit_cap: float = 0.0) -> None:
+                           logit_cap: float = 0.0, tickets=None) -> None:
     """decode_attention_cpu-style addressing (sgl-kernel/csrc/cpu/decode.cpp:1375): the kernel
-    reads req_to_token[req_pool_indices[b], :seq_lens[b]] directly, no kv_indices gather."""
+    reads req_to_token[req_pool_indices[b], :seq_lens[b]] directly, no kv_indices gather.
+    tickets (optional): >= B * Hq int32 arrival counters, zero between calls (the kernel leaves them
+    zero); with them the KV splits are merged inside the attention launch instead of by a second one."""
     _gpu(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
     B, Hq, D = q.shape
     Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
@@ -327,7 +338,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
     check(_lib_().mi355_decode_attention(
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
-        req_to_token.stride(0), _p(attn_logits), _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, Dv,
+        req_to_token.stride(0), _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, Hkv, D, Dv,
         q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer), _stream(q)),
         "decode_attention")
 
@@ -354,7 +365,7 @@ def decode_attention_paged_static(q, k_buffer, v_buffer, o, req_to_token, req_po
 
 def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache, k_buffer, v_buffer, o, req_to_token,
                                req_pool_indices, seq_lens, attn_logits, attn_lse, num_kv_splits: int,
-                               sm_scale: float, part_x_scale=None, part_w_scale=None) -> None:
+                               sm_scale: float, part_x_scale=None, part_w_scale=None, tickets=None) -> None:
     """Decode attention straight from the qkv GEMM's split-K partials [splits, B, (Hq + 2 Hkv) * D]:
     sums them, applies neox RoPE to q and the new k, writes the new k / v rows into cache slot
     out_cache_loc[b] (= req_to_token[req_pool_indices[b], seq_lens[b] - 1] for real rows) and attends.  o: [B, Hq, D]."""
@@ -379,13 +390,13 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
         out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
         _dt(cos_sin_cache), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0), _p(attn_logits),
-        _p(attn_lse), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _kvdt(o, k_buffer), _stream(o)),
+        _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _kvdt(o, k_buffer), _stream(o)),
         "decode_attention_fused_qkv")
 
 
 def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
                          attn_lse, num_kv_splits: int, kv_lora_rank: int, sm_scale: float,
-                         logit_cap: float = 0.0) -> None:
+                         logit_cap: float = 0.0, tickets=None) -> None:
     """MQA over the compressed MLA cache (deepseek_v2.py:866-875): kv_buffer [slots, 1, rank + rope],
     q [B, H, rank + rope], o [B, H, rank]; the value is kv_buffer[..., :rank]."""
     _gpu(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens)
@@ -397,7 +408,7 @@ def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_le
     check(_lib_().mi355_decode_attention_mla(
         q.data_ptr(), kv_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0),
-        _p(attn_logits), _p(attn_lse), num_kv_splits, B, Hq, kv_lora_rank, D - kv_lora_rank,
+        _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, kv_lora_rank, D - kv_lora_rank,
         q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap), _dt(q), _stream(q)),
         "decode_attention_mla")
 

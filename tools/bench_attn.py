@@ -49,10 +49,15 @@ qg = q.float().view(bs, hkv, hq // hkv, D)
 s = torch.einsum('bhgd,bkhd->bhgk', qg, K) * D ** -0.5
 ref = torch.einsum('bhgk,bkhd->bhgd', s.softmax(-1), V).reshape(bs, hq, D)
 nbytes = bs * ctx * hkv * D * 2 * kb[0].element_size()
+# TICKETS=1: the KV splits are merged inside the attention launch (arrival counters) instead of by a second launch
+tk = torch.zeros(bs * hq, dtype=torch.int32, device='cuda') if os.environ.get('TICKETS') else None
 for dbg in ((0,) if os.environ.get('ONLY0') else (3, 0)):
     lib.mi355_debug_set(6, dbg)   # 3 = K rows straight into fragments (ablation), 0 = whole K rows staged through LDS (product)
     for ns in [int(x) for x in os.environ.get('SPLITS', '1,2,3,4').split(',')]:
-        ops.decode_attention_paged(q, kb[0], vb[0], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5)
+        o.zero_()
+        ops.decode_attention_paged(q, kb[0], vb[0], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5, tickets=tk)
         err = (o.float() - ref).abs().max().item()
-        t = timeit(lambda i: ops.decode_attention_paged(q, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5))
-        print(f"dbg={dbg} splits={ns}: {t:6.1f} us  {nbytes / t / 1e6:5.2f} TB/s  err={err:.4f}", flush=True)
+        t = timeit(lambda i: ops.decode_attention_paged(q, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5, tickets=tk))
+        left = int(tk.abs().sum().item()) if tk is not None else 0
+        print(f"dbg={dbg} splits={ns}{' in-kernel merge' if tk is not None else ''}: {t:6.1f} us  {nbytes / t / 1e6:5.2f} TB/s  err={err:.4f}"
+              + (f"  tickets left {left}" if left else ""), flush=True)

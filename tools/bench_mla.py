@@ -35,12 +35,15 @@ K = kv[0][r2t[:nb].long(), 0].float()
 s = torch.einsum('bhd,bkd->bhk', q[:nb].float(), K) * D ** -0.5
 ref = torch.einsum('bhk,bkd->bhd', s.softmax(-1), K[..., :rank])
 nbytes = bs * ctx * D * 2
+# TICKETS=1: the KV splits are merged inside the attention launch instead of by a second launch
+tk = torch.zeros(bs * H, dtype=torch.int32, device='cuda') if os.environ.get('TICKETS') else None
 for dbg in ((0,) if os.environ.get("MLA_AB") else (1, 2, 5, 0)):
     lib.mi355_debug_set(6, dbg)   # 1 = generic wave-per-head kernel, 2 = MFMA kernel with rows in registers, 0 = rows through the LDS ring (product)
     for ns in (1, 2, 4, 8):
         if dbg == 1 and ns not in (1, 4): continue
         if len(sys.argv) > 4 and ns != int(sys.argv[4]): continue
-        ops.decode_attention_mla(q, kv[0], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5)
+        o.zero_()
+        ops.decode_attention_mla(q, kv[0], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5, tickets=tk)
         err = (o[:nb].float() - ref).abs().max().item()
-        t = timeit(lambda i: ops.decode_attention_mla(q, kv[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5))
-        print(f"variant={dbg} splits={ns}: {t:7.1f} us  {nbytes / t / 1e6:5.2f} TB/s  err={err:.4f}", flush=True)
+        t = timeit(lambda i: ops.decode_attention_mla(q, kv[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5, tickets=tk))
+        print(f"variant={dbg} splits={ns}{' in-kernel merge' if tk is not None and dbg in (0, 5) else ''}: {t:7.1f} us  {nbytes / t / 1e6:5.2f} TB/s  err={err:.4f}", flush=True)
