@@ -127,6 +127,7 @@ class Mi355AttnBackend(AttentionBackend):
             logits, lse = self._scratch(bs, max(splits, wsplits)) if max(splits, wsplits) > 1 else (None, None)
             md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits,
                                  tickets=self._tickets if logits is not None else None)
+            self._reset_tickets(max(splits, wsplits))
             if self.sliding_window_size:
                 cpu = forward_batch.seq_lens_cpu.tolist() if forward_batch.seq_lens_cpu is not None else None
                 md.window_kv_indptr, md.window_kv_indices = self._window(
@@ -182,6 +183,14 @@ class Mi355AttnBackend(AttentionBackend):
         # window gather of sliding-window models is refreshed (into the buffers the graph captured)
         if self.sliding_window_size:
             self._window(seq_lens[:bs], None, req_pool_indices[:bs], bs, self.graph_window_indptr, self.graph_window_indices)
+        self._reset_tickets(max(self.graph_num_splits.get(bs, 1), 2 if self.sliding_window_size else 1))
+
+    def _reset_tickets(self, splits: int):
+        """The kernels hand the split-merge counters back zeroed; a launch that died half-way (a failed
+        step, an aborted capture) would leave some raised and every later merge of that cell would never
+        fire.  One small fill per forward makes the next step start clean whatever happened before."""
+        if splits > 1 and self._tickets is not None:
+            self._tickets.zero_()
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
