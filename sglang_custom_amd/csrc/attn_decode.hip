@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   };
   auto load_kv = [&](const int32_t (&slot)[U], Vec<T, VE> (&kv)[U], Vec<T, VE> (&vv)[U]) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) kv[u] = ldvec<T, VE>(kbase + (int64_t)slot[u] * row_stride);
+    for (int u = 0; u < U; ++u) kv[u] = ldvec_nt<T, VE>(kbase + (int64_t)slot[u] * row_stride);
 #pragma unroll
-    for (int u = 0; u < U; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)slot[u] * row_stride);
+    for (int u = 0; u < U; ++u) vv[u] = ldvec_nt<T, VE>(vbase + (int64_t)slot[u] * row_stride);
   };
   auto compute = [&](int it, const Vec<T, VE> (&kv)[U], const Vec<T, VE> (&vv)[U]) {
     float s[U][G];
@@ -842,19 +842,19 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
     const KVT* krow = kbase + (int64_t)sk * row_stride;
     if constexpr (KV8 && KROW) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) kf[u] = *reinterpret_cast<const uint2*>(kbase + (int64_t)sv[u] * row_stride);
+      for (int u = 0; u < 4; ++u) kf[u] = ld8_nt(kbase + (int64_t)sv[u] * row_stride);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const uint2*>(vbase + (int64_t)sv[u] * row_stride);
+      for (int u = 0; u < 4; ++u) vv[u] = ld8_nt(vbase + (int64_t)sv[u] * row_stride);
     } else if constexpr (KV8) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const uint2*>(krow + 32 * s);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const uint2*>(vbase + (int64_t)sv[u] * row_stride);
+      for (int u = 0; u < 4; ++u) vv[u] = ld8_nt(vbase + (int64_t)sv[u] * row_stride);
     } else if constexpr (KROW) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) kf[u] = ldvec<T, VE>(kbase + (int64_t)sv[u] * row_stride);
+      for (int u = 0; u < 4; ++u) kf[u] = ldvec_nt<T, VE>(kbase + (int64_t)sv[u] * row_stride);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) vv[u] = ldvec<T, VE>(vbase + (int64_t)sv[u] * row_stride);
+      for (int u = 0; u < 4; ++u) vv[u] = ldvec_nt<T, VE>(vbase + (int64_t)sv[u] * row_stride);
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
@@ -1380,21 +1380,39 @@ __device__ __forceinline__ unsigned lds_byte_address(const void* p) {
 // One wave-wide load of 16 bytes per active lane to LDS at `lds_base` (wave-uniform) + 16 * lane.
 // M0 carries the LDS base; it is saved and restored inside the statement.
 //   _v: per-lane 64-bit source address; _s: wave-uniform 64-bit base + per-lane 32-bit byte offset.
+// NT: the non-temporal cache policy, for rows that are read once per step (decode); rows that several
+// workgroups share within a launch (extend) keep the default policy.
+template <bool NT = false>
 __device__ __forceinline__ void load_to_lds_16_v(const void* src, unsigned lds_base) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_base)
-      : "memory");
+  if constexpr (NT)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
 }
+template <bool NT = false>
 __device__ __forceinline__ void load_to_lds_16_s(uint64_t base, unsigned lane_off, unsigned lds_base) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(lane_off), "s"(base), "s"(lds_base)
-      : "memory");
+  if constexpr (NT)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_base)
+        : "memory");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_base)
+        : "memory");
 }
 
 template <typename T, bool CAP, int NSB>
@@ -1440,14 +1458,14 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
   const int tm0 = -(int)(trow == 0), tm1 = -(int)(trow == 1), tm2 = -(int)(trow == 2), tm3 = -(int)(trow == 3);
   auto issue_tile = [&](int buf, int32_t s0, int32_t s1, int32_t s2, int32_t s3) {
     const unsigned base = ring + (unsigned)buf * MLR_TILE + (unsigned)(4 * wave) * MLR_ROWB;
-    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s0 * row_bytes, lane16, base);
-    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s1 * row_bytes, lane16, base + MLR_ROWB);
-    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s2 * row_bytes, lane16, base + 2 * MLR_ROWB);
-    load_to_lds_16_s(kv_base + (uint64_t)(uint32_t)s3 * row_bytes, lane16, base + 3 * MLR_ROWB);
+    load_to_lds_16_s<true>(kv_base + (uint64_t)(uint32_t)s0 * row_bytes, lane16, base);
+    load_to_lds_16_s<true>(kv_base + (uint64_t)(uint32_t)s1 * row_bytes, lane16, base + MLR_ROWB);
+    load_to_lds_16_s<true>(kv_base + (uint64_t)(uint32_t)s2 * row_bytes, lane16, base + 2 * MLR_ROWB);
+    load_to_lds_16_s<true>(kv_base + (uint64_t)(uint32_t)s3 * row_bytes, lane16, base + 3 * MLR_ROWB);
     // row trow's slot by masks (a chain of selects would be turned into an indexed array in scratch memory)
     const uint32_t ts = (uint32_t)((s0 & tm0) | (s1 & tm1) | (s2 & tm2) | (s3 & tm3));
     if (lane < 32)
-      load_to_lds_16_v(reinterpret_cast<const char*>(kvbuf) + (uint64_t)ts * row_bytes + tsw,
+      load_to_lds_16_v<true>(reinterpret_cast<const char*>(kvbuf) + (uint64_t)ts * row_bytes + tsw,
                        ring + (unsigned)buf * MLR_TILE + MLR_TAIL + (unsigned)(4 * wave) * 128);
   };
   auto issue_step = [&](int step, const Slots& sl) {

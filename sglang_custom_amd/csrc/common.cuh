@@ -39,6 +39,18 @@ template <typename T, int N> struct alignas(sizeof(T) * N) Vec {
 template <typename T, int N> __device__ __forceinline__ Vec<T, N> ldvec(const T* p) {
   return *reinterpret_cast<const Vec<T, N>*>(p);
 }
+// The same with the non-temporal cache policy: for bytes that are read once and not again before they
+// would have been evicted anyway (a step's sweep over the KV cache).
+template <typename T, int N> __device__ __forceinline__ Vec<T, N> ldvec_nt(const T* p) {
+  static_assert(sizeof(T) * N == 16, "16-byte vectors only");
+  typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(Vec<T, N>, __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p)));
+}
+__device__ __forceinline__ uint2 ld8_nt(const void* p) {
+  typedef unsigned nt_u32x2 __attribute__((ext_vector_type(2)));
+  const nt_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x2*>(p));
+  return uint2{v.x, v.y};
+}
 template <typename T, int N> __device__ __forceinline__ void stvec(T* p, const Vec<T, N>& x) {
   *reinterpret_cast<Vec<T, N>*>(p) = x;
 }
