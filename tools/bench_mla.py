@@ -39,7 +39,7 @@ nbytes = bs * ctx * D * 2
 tk = torch.zeros(bs * H, dtype=torch.int32, device='cuda') if os.environ.get('TICKETS') else None
 for dbg in ((0,) if os.environ.get("MLA_AB") else (1, 2, 5, 0)):
     lib.mi355_debug_set(6, dbg)   # 1 = generic wave-per-head kernel, 2 = MFMA kernel with rows in registers, 0 = rows through the LDS ring (product)
-    for ns in (1, 2, 4, 8):
+    for ns in [int(x) for x in os.environ.get('SPLITS', '1,2,4,8').split(',')]:
         if dbg == 1 and ns not in (1, 4): continue
         if len(sys.argv) > 4 and ns != int(sys.argv[4]): continue
         o.zero_()
