@@ -108,9 +108,10 @@ class Mi355AttnBackend(AttentionBackend):
     def _plan_splits(self, bs: int, max_seq_len: int) -> int:
         if self.is_mla:
             # the MLA kernel keeps two workgroups per CU busy and streams 1152-byte rows: it is fastest at
-            # 512 workgroups (64 sequences x 16 heads x 4096 keys: 255 / 141 / 85 / 76 us at 1 / 2 / 4 / 8 splits)
+            # 512 workgroups (64 sequences x 16 heads x 4096 keys: 190 / 107 / 75 / 68 us at 1 / 2 / 4 / 8 splits,
+            # 91 at 10) with at least 256 keys per split (64 x 1024 keys: 31.6 us at 4 splits, 34.5 at 8)
             wgs = max(1, bs * self.num_kv_head)
-            return max(1, min(MAX_KV_SPLITS, (512 + wgs - 1) // wgs, max(1, max_seq_len // 128)))
+            return max(1, min(MAX_KV_SPLITS, (512 + wgs - 1) // wgs, max(1, max_seq_len // 256)))
         return get_ops().decode_num_splits(bs, self.num_kv_head, max_seq_len, MAX_KV_SPLITS)
 
     # ---- eager ----
