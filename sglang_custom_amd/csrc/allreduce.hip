@@ -276,16 +276,15 @@ __global__ __launch_bounds__(AR_THREADS) void ar_all_gather_kernel(ArPeers p, co
 // parallel decoder layer: x (this rank's partial sums) -> sum over ranks, rounded to T exactly as
 // the plain all-reduce rounds it -> + residual (kept in fp32 for the norm, stored rounded) ->
 // RMSNorm * weight.  The arithmetic after the sum repeats the fused add+RMSNorm kernel's statement
-// by statement (256 lanes, same per-lane accumulation and block reduction), so the result equals
+// by statement (same lanes per row, same per-lane accumulation and block reduction), so the result equals
 // all-reduce followed by that kernel bit for bit.  A workgroup owns whole rows: b, b + grid, ...
 // replaces: RMSNorm.forward_with_allreduce_fusion (layers/layernorm.py:166-190) and the deferred
 //           all-reduce of LayerCommunicator.prepare_mlp / prepare_attn (layers/communicator.py).
-template <typename T, int NR, int CHUNKS>
-__global__ __launch_bounds__(256) void ar_fused_add_rmsnorm_kernel(ArPeers p, T* x, T* residual, const T* __restrict__ w,
+template <typename T, int NR, int CHUNKS, int BT>
+__global__ __launch_bounds__(BT) void ar_fused_add_rmsnorm_kernel(ArPeers p, T* x, T* residual, const T* __restrict__ w,
                                                                    int rows, int64_t hidden, float eps, int rank,
                                                                    uint32_t* status, long long timeout) {
   constexpr int VE = 16 / sizeof(T);
-  constexpr int BT = 256;
   __shared__ float red[16];
   const int nvec = (int)(hidden / VE);
   ArVec* mine = reinterpret_cast<ArVec*>(ar_staging(p.base[rank]));
@@ -391,13 +390,14 @@ static int ar_fused_norm_launch(const ArComm* c, T* x, T* residual, const T* w, 
   const int nvec = (int)(hidden / (16 / sizeof(T)));
   const int chunks = (nvec + 255) / 256;
   const int grid = std::min(AR_MAX_BLOCKS, rows);
-#define AR_NORM(C) \
-  ar_fused_add_rmsnorm_kernel<T, NR, C><<<grid, 256, 0, st>>>(c->peers, x, residual, w, rows, hidden, eps, c->rank, c->status, \
-                                                              c->timeout_ticks)
-  if (chunks <= 1) AR_NORM(1);
-  else if (chunks <= 2) AR_NORM(2);
-  else if (chunks <= 4) AR_NORM(4);
-  else AR_NORM(8);
+  // lanes per row and chunks per lane exactly as the fused add+RMSNorm launch picks them (csrc/elementwise.hip)
+#define AR_NORM(C, BT_) \
+  ar_fused_add_rmsnorm_kernel<T, NR, C, BT_><<<grid, BT_, 0, st>>>(c->peers, x, residual, w, rows, hidden, eps, c->rank, c->status, \
+                                                                   c->timeout_ticks)
+  if (chunks <= 1) AR_NORM(1, 256);
+  else if (chunks <= 2) AR_NORM(1, 512);
+  else if (chunks <= 4) AR_NORM(2, 512);
+  else AR_NORM(4, 512);
 #undef AR_NORM
   return MI355_OK;
 }

@@ -238,12 +238,13 @@ static int launch_rmsnorm(T* out, T* x, T* residual, const T* w, int64_t rows, i
 #define LAUNCH(C, BT_)                                                                                  \
   hipLaunchKernelGGL((rmsnorm_vec_kernel<T, ADD, C, BT_>), grid, dim3(BT_), 0, st, out, x, residual, w, \
                      hidden, x_stride, out_stride, eps, pf, pf_wgs, part, nsplit, part_xs, part_ws, q_out, q_scale)
-    // (512 lanes per row were measured for decode-sized inputs: 0.5 % on the step, and a different
-    // reduction order than the 256-lane launch -- not worth two result variants)
+    // Rows of more than 256 vectors get 512 lanes (half the chunks per lane: all loads of a row, split-K
+    // partials included, in fewer memory round trips).  The lane count is a function of the row length
+    // alone, so a row's bits never depend on the batch it is normalised in.
     if (chunks <= 1) LAUNCH(1, 256);
-    else if (chunks <= 2) LAUNCH(2, 256);
-    else if (chunks <= 4) LAUNCH(4, 256);
-    else LAUNCH(8, 256);
+    else if (chunks <= 2) LAUNCH(1, 512);
+    else if (chunks <= 4) LAUNCH(2, 512);
+    else LAUNCH(4, 512);
 #undef LAUNCH
   } else if (ADD) {
     hipLaunchKernelGGL((fused_add_rmsnorm_generic_kernel<T>), grid, block, 0, st, x, residual, w,
