@@ -49,8 +49,6 @@ class ModelRunner:
             from ..models.deepseek_v2 import DeepseekV2ForCausalLM
 
             model_cls = DeepseekV2ForCausalLM
-            if tp_size != 1:
-                raise NotImplementedError("the DeepSeek stack runs at tensor-parallel size 1")
         self.model = model_cls(model_config, dtype=self.dtype, device=self.device,
                                quant_method_factory=quant_factory)
         if weights is not None:

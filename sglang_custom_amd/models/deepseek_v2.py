@@ -26,7 +26,8 @@ from torch import nn
 
 from ..layers.activation import SiluAndMul
 from ..layers.layernorm import RMSNorm
-from ..layers.linear import ReplicatedLinear
+from ..distributed.parallel_state import get_tensor_model_parallel_world_size
+from ..layers.linear import MergedColumnParallelLinear, ReplicatedLinear, RowParallelLinear
 from ..layers.logits_processor import LogitsProcessor
 from ..layers.radix_attention import RadixAttention
 from ..layers.rotary_embedding import get_rope, yarn_get_mscale
@@ -40,7 +41,14 @@ class DeepseekV2AttentionMLA(nn.Module):
                  rope_scaling: Optional[dict] = None):
         super().__init__()
         self.hidden_size = hidden_size
-        self.num_local_heads = num_heads
+        # Tensor parallelism as the reference shards this module (:781-840): the heads are divided over the
+        # ranks -- q_b_proj / q_proj and kv_b_proj column-parallel, o_proj row-parallel with a sum over ranks --
+        # while the low-rank "a" projections and the latent cache are replicated (one latent row per token
+        # serves every head).
+        tp = get_tensor_model_parallel_world_size()
+        assert num_heads % tp == 0, f"{num_heads} heads over {tp} ranks"
+        self.num_heads = num_heads
+        self.num_local_heads = num_heads // tp
         self.qk_nope_head_dim, self.qk_rope_head_dim = qk_nope_head_dim, qk_rope_head_dim
         self.qk_head_dim = qk_nope_head_dim + qk_rope_head_dim
         self.v_head_dim = v_head_dim
@@ -51,13 +59,13 @@ class DeepseekV2AttentionMLA(nn.Module):
             self.fused_qkv_a_proj_with_mqa = ReplicatedLinear(
                 hidden_size, q_lora_rank + kv_lora_rank + qk_rope_head_dim, dtype, device)
             self.q_a_layernorm = RMSNorm(q_lora_rank, eps=rms_norm_eps)
-            self.q_b_proj = ReplicatedLinear(q_lora_rank, num_heads * self.qk_head_dim, dtype, device)
+            self.q_b_proj = MergedColumnParallelLinear(q_lora_rank, [num_heads * self.qk_head_dim], dtype, device)
         else:
-            self.q_proj = ReplicatedLinear(hidden_size, num_heads * self.qk_head_dim, dtype, device)
+            self.q_proj = MergedColumnParallelLinear(hidden_size, [num_heads * self.qk_head_dim], dtype, device)
             self.kv_a_proj_with_mqa = ReplicatedLinear(hidden_size, kv_lora_rank + qk_rope_head_dim, dtype, device)
         self.kv_a_layernorm = RMSNorm(kv_lora_rank, eps=rms_norm_eps)
-        self.kv_b_proj = ReplicatedLinear(kv_lora_rank, num_heads * (qk_nope_head_dim + v_head_dim), dtype, device)
-        self.o_proj = ReplicatedLinear(num_heads * v_head_dim, hidden_size, dtype, device)
+        self.kv_b_proj = MergedColumnParallelLinear(kv_lora_rank, [num_heads * (qk_nope_head_dim + v_head_dim)], dtype, device)
+        self.o_proj = RowParallelLinear(num_heads * v_head_dim, hidden_size, dtype, device)
         if rope_scaling:
             rope_scaling = dict(rope_scaling, rope_type="deepseek_yarn")
             mscale = yarn_get_mscale(rope_scaling["factor"], float(rope_scaling.get("mscale_all_dim", False)))
@@ -65,9 +73,9 @@ class DeepseekV2AttentionMLA(nn.Module):
         self.rotary_emb = get_rope(qk_rope_head_dim, qk_rope_head_dim, max_position_embeddings, rope_theta,
                                    is_neox_style=False, rope_scaling=rope_scaling, dtype=dtype)
         # the two RadixAttention views of one layer (:866-886)
-        self.attn_mqa = RadixAttention(num_heads, kv_lora_rank + qk_rope_head_dim, self.scaling, num_kv_heads=1,
+        self.attn_mqa = RadixAttention(self.num_local_heads, kv_lora_rank + qk_rope_head_dim, self.scaling, num_kv_heads=1,
                                        layer_id=layer_id, v_head_dim=kv_lora_rank)
-        self.attn_mha = RadixAttention(num_heads, self.qk_head_dim, self.scaling, num_kv_heads=num_heads,
+        self.attn_mha = RadixAttention(self.num_local_heads, self.qk_head_dim, self.scaling, num_kv_heads=self.num_local_heads,
                                        layer_id=layer_id, v_head_dim=v_head_dim)
         self.w_kc = self.w_vc = None
         for m in self.modules():
@@ -80,6 +88,10 @@ class DeepseekV2AttentionMLA(nn.Module):
         The absorbed (decode) path is built from it by post_load_weights(); the multi-head prefill, which
         would run kv_b_proj as an fp8 linear, is outside this module's fp8 support."""
         assert weight.dtype == torch.float8_e4m3fn and weight_scale.shape == (weight.shape[0], 1)
+        if weight.shape[0] != self.kv_b_proj.weight.shape[0]:   # the whole checkpoint tensor: keep this rank's heads
+            per, r = self.kv_b_proj.weight.shape[0], self.kv_b_proj.tp_rank
+            assert weight.shape[0] == per * self.kv_b_proj.tp_size
+            weight, weight_scale = weight[r * per:(r + 1) * per], weight_scale[r * per:(r + 1) * per]
         self._kv_b_fp8 = (weight, weight_scale.float())
 
     def post_load_weights(self) -> None:
@@ -166,12 +178,12 @@ class DeepseekV2AttentionMLA(nn.Module):
 
 # =============================== the decoder stack (dense layers) ===================================
 class DeepseekV2MLP(nn.Module):
-    """gate_up -> SiLU-and-mul -> down (:167-219)."""
+    """gate_up -> SiLU-and-mul -> down (:167-219); column- / row-parallel over the ranks (:182-198)."""
 
     def __init__(self, hidden_size: int, intermediate_size: int, dtype, device):
         super().__init__()
-        self.gate_up_proj = ReplicatedLinear(hidden_size, 2 * intermediate_size, dtype, device)
-        self.down_proj = ReplicatedLinear(intermediate_size, hidden_size, dtype, device)
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size, intermediate_size], dtype, device)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, dtype, device)
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
@@ -257,8 +269,8 @@ class DeepseekV2ForCausalLM(nn.Module):
         def put(param, value):
             param.data.copy_(value.to(dtype=param.dtype), non_blocking=True)
 
-        put(self.model.embed_tokens.weight, weights["model.embed_tokens.weight"])
-        put(self.lm_head.weight, weights["lm_head.weight"])
+        put(self.model.embed_tokens.weight, self.model.embed_tokens.shard_from_checkpoint(weights["model.embed_tokens.weight"]))
+        put(self.lm_head.weight, self.lm_head.shard_from_checkpoint(weights["lm_head.weight"]))
         put(self.model.norm.weight, weights["model.norm.weight"])
         for i, layer in enumerate(self.model.layers):
             p = f"model.layers.{i}."
@@ -269,16 +281,16 @@ class DeepseekV2ForCausalLM(nn.Module):
                 put(at.fused_qkv_a_proj_with_mqa.weight, torch.cat(
                     [weights[p + "self_attn.q_a_proj.weight"], weights[p + "self_attn.kv_a_proj_with_mqa.weight"]], 0))
                 put(at.q_a_layernorm.weight, weights[p + "self_attn.q_a_layernorm.weight"])
-                put(at.q_b_proj.weight, weights[p + "self_attn.q_b_proj.weight"])
+                put(at.q_b_proj.weight, at.q_b_proj.shard_from_checkpoint(weights[p + "self_attn.q_b_proj.weight"]))
             else:
-                put(at.q_proj.weight, weights[p + "self_attn.q_proj.weight"])
+                put(at.q_proj.weight, at.q_proj.shard_from_checkpoint(weights[p + "self_attn.q_proj.weight"]))
                 put(at.kv_a_proj_with_mqa.weight, weights[p + "self_attn.kv_a_proj_with_mqa.weight"])
             put(at.kv_a_layernorm.weight, weights[p + "self_attn.kv_a_layernorm.weight"])
-            put(at.kv_b_proj.weight, weights[p + "self_attn.kv_b_proj.weight"])
-            put(at.o_proj.weight, weights[p + "self_attn.o_proj.weight"])
-            put(layer.mlp.gate_up_proj.weight, torch.cat(
-                [weights[p + "mlp.gate_proj.weight"], weights[p + "mlp.up_proj.weight"]], 0))
-            put(layer.mlp.down_proj.weight, weights[p + "mlp.down_proj.weight"])
+            put(at.kv_b_proj.weight, at.kv_b_proj.shard_from_checkpoint(weights[p + "self_attn.kv_b_proj.weight"]))
+            put(at.o_proj.weight, at.o_proj.shard_from_checkpoint(weights[p + "self_attn.o_proj.weight"]))
+            put(layer.mlp.gate_up_proj.weight, layer.mlp.gate_up_proj.shard_from_checkpoint(
+                weights[p + "mlp.gate_proj.weight"], weights[p + "mlp.up_proj.weight"]))
+            put(layer.mlp.down_proj.weight, layer.mlp.down_proj.shard_from_checkpoint(weights[p + "mlp.down_proj.weight"]))
         self.post_load_weights()
 
     def post_load_weights(self) -> None:

@@ -228,6 +228,89 @@ def test_tensor_parallel_two_ranks_on_one_gpu(preset, dtn):
     assert np.array_equal(results[0][1], results[1][1])
 
 
+def _tp_rank_main_deepseek(rank, world, port, queue, preset, dtn):
+    """One tensor-parallel rank of the tiny DeepSeek (MLA) stack on cuda:0: this rank's 8 of the 16 heads on the
+    HIP kernels (multi-head prefill, absorbed decode over the replicated latent cache, eager and from a graph),
+    o_proj / down_proj partial sums through the one-launch all-reduce."""
+    try:
+        import torch
+
+        import cases
+        from oracle.deepseek_ref import OracleDeepseek
+        from sglang_custom_amd import bench_one_batch as bob
+        from sglang_custom_amd.configs.model_config import ModelConfig
+        from sglang_custom_amd.distributed import parallel_state
+        from sglang_custom_amd.managers.schedule_batch import Req
+        from sglang_custom_amd.mem_cache.memory_pool import MLATokenToKVPool
+        from sglang_custom_amd.model_executor.model_runner import ModelRunner
+        from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+        from sglang_custom_amd.server_args import ServerArgs
+
+        torch.cuda.set_device(0)
+        dt = getattr(torch, dtn)
+        cfg = hf_config_dict(preset, dtn)
+        w = make_synthetic_llama_weights(cfg, seed=1234, dtype=dt)
+        prompts = cases.e2e_prompts(cfg["vocab_size"], (5, 33, 70))
+        sa = ServerArgs(dtype=dtn, max_total_tokens=1024, max_running_requests=8, cuda_graph_bs=[4],
+                        dist_backend="gloo", dist_init_method=f"tcp://127.0.0.1:{port}",
+                        disable_custom_all_reduce=False)
+        mr = ModelRunner(ModelConfig(cfg, dtype=dtn), sa, tp_rank=rank, tp_size=world,
+                         weights={k: v.cuda() for k, v in w.items()})
+        assert isinstance(mr.token_to_kv_pool, MLATokenToKVPool) and mr.graph_runner is not None
+        at = mr.model.model.layers[0].self_attn
+        assert at.num_local_heads == cfg["num_attention_heads"] // world
+        ca = parallel_state.get_custom_all_reduce()
+        assert ca is not None and not ca.disabled
+        steps = 4
+        oracle = OracleDeepseek(cfg, w, dt, max_total_tokens=1024, max_reqs=16, context_len=512)
+        ref_toks, ref_logits = oracle.generate_greedy(prompts, steps)
+        nxt, logits, batch = bob.extend([Req(i, p) for i, p in enumerate(prompts)], mr)
+        toks, lgs = [nxt.cpu()], [logits.float().cpu()]
+        for s in range(steps - 1):
+            feed = nxt if dt == torch.float32 else ref_toks[:, s].cuda()   # 16-bit: teacher-forced
+            nxt, logits = bob.decode(feed, batch, mr)
+            toks.append(nxt.cpu())
+            lgs.append(logits.float().cpu())
+        ca.check_status()
+        assert ca.calls["all_reduce"] >= 2 * cfg["num_hidden_layers"]
+        err = max((a - b.float()).abs().max().item() for a, b in zip(lgs, ref_logits))
+        if dt == torch.float32:
+            assert torch.equal(torch.stack(toks, 1), ref_toks)
+            assert err < 1e-3, err
+        else:
+            assert err < 6e-2, err   # each rank rounds its partial sums before they are added
+        parallel_state.destroy_model_parallel()
+        queue.put((rank, (torch.stack(toks, 1).numpy(), torch.stack(lgs).numpy())))
+    except BaseException:  # noqa: BLE001
+        queue.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,dtn", [("tiny-deepseek", "float32"), ("tiny-deepseek-yarn", "bfloat16")])
+def test_deepseek_tensor_parallel_two_ranks_on_one_gpu(preset, dtn):
+    import numpy as np
+
+    port = _free_port()
+    queue = _CTX.Queue()
+    procs = [_CTX.Process(target=_tp_rank_main_deepseek, args=(r, 2, port, queue, preset, dtn)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(2):
+            rank, msg = queue.get(timeout=140)
+            results[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    for r in range(2):
+        assert not isinstance(results[r], str), f"rank {r}: {results[r]}"
+    assert np.array_equal(results[0][0], results[1][0])
+    assert np.array_equal(results[0][1], results[1][1])
+
+
 def _skew_rank_main(rank, world, port, queue):
     """Rank skew: a peer that is late but within the timeout changes nothing; a peer that stays away
     longer than the timeout makes the waiting rank's call fail loudly (NaN output + status error)."""

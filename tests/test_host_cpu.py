@@ -120,6 +120,79 @@ def test_tensor_parallel_world2_gloo_matches_oracle():
         assert shapes["head"][0] == cfg["vocab_size"] // 2
 
 
+def _tp_worker_deepseek(rank, world, port, preset, q):
+    try:
+        torch.set_num_threads(2)
+        import cases
+        from sglang_custom_amd import bench_one_batch as bob
+        from sglang_custom_amd.managers.schedule_batch import Req
+
+        cfg, w, dt, mr = _build(preset, "float32", rank, world, f"tcp://127.0.0.1:{port}")
+        prompts = cases.e2e_prompts(cfg["vocab_size"], (5, 33))
+        nxt, lg, batch = bob.extend([Req(i, p) for i, p in enumerate(prompts)], mr)
+        toks, logits = [nxt.clone()], [lg.clone()]
+        for _ in range(3):
+            nxt, lg = bob.decode(nxt, batch, mr)
+            toks.append(nxt.clone())
+            logits.append(lg.clone())
+        at = mr.model.model.layers[0].self_attn
+        shapes = dict(q=tuple((at.q_b_proj if at.q_lora_rank is not None else at.q_proj).weight.shape),
+                      kv_b=tuple(at.kv_b_proj.weight.shape), o=tuple(at.o_proj.weight.shape),
+                      w_kc=tuple(at.w_kc.shape), w_vc=tuple(at.w_vc.shape),
+                      gate_up=tuple(mr.model.model.layers[0].mlp.gate_up_proj.weight.shape),
+                      cache=tuple(mr.token_to_kv_pool.get_key_buffer(0).shape[1:]),
+                      heads=(at.attn_mqa.tp_q_head_num, at.attn_mha.tp_k_head_num))
+        q.put((rank, torch.stack(toks, 1).numpy(), torch.stack(logits).numpy(), shapes))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+        raise e
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("preset", ["tiny-deepseek", "tiny-deepseek-yarn"])
+def test_deepseek_tensor_parallel_world2_gloo_matches_oracle(preset):
+    """The MLA stack over two ranks as the reference shards it (models/deepseek_v2.py:781-840, 182-198): heads
+    divided (q_b_proj / q_proj / kv_b_proj column-parallel, o_proj row-parallel), the low-rank projections and
+    the latent cache replicated, the MLP column- / row-parallel.  Both ranks must produce the single-process
+    oracle's tokens and logits (prefill in the multi-head form, decode in the absorbed form)."""
+    import cases
+    from oracle.deepseek_ref import OracleDeepseek
+    from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker_deepseek, args=(r, 2, port, preset, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == "error"), r[2]
+    cfg = hf_config_dict(preset, "float32")
+    w = make_synthetic_llama_weights(cfg, seed=1234, dtype=torch.float32)
+    prompts = cases.e2e_prompts(cfg["vocab_size"], (5, 33))
+    ref_toks, ref_logits = OracleDeepseek(cfg, w, torch.float32, max_total_tokens=512, max_reqs=8,
+                                          context_len=256).generate_greedy(prompts, 4)
+    H, nope, rope, vd, rank_ = (cfg["num_attention_heads"], cfg["qk_nope_head_dim"], cfg["qk_rope_head_dim"],
+                                cfg["v_head_dim"], cfg["kv_lora_rank"])
+    for rank, toks, lg, shapes in res:
+        assert torch.equal(torch.from_numpy(toks), ref_toks), f"rank {rank}"
+        assert (torch.from_numpy(lg) - torch.stack(ref_logits)).abs().max() < 1e-4
+        q_in = cfg["q_lora_rank"] or cfg["hidden_size"]
+        assert shapes["q"] == (H // 2 * (nope + rope), q_in)
+        assert shapes["kv_b"] == (H // 2 * (nope + vd), rank_)
+        assert shapes["o"] == (cfg["hidden_size"], H // 2 * vd)
+        assert shapes["w_kc"] == (H // 2, nope, rank_) and shapes["w_vc"] == (H // 2, rank_, vd)
+        assert shapes["gate_up"] == (cfg["intermediate_size"], cfg["hidden_size"])      # 2 * inter / 2 ranks
+        assert shapes["cache"] == (1, rank_ + rope)                                      # replicated latent rows
+        assert shapes["heads"] == (H // 2, H // 2)
+
+
 def _scheduler_case(mr, cfg, w, dt, tol):
     """Requests of different lengths arriving over time, a KV pool too small for all of them at
     once, prompts split into 16-token chunks: every request must produce exactly the tokens the
