@@ -22,8 +22,10 @@ from .mla_ref import OracleMLA
 
 class OracleDeepseek(OracleLlama):
     def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], dtype: torch.dtype, max_total_tokens: int = 4096,
-                 max_reqs: int = 64, context_len: Optional[int] = None):
+                 max_reqs: int = 64, context_len: Optional[int] = None, fp8_w8a8: bool = False):
         self.cfg, self.dtype = cfg, dtype
+        self.fp8 = fp8_w8a8        # every decoder-layer projection as an fp8 W8A8 linear (llama_ref._linear); the head stays 16-bit
+        self._q = {}
         self.h, self.L = cfg["hidden_size"], cfg["num_hidden_layers"]
         self.eps, self.vocab = cfg["rms_norm_eps"], cfg["vocab_size"]
         self.w = {k: v.to(dtype) for k, v in weights.items()}
@@ -43,7 +45,7 @@ class OracleDeepseek(OracleLlama):
             m = OracleMLA(w, dtype, cfg["hidden_size"], cfg["num_attention_heads"], cfg["qk_nope_head_dim"],
                           cfg["qk_rope_head_dim"], cfg["v_head_dim"], cfg["kv_lora_rank"], qr, theta=cfg["rope_theta"],
                           eps=self.eps, rope_scaling=cfg.get("rope_scaling"),
-                          max_position=cfg["max_position_embeddings"], slots=max_total_tokens)
+                          max_position=cfg["max_position_embeddings"], slots=max_total_tokens, fp8_w8a8=fp8_w8a8)
             m.req_to_token = self.req_to_token     # one request table for every layer
             self.attn.append(m)
         self.gate_up = [torch.cat([self.w[f"model.layers.{i}.mlp.gate_proj.weight"],
@@ -63,7 +65,8 @@ class OracleDeepseek(OracleLlama):
                 h, residual = ops_ref.rmsnorm(h, w[p + "input_layernorm.weight"], self.eps, residual)
             h = attend(i, h)
             h, residual = ops_ref.rmsnorm(h, w[p + "post_attention_layernorm.weight"], self.eps, residual)
-            h = F.linear(ops_ref.silu_and_mul(F.linear(h, self.gate_up[i])), w[p + "mlp.down_proj.weight"])
+            h = self._linear(ops_ref.silu_and_mul(self._linear(h, self.gate_up[i], ("gate_up", i))),
+                             w[p + "mlp.down_proj.weight"], ("down", i))
         h, _ = ops_ref.rmsnorm(h, w["model.norm.weight"], self.eps, residual)
         return h
 

@@ -38,8 +38,10 @@ class DeepseekV2AttentionMLA(nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, qk_nope_head_dim: int, qk_rope_head_dim: int,
                  v_head_dim: int, q_lora_rank: Optional[int], kv_lora_rank: int, layer_id: int, dtype, device,
                  rope_theta: float = 10000.0, max_position_embeddings: int = 8192, rms_norm_eps: float = 1e-6,
-                 rope_scaling: Optional[dict] = None):
+                 rope_scaling: Optional[dict] = None, quant_method_factory=None):
         super().__init__()
+        qm = quant_method_factory or (lambda: None)   # one linear method per projection (fp8 W8A8 or unquantised)
+        self.dtype = dtype
         self.hidden_size = hidden_size
         # Tensor parallelism as the reference shards this module (:781-840): the heads are divided over the
         # ranks -- q_b_proj / q_proj and kv_b_proj column-parallel, o_proj row-parallel with a sum over ranks --
@@ -57,15 +59,15 @@ class DeepseekV2AttentionMLA(nn.Module):
         if q_lora_rank is not None:
             # fused_qkv_a_proj_with_mqa: [q_a | kv_a + k_pe] in one projection (:760-768)
             self.fused_qkv_a_proj_with_mqa = ReplicatedLinear(
-                hidden_size, q_lora_rank + kv_lora_rank + qk_rope_head_dim, dtype, device)
+                hidden_size, q_lora_rank + kv_lora_rank + qk_rope_head_dim, dtype, device, qm())
             self.q_a_layernorm = RMSNorm(q_lora_rank, eps=rms_norm_eps)
-            self.q_b_proj = MergedColumnParallelLinear(q_lora_rank, [num_heads * self.qk_head_dim], dtype, device)
+            self.q_b_proj = MergedColumnParallelLinear(q_lora_rank, [num_heads * self.qk_head_dim], dtype, device, qm())
         else:
-            self.q_proj = MergedColumnParallelLinear(hidden_size, [num_heads * self.qk_head_dim], dtype, device)
-            self.kv_a_proj_with_mqa = ReplicatedLinear(hidden_size, kv_lora_rank + qk_rope_head_dim, dtype, device)
+            self.q_proj = MergedColumnParallelLinear(hidden_size, [num_heads * self.qk_head_dim], dtype, device, qm())
+            self.kv_a_proj_with_mqa = ReplicatedLinear(hidden_size, kv_lora_rank + qk_rope_head_dim, dtype, device, qm())
         self.kv_a_layernorm = RMSNorm(kv_lora_rank, eps=rms_norm_eps)
-        self.kv_b_proj = MergedColumnParallelLinear(kv_lora_rank, [num_heads * (qk_nope_head_dim + v_head_dim)], dtype, device)
-        self.o_proj = RowParallelLinear(num_heads * v_head_dim, hidden_size, dtype, device)
+        self.kv_b_proj = MergedColumnParallelLinear(kv_lora_rank, [num_heads * (qk_nope_head_dim + v_head_dim)], dtype, device, qm())
+        self.o_proj = RowParallelLinear(num_heads * v_head_dim, hidden_size, dtype, device, qm())
         if rope_scaling:
             rope_scaling = dict(rope_scaling, rope_type="deepseek_yarn")
             mscale = yarn_get_mscale(rope_scaling["factor"], float(rope_scaling.get("mscale_all_dim", False)))
@@ -94,6 +96,11 @@ class DeepseekV2AttentionMLA(nn.Module):
             weight, weight_scale = weight[r * per:(r + 1) * per], weight_scale[r * per:(r + 1) * per]
         self._kv_b_fp8 = (weight, weight_scale.float())
 
+    def linears(self):
+        if self.q_lora_rank is not None:
+            return [self.fused_qkv_a_proj_with_mqa, self.q_b_proj, self.kv_b_proj, self.o_proj]
+        return [self.q_proj, self.kv_a_proj_with_mqa, self.kv_b_proj, self.o_proj]
+
     def post_load_weights(self) -> None:
         """w_kc [H, nope, rank] and w_vc [H, rank, v]: kv_b_proj split per head (:2150-2313).  From an
         fp8 kv_b_proj the reference re-quantises to ONE scale per tensor (channel_quant_to_tensor_quant,
@@ -101,6 +108,8 @@ class DeepseekV2AttentionMLA(nn.Module):
         the same two bf16 tensors are built once here."""
         fp8 = getattr(self, "_kv_b_fp8", None)
         w = self.kv_b_proj.weight.data
+        if fp8 is None and w.dtype == torch.float8_e4m3fn:   # quantised at load by the fp8 W8A8 linear method
+            fp8 = (w, self.kv_b_proj.weight_scale.data.float())
         if fp8 is not None:
             wq, ws = fp8
             x = wq.to(torch.float32) * ws
@@ -115,8 +124,8 @@ class DeepseekV2AttentionMLA(nn.Module):
         if fp8 is not None:
             w_kc = w_kc.to(torch.bfloat16) * self.w_scale
             w_vc = w_vc.to(torch.bfloat16) * self.w_scale
-        self.w_kc = w_kc.contiguous().to(self.kv_b_proj.weight.dtype)
-        self.w_vc = w_vc.transpose(1, 2).contiguous().to(self.kv_b_proj.weight.dtype)
+        self.w_kc = w_kc.contiguous().to(self.dtype)
+        self.w_vc = w_vc.transpose(1, 2).contiguous().to(self.dtype)
 
     # ---- shared front end ----
     def _q_and_latent(self, hidden_states):
@@ -180,10 +189,11 @@ class DeepseekV2AttentionMLA(nn.Module):
 class DeepseekV2MLP(nn.Module):
     """gate_up -> SiLU-and-mul -> down (:167-219); column- / row-parallel over the ranks (:182-198)."""
 
-    def __init__(self, hidden_size: int, intermediate_size: int, dtype, device):
+    def __init__(self, hidden_size: int, intermediate_size: int, dtype, device, quant_method_factory=None):
         super().__init__()
-        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size, intermediate_size], dtype, device)
-        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, dtype, device)
+        qm = quant_method_factory or (lambda: None)
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size, intermediate_size], dtype, device, qm())
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, dtype, device, qm())
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
@@ -194,14 +204,14 @@ class DeepseekV2DecoderLayer(nn.Module):
     """input_layernorm -> MLA -> post_attention_layernorm -> MLP with the residual carried beside the
     hidden states (:1740-1968, the dense branch)."""
 
-    def __init__(self, config, layer_id: int, dtype, device):
+    def __init__(self, config, layer_id: int, dtype, device, quant_method_factory=None):
         super().__init__()
         self.self_attn = DeepseekV2AttentionMLA(
             config.hidden_size, config.num_attention_heads, config.qk_nope_head_dim, config.qk_rope_head_dim,
             config.v_head_dim, config.q_lora_rank, config.kv_lora_rank, layer_id, dtype, device,
             rope_theta=config.rope_theta, max_position_embeddings=config.max_position_embeddings,
-            rms_norm_eps=config.rms_norm_eps, rope_scaling=config.rope_scaling)
-        self.mlp = DeepseekV2MLP(config.hidden_size, config.intermediate_size, dtype, device)
+            rms_norm_eps=config.rms_norm_eps, rope_scaling=config.rope_scaling, quant_method_factory=quant_method_factory)
+        self.mlp = DeepseekV2MLP(config.hidden_size, config.intermediate_size, dtype, device, quant_method_factory)
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
@@ -217,10 +227,10 @@ class DeepseekV2DecoderLayer(nn.Module):
 
 
 class DeepseekV2Model(nn.Module):
-    def __init__(self, config, dtype, device):
+    def __init__(self, config, dtype, device, quant_method_factory=None):
         super().__init__()
         self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size, dtype, device)
-        self.layers = nn.ModuleList([DeepseekV2DecoderLayer(config, i, dtype, device)
+        self.layers = nn.ModuleList([DeepseekV2DecoderLayer(config, i, dtype, device, quant_method_factory)
                                      for i in range(config.num_hidden_layers)])
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
@@ -238,8 +248,6 @@ class DeepseekV2ForCausalLM(nn.Module):
 
     def __init__(self, config, dtype=torch.bfloat16, device="cuda", quant_method_factory=None):
         super().__init__()
-        if quant_method_factory is not None:
-            raise NotImplementedError("fp8 linears of the DeepSeek stack: only kv_b_proj (load_kv_b_proj_fp8) is supported")
         hf = config.hf_config
         n_experts = getattr(hf, "n_routed_experts", None)
         if n_experts is not None and getattr(hf, "first_k_dense_replace", 0) < config.num_hidden_layers:
@@ -248,7 +256,10 @@ class DeepseekV2ForCausalLM(nn.Module):
                 "(first_k_dense_replace >= num_hidden_layers)")
         self.config = config
         self.dtype = dtype
-        self.model = DeepseekV2Model(config, dtype, device)
+        # quant_method_factory (W8A8Fp8LinearMethod): every decoder-layer projection becomes an fp8 W8A8 linear,
+        # quantised per output channel when the weights are loaded (w8a8_fp8.py:118-134); kv_b_proj, an fp8
+        # tensor then, feeds the absorbed form through the re-quantisation of post_load_weights()
+        self.model = DeepseekV2Model(config, dtype, device, quant_method_factory)
         self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size, dtype, device)
         self.logits_processor = LogitsProcessor(config)
         for m in self.modules():
@@ -295,6 +306,8 @@ class DeepseekV2ForCausalLM(nn.Module):
 
     def post_load_weights(self) -> None:
         for layer in self.model.layers:
+            for lin in layer.self_attn.linears() + [layer.mlp.gate_up_proj, layer.mlp.down_proj]:
+                lin.quant_method.process_weights_after_loading(lin)
             layer.self_attn.post_load_weights()
 
     @torch.no_grad()
