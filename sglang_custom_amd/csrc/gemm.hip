@@ -374,10 +374,21 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_ring_kernel(
         mine[r] = round_to<T>(v[r]);
         other[r] = __shfl_xor(mine[r], 32, 64);
       }
-      if (q < 2 && m < M) {
+      // Lanes q < 2 hold gate values (their up partners 32 lanes higher), lanes q >= 2 the mirror image.
+      // Every lane takes two of the four outputs of its pair -- the low lane r = 0, 1, the high lane r = 2, 3 --
+      // so the activation's ~40 instructions per output run on all 64 lanes instead of 32; the high lane's two
+      // results travel back as one packed word.  Same statement per output: same bits.
+      const bool lo = q < 2;
+      const float g0 = lo ? mine[0] : other[2], u0 = lo ? other[0] : mine[2];
+      const float g1 = lo ? mine[1] : other[3], u1 = lo ? other[1] : mine[3];
+      const T s0 = silu_mul_one<T>(from_f32<T>(g0), from_f32<T>(u0));
+      const T s1 = silu_mul_one<T>(from_f32<T>(g1), from_f32<T>(u1));
+      const Vec<T, 2> pk{{s0, s1}};
+      const unsigned got = (unsigned)__shfl_xor((int)__builtin_bit_cast(unsigned, pk), 32, 64);
+      if (lo && m < M) {
         const int half_n = N >> 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o4[r] = (OUT)silu_mul_one<T>(from_f32<T>(mine[r]), from_f32<T>(other[r]));
+        const Vec<T, 2> hi = __builtin_bit_cast(Vec<T, 2>, got);
+        o4[0] = (OUT)s0; o4[1] = (OUT)s1; o4[2] = (OUT)hi.v[0]; o4[3] = (OUT)hi.v[1];
         store4(y + (int64_t)m * half_n, tile * 8 + 4 * q, half_n, o4);
       }
     } else {
