@@ -723,26 +723,10 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
 
   // FUSED: the workgroup first reduces its (G + 2) x 128 slice of the qkv row (q heads, k, v) from
-  // the split-K partials into LDS -- one float4 per thread and split -- together with the rounded
-  // cos | sin row of the sequence's position; the MFMA fragments are then read from LDS and rotated
-  // in registers (neox pairs feature i with i + 64: fragment s with s + 2).
+  // the split-K partials into LDS -- one float4 per thread and split -- and applies neox RoPE to the q and
+  // k slices on the way (features i and i + 64 of a head exchange through a lane shuffle); the MFMA fragments
+  // are then read from LDS as they are.
   __shared__ __attribute__((aligned(16))) T sm_qkv[FUSED ? (G + 2) * D : 8];
-  __shared__ __attribute__((aligned(16))) float sm_cs[FUSED ? D : 4];
-  float rc[2][8], rs[2][8];   // cos / sin of this lane's first-half features (FUSED only)
-  auto rotate = [&](frag (&y)[4]) {
-    // every product and sum rounds on its own, as in the RoPE kernel: with native f16 arithmetic the
-    // compiler would otherwise contract the rounded products into fused multiply-adds
-#pragma clang fp contract(off)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x1 = to_f32((T)y[s][j]), x2 = to_f32((T)y[s + 2][j]);
-        const float c = rc[s][j], sn = rs[s][j];
-        y[s][j] = from_f32<T>(round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * sn)));
-        y[s + 2][j] = from_f32<T>(round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * sn)));
-      }
-  };
   auto reduce_qkv_to_lds = [&]() {
     const int64_t pos = fz.positions[b];
     for (int v = threadIdx.x; v < (G + 2) * 32; v += 256) {
@@ -767,18 +751,43 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) out.v[j] = from_f32<T>(sum[j] + 0.f);
       }
+      // neox RoPE on the q heads and the new key, here, once per workgroup (each wave would otherwise rotate
+      // its own copy of all heads after the barrier): features i and i + 64 of a head sit in lanes 16 apart of
+      // this wave (f4 and f4 + 16).  Rounding points of the RoPE kernel; the value slice is left alone.
+      // (All 32 lanes of a slice are active together, and slices never straddle a wave: the exchange is safe.)
+      if (seg <= G) {   // (uniform over the 32 lanes of a slice)
+#pragma clang fp contract(off)
+        const int fl = f4 & 15;
+        float c4v[4], s4v[4];
+        if (fz.cache_f32) {
+          const float4 cc = *reinterpret_cast<const float4*>(static_cast<const float*>(fz.cos_sin) + pos * D + 4 * fl);
+          const float4 ss = *reinterpret_cast<const float4*>(static_cast<const float*>(fz.cos_sin) + pos * D + 64 + 4 * fl);
+          c4v[0] = cc.x; c4v[1] = cc.y; c4v[2] = cc.z; c4v[3] = cc.w;
+          s4v[0] = ss.x; s4v[1] = ss.y; s4v[2] = ss.z; s4v[3] = ss.w;
+        } else {
+          const Vec<T, 4> cc = ldvec<T, 4>(static_cast<const T*>(fz.cos_sin) + pos * D + 4 * fl);
+          const Vec<T, 4> ss = ldvec<T, 4>(static_cast<const T*>(fz.cos_sin) + pos * D + 64 + 4 * fl);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { c4v[j] = to_f32(cc.v[j]); s4v[j] = to_f32(ss.v[j]); }
+        }
+        const bool second = f4 >= 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float mine = to_f32(out.v[j]);
+          const float theirs = __shfl_xor(mine, 16, 64);
+          const float c = round_to<T>(c4v[j]), sn = round_to<T>(s4v[j]);
+          const float x1 = second ? theirs : mine, x2 = second ? mine : theirs;
+          const float y = second ? round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * sn))
+                                 : round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * sn));
+          out.v[j] = from_f32<T>(y);
+        }
+      }
       stvec<T, 4>(&sm_qkv[seg * D + 4 * f4], out);
     }
-    if (threadIdx.x < D) {
-      const int64_t i = pos * D + threadIdx.x;
-      const float cv = fz.cache_f32 ? static_cast<const float*>(fz.cos_sin)[i] : to_f32(static_cast<const T*>(fz.cos_sin)[i]);
-      sm_cs[threadIdx.x] = round_to<T>(cv);
-    }
   };
-  auto frags_from_lds = [&](int seg, frag (&y)[4]) {
+  auto frags_from_lds = [&](int seg, frag (&y)[4]) {   // (rotated already)
 #pragma unroll
     for (int s = 0; s < 4; ++s) y[s] = *reinterpret_cast<const frag*>(&sm_qkv[seg * D + 32 * s + 8 * c4]);
-    rotate(y);
   };
 
   frag qf[4];
@@ -983,13 +992,6 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   }
   if constexpr (FUSED) {
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      *reinterpret_cast<float4*>(&rc[s][0]) = *reinterpret_cast<const float4*>(&sm_cs[32 * s + 8 * c4]);
-      *reinterpret_cast<float4*>(&rc[s][4]) = *reinterpret_cast<const float4*>(&sm_cs[32 * s + 8 * c4 + 4]);
-      *reinterpret_cast<float4*>(&rs[s][0]) = *reinterpret_cast<const float4*>(&sm_cs[64 + 32 * s + 8 * c4]);
-      *reinterpret_cast<float4*>(&rs[s][4]) = *reinterpret_cast<const float4*>(&sm_cs[64 + 32 * s + 8 * c4 + 4]);
-    }
     frags_from_lds(r16 < G ? r16 : 0, qf);
     if (r16 >= G) {
 #pragma unroll
