@@ -625,8 +625,11 @@ static constexpr int g_force_waves = 0;
 // traffic (splits * M * N * 8 bytes written + read), so wide outputs are never split.
 static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k, bool ring) {
   SkinnyPlan p;
-  p.nt = n >= 64 * 1024 ? 2 : 1;  // very wide outputs (lm_head): two tiles per wave
-  p.waves = 4;
+  // Very wide outputs (lm_head): two tiles per wave and, on the ring kernel, eight waves -- 256
+  // rows per workgroup, so the activation tile is staged half as often per weight byte.  Up to 16
+  // rows of x there is little to stage and one tile per wave keeps more workgroups in flight.
+  p.nt = n >= 64 * 1024 && (m > 16 || !ring) ? 2 : 1;
+  p.waves = p.nt == 2 && ring ? 8 : 4;
   const int64_t tiles = (n + 15) / 16;
   const int64_t kchunks = (k + SK_BK - 1) / SK_BK;
   int64_t splits = 1;
@@ -733,6 +736,8 @@ static void launch_skinny_cfg(const T* x, const T* w, const T* bias, OUT* y, cha
       if (p.waves == 6) return launch_ring<T, MT, NT, OUT, PACKED, 6, ACT>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
       return launch_ring<T, MT, NT, OUT, PACKED, 4, ACT>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
     }
+    if constexpr (!ACT && PACKED && NT == 2)
+      if (p.waves == 8) return launch_ring<T, MT, NT, OUT, PACKED, 8>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
     if constexpr (!ACT)
       return launch_ring<T, MT, NT, OUT, PACKED, 4>(x, w, bias, y, slab, counters, M, N, K, x_stride, p, st);
   }
