@@ -30,17 +30,35 @@ __global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restric
           bidx = (int)(i * 4 + j);
         }
     };
-    // four loads in flight per lane before the first comparison: 64 rows are 64 workgroups, so the
-    // row is read at the latency of its loads unless each lane keeps several outstanding
-    int64_t i = threadIdx.x;
-    for (; i + 3 * SAMP_THREADS < nv; i += 4 * SAMP_THREADS) {
-      float4 v[4];
+    // A lane meets its elements in rising index order, so "strictly greater" alone keeps the first
+    // maximum: three branch-free instructions per element.  It cannot pick among elements equal to
+    // the initial -inf; a lane that ends with nothing selected repeats the pass with the full rule.
+    auto take_gt = [&](const float4& v, int64_t i) {
+      const float a[4] = {v.x, v.y, v.z, v.w};
+      const int base = (int)i * 4;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(row + (i + u * SAMP_THREADS) * 4);
+      for (int j = 0; j < 4; ++j) {
+        const bool gt = a[j] > best;
+        best = gt ? a[j] : best;
+        bidx = gt ? base + j : bidx;
+      }
+    };
+    // sixteen loads in flight per lane before the first comparison: 64 rows are 64 workgroups, so
+    // a row is read at the latency of its load rounds (two for a 128k vocabulary), not at bandwidth
+    constexpr int U = 16;
+    auto scan = [&](auto&& pick) {
+      for (int64_t i = threadIdx.x; i < nv; i += U * SAMP_THREADS) {
+        float4 v[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) take(v[u], i + u * SAMP_THREADS);
-    }
-    for (; i < nv; i += SAMP_THREADS) take(*reinterpret_cast<const float4*>(row + i * 4), i);
+        for (int u = 0; u < U; ++u)
+          if (i + u * SAMP_THREADS < nv) v[u] = *reinterpret_cast<const float4*>(row + (i + u * SAMP_THREADS) * 4);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (i + u * SAMP_THREADS < nv) pick(v[u], i + u * SAMP_THREADS);
+      }
+    };
+    scan(take_gt);
+    if (bidx == 0x7fffffff) scan(take);
     for (int64_t i = nv * 4 + threadIdx.x; i < vocab; i += SAMP_THREADS)
       if (row[i] > best || (row[i] == best && (int)i < bidx)) {
         best = row[i];

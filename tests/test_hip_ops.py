@@ -944,6 +944,26 @@ def test_backend_sliding_window_layers_follow_the_reference_window_lists(ops):
             assert maxdiff(o[b], ref) <= ATTN_TOL["bf16"], (window, b)
 
 
+def test_argmax_rows_of_minus_infinity_and_nan(ops):
+    """Rows a grammar mask or an overflow can produce: everything -inf but a few entries, everything
+    -inf (torch: index 0), -inf everywhere but NaNs in front (NaN never wins here; the first -inf
+    does), a maximum that repeats in the columns one lane owns, odd vocabulary with a scalar tail."""
+    for V in (128256, 4100, 4099, 37):
+        g = torch.Generator().manual_seed(V)
+        x = torch.randn((8, V), generator=g)
+        x[0] = float("-inf"); x[0, V - 3] = -5.0; x[0, V // 2] = -5.0
+        x[1] = float("-inf")
+        x[2] = float("-inf"); x[2, :3] = float("nan")
+        x[3, 5] = x[3, 5 + 4096 if V > 5000 else V - 1] = 9.0            # 5 and 5 + 4096 fall to the same lane
+        x[4, : V // 2] = float("-inf")
+        x[5] = 1.0
+        x[6, V - 1] = 50.0
+        want = torch.argmax(torch.nan_to_num(x, nan=float("-inf")), -1)
+        want[2] = 3                                                       # first -inf behind the NaNs
+        got = ops.argmax(x.to(DEV)).cpu()
+        assert torch.equal(got, want), (V, got.tolist(), want.tolist())
+
+
 def test_argmax_and_sampler_at_llama3_vocab(ops):
     """vocab 128256 (sgl-kernel/tests/test_sampling.py runs its cases at 111 / 32000 / 128256): arg-max
     with the first-index tie rule, softmax with temperature, and the joint top-k / top-p / min-p
