@@ -294,6 +294,16 @@ def _tickets(t, need: int):
     return t.data_ptr()
 
 
+def _split_scratch(attn_logits, attn_lse, rows: int, dv: int, splits: int) -> None:
+    """The kernels write rows * splits partial outputs of dv floats and as many log-sum-exps: refuse a
+    scratch pair that cannot hold them (the C ABI sees raw pointers and cannot)."""
+    if splits > 1:
+        assert attn_logits is not None and attn_lse is not None, "num_kv_splits > 1 needs attn_logits / attn_lse"
+        assert attn_logits.is_cuda and attn_lse.is_cuda and attn_logits.dtype == attn_lse.dtype == torch.float32
+        assert attn_logits.numel() >= rows * splits * dv and attn_lse.numel() >= rows * splits, \
+            f"split scratch too small for {rows} rows x {splits} splits x {dv}"
+
+
 def decode_num_splits(bs: int, hkv: int, max_seq_len: int, max_splits: int) -> int:
     return _lib_().mi355_decode_num_splits(bs, hkv, max_seq_len, max_splits)
 
@@ -335,6 +345,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
     assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
     assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
     assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    _split_scratch(attn_logits, attn_lse, B * Hq, Dv, num_kv_splits)
     check(_lib_().mi355_decode_attention(
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
@@ -385,6 +396,7 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
     if part_x_scale is not None:   # partials of an fp8 GEMM: its per-token / per-channel scales
         assert part_x_scale.dtype == part_w_scale.dtype == torch.float32 and part_x_scale.numel() == B
         assert part_w_scale.numel() == qkv_part.shape[2] and part_x_scale.is_contiguous() and part_w_scale.is_contiguous()
+    _split_scratch(attn_logits, attn_lse, B * Hq, D, num_kv_splits)
     check(_lib_().mi355_decode_attention_fused_qkv(
         qkv_part.data_ptr(), qkv_part.shape[0], _p(part_x_scale), _p(part_w_scale), positions.data_ptr(),
         out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
@@ -405,6 +417,7 @@ def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_le
     assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous() and o.shape == (B, Hq, kv_lora_rank)
     assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
     assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    _split_scratch(attn_logits, attn_lse, B * Hq, kv_lora_rank, num_kv_splits)
     check(_lib_().mi355_decode_attention_mla(
         q.data_ptr(), kv_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0),

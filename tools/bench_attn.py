@@ -29,7 +29,8 @@ for b in range(bs):
     if ctx > PL: r2t[b, PL:ctx] = 1 + bs * SP + torch.arange(ctx - PL, device='cuda') * bs + b
 rpi = torch.arange(bs, dtype=torch.int64, device='cuda')
 sl = torch.full((bs,), ctx, dtype=torch.int64, device='cuda')
-MAXS = 16
+SPLIT_LIST = [int(x) for x in os.environ.get('SPLITS', '1,2,3,4').split(',')]
+MAXS = max(SPLIT_LIST)   # the partials of the widest split plan must fit
 logits = torch.empty(bs, hq, MAXS, D, dtype=torch.float32, device='cuda'); lse = torch.empty(bs, hq, MAXS, dtype=torch.float32, device='cuda')
 def timeit(fn, reps=12):
     fn(0); torch.cuda.synchronize()
@@ -53,7 +54,7 @@ nbytes = bs * ctx * hkv * D * 2 * kb[0].element_size()
 tk = torch.zeros(bs * hq, dtype=torch.int32, device='cuda') if os.environ.get('TICKETS') else None
 for dbg in ((0,) if os.environ.get('ONLY0') else (3, 0)):
     lib.mi355_debug_set(6, dbg)   # 3 = K rows straight into fragments (ablation), 0 = whole K rows staged through LDS (product)
-    for ns in [int(x) for x in os.environ.get('SPLITS', '1,2,3,4').split(',')]:
+    for ns in SPLIT_LIST:
         o.zero_()
         ops.decode_attention_paged(q, kb[0], vb[0], o, r2t, rpi, sl, logits, lse, ns, D ** -0.5, tickets=tk)
         err = (o.float() - ref).abs().max().item()

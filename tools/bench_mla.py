@@ -17,7 +17,8 @@ o = torch.empty(bs, H, rank, device='cuda', dtype=torch.bfloat16)
 r2t = (1 + torch.arange(bs * ctx, device='cuda', dtype=torch.int32)).view(bs, ctx).contiguous()
 rpi = torch.arange(bs, dtype=torch.int64, device='cuda')
 sl = torch.full((bs,), ctx, dtype=torch.int64, device='cuda')
-MAXS = 16
+SPLIT_LIST = [int(x) for x in os.environ.get('SPLITS', '1,2,4,8').split(',')]
+MAXS = max(SPLIT_LIST)   # the partials of the widest split plan must fit
 lg = torch.empty(bs * H * MAXS * rank, dtype=torch.float32, device='cuda'); ls = torch.empty(bs * H * MAXS, dtype=torch.float32, device='cuda')
 def timeit(fn, reps=8):
     fn(0); torch.cuda.synchronize()
@@ -39,7 +40,7 @@ nbytes = bs * ctx * D * 2
 tk = torch.zeros(bs * H, dtype=torch.int32, device='cuda') if os.environ.get('TICKETS') else None
 for dbg in ((0,) if os.environ.get("MLA_AB") else (1, 2, 5, 0)):
     lib.mi355_debug_set(6, dbg)   # 1 = generic wave-per-head kernel, 2 = MFMA kernel with rows in registers, 0 = rows through the LDS ring (product)
-    for ns in [int(x) for x in os.environ.get('SPLITS', '1,2,4,8').split(',')]:
+    for ns in SPLIT_LIST:
         if dbg == 1 and ns not in (1, 4): continue
         if len(sys.argv) > 4 and ns != int(sys.argv[4]): continue
         o.zero_()
