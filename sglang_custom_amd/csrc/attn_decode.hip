@@ -1871,17 +1871,15 @@ int g_decode_variant = 0;
 static constexpr int g_decode_variant = 0;
 #endif
 
-static thread_local bool g_kv8 = false;   // set by the entry point for the duration of one launch_decode call (fp8 KV cache)
-
 template <typename T, int D, int U, bool CAP>
 static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const DecodeParams& p,
-                             int64_t bs, hipStream_t st) {
+                             int64_t bs, bool kv8, hipStream_t st) {   // kv8: the KV cache holds e4m3fn bytes
   const int gtotal = p.hq / p.hkv;
   const int G = gtotal % 8 == 0 ? 8 : gtotal % 4 == 0 ? 4 : gtotal % 2 == 0 ? 2 : 1;
   const dim3 grid((unsigned)(p.hkv * (gtotal / G)), (unsigned)p.num_splits, (unsigned)bs);
   const dim3 block(256);
   if constexpr (D == 128 && !std::is_same<T, float>::value) {
-    if (g_kv8) {
+    if (kv8) {
       switch (G) {
         case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, CAP, false, true, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
         case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, CAP, false, true, true>), grid, block, 0, st, q, kb, vb, o, p, FusedQkv()); break;
@@ -1929,15 +1927,15 @@ static void launch_decode_dc(const T* q, const T* kb, const T* vb, T* o, const D
 
 template <typename T, int D, int U>
 static bool launch_decode_d(const T* q, const T* kb, const T* vb, T* o, const DecodeParams& p,
-                            int64_t bs, hipStream_t st) {
-  if (p.logit_cap > 0.f) launch_decode_dc<T, D, U, true>(q, kb, vb, o, p, bs, st);
-  else launch_decode_dc<T, D, U, false>(q, kb, vb, o, p, bs, st);
+                            int64_t bs, bool kv8, hipStream_t st) {
+  if (p.logit_cap > 0.f) launch_decode_dc<T, D, U, true>(q, kb, vb, o, p, bs, kv8, st);
+  else launch_decode_dc<T, D, U, false>(q, kb, vb, o, p, bs, kv8, st);
   return true;
 }
 
 template <typename T>
 static int launch_decode(const void* q_, const void* kb_, const void* vb_, void* o_,
-                         const DecodeParams& p_in, int64_t bs, int D, int Dv, hipStream_t st) {
+                         const DecodeParams& p_in, int64_t bs, int D, int Dv, bool kv8, hipStream_t st) {
   DecodeParams p = p_in;
   const T* q = (const T*)q_;
   const T* kb = (const T*)kb_;
@@ -1947,16 +1945,16 @@ static int launch_decode(const void* q_, const void* kb_, const void* vb_, void*
                    p.q_stride % V16<T>::n == 0;
   constexpr int VE = V16<T>::n;
   // only the matrix-core kernel (head_dim 128, 16-bit) merges the splits itself
-  if (!(vec && D == 128 && !std::is_same<T, float>::value && (g_kv8 || g_decode_variant == 0) &&
+  if (!(vec && D == 128 && !std::is_same<T, float>::value && (kv8 || g_decode_variant == 0) &&
         p.num_splits > 1 && p.num_splits <= MERGE_MAX_SPLITS))
     p.tickets = nullptr;
-  if (g_kv8 && !(vec && D == 128 && !std::is_same<T, float>::value)) {
+  if (kv8 && !(vec && D == 128 && !std::is_same<T, float>::value)) {
     set_error("decode_attention: an fp8 KV cache needs head_dim 128, a 16-bit dtype and 16-B aligned pointers");
     return MI355_ERR_UNSUPPORTED;
   }
-  if (vec && D == 64) launch_decode_d<T, 64, 4>(q, kb, vb, o, p, bs, st);
-  else if (vec && D == 128) launch_decode_d<T, 128, 4>(q, kb, vb, o, p, bs, st);
-  else if (vec && D == 256 && D / VE <= 64) launch_decode_d<T, 256, 2>(q, kb, vb, o, p, bs, st);
+  if (vec && D == 64) launch_decode_d<T, 64, 4>(q, kb, vb, o, p, bs, kv8, st);
+  else if (vec && D == 128) launch_decode_d<T, 128, 4>(q, kb, vb, o, p, bs, kv8, st);
+  else if (vec && D == 256 && D / VE <= 64) launch_decode_d<T, 256, 2>(q, kb, vb, o, p, bs, kv8, st);
   else {
     if (D > 1024 || Dv > 1024) {
       set_error("decode_attention: head_dim %d / v_head_dim %d > 1024", D, Dv);
@@ -1973,12 +1971,12 @@ static int launch_decode(const void* q_, const void* kb_, const void* vb_, void*
 
 template <typename T>
 static int launch_decode_fused(const T* kb, const T* vb, T* o, const DecodeParams& p_in, const FusedQkv& fz,
-                               int64_t bs, hipStream_t st) {
+                               int64_t bs, bool kv8, hipStream_t st) {
   DecodeParams p = p_in;
   if (p.num_splits <= 1 || p.num_splits > MERGE_MAX_SPLITS) p.tickets = nullptr;
   const int G = p.hq / p.hkv;
   const dim3 grid((unsigned)p.hkv, (unsigned)p.num_splits, (unsigned)bs), block(256);
-  if (g_kv8) {
+  if (kv8) {
     switch (G) {
       case 8: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 8, false, true, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
       case 4: hipLaunchKernelGGL((decode_attn_mfma_pv_kernel<T, 4, false, true, true, true>), grid, block, 0, st, (const T*)nullptr, kb, vb, o, p, fz); break;
@@ -2079,12 +2077,11 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   p.k_slot_stride = (int64_t)hkv * head_dim;
   p.v_slot_stride = (int64_t)hkv * v_head_dim;
   int rc = MI355_OK;
-  g_kv8 = (dtype & MI355_KV_FP8) != 0;
+  const bool kv8 = (dtype & MI355_KV_FP8) != 0;
   dtype &= 0xff;
   MI355_DISPATCH_DTYPE(dtype, "decode_attention",
-                       rc = launch_decode<T>(q, k_buffer, v_buffer, o, p, bs, head_dim, v_head_dim,
+                       rc = launch_decode<T>(q, k_buffer, v_buffer, o, p, bs, head_dim, v_head_dim, kv8,
                                              (hipStream_t)stream));
-  g_kv8 = false;
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("decode_attention");
   return MI355_OK;
@@ -2102,18 +2099,32 @@ static constexpr int kMaxDevices = 64;
 static std::mutex g_static_mu;
 static float* g_static_ptr[kMaxDevices];   // per device; null until that device's first call
 
-static int static_scratch_ptr(float** out) {
+// The array lives once per GPU: the copy a launch must use is the one on the device that owns
+// `stream` (the calling thread's current device only for the null stream).
+static int static_scratch_ptr(hipStream_t stream, float** out) {
   int dev = -1;
-  hipError_t e = hipGetDevice(&dev);
+  hipError_t e = hipSuccess;
+  if (stream != nullptr) {
+    hipDevice_t sd = -1;
+    e = hipStreamGetDevice(stream, &sd);
+    dev = (int)sd;
+  } else {
+    e = hipGetDevice(&dev);
+  }
   if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
-    set_error("decode_attention_static: hipGetDevice failed or device %d outside 0..%d: %s", dev, kMaxDevices - 1,
+    set_error("decode_attention_static: no device for the stream, or device %d outside 0..%d: %s", dev, kMaxDevices - 1,
               hipGetErrorString(e));
     return MI355_ERR_LAUNCH;
   }
   std::lock_guard<std::mutex> lk(g_static_mu);
   if (!g_static_ptr[dev]) {
+    // hipGetSymbolAddress answers for the CURRENT device: make the stream's device current for the query
+    int cur = -1;
+    e = hipGetDevice(&cur);
+    if (e == hipSuccess && cur != dev) e = hipSetDevice(dev);
     void* ptr = nullptr;
-    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch));
+    if (e == hipSuccess) e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch));
+    if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
     if (e != hipSuccess || !ptr) {
       set_error("decode_attention_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
       return MI355_ERR_LAUNCH;
@@ -2130,9 +2141,11 @@ int mi355_decode_attention_static(const void* q, const void* k_buffer, const voi
                                   int num_splits, int64_t bs, int hq, int hkv, int head_dim, int v_head_dim,
                                   int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap, int dtype,
                                   void* stream) {
-  MI355_REQUIRE(bs >= 0 && hq > 0 && v_head_dim > 0 && num_splits >= 1, MI355_ERR_INVALID,
-                "decode_attention_static: bad shape bs=%lld hq=%d Dv=%d splits=%d", (long long)bs, hq, v_head_dim,
-                num_splits);
+  // bounded before any size arithmetic: the products below then stay far inside int64
+  MI355_REQUIRE(bs >= 0 && bs <= 65535 && hq > 0 && hq <= 65535 && v_head_dim > 0 && v_head_dim <= 1024 &&
+                    num_splits >= 1 && num_splits <= MI355_MAX_KV_SPLITS,
+                MI355_ERR_INVALID, "decode_attention_static: bad shape bs=%lld hq=%d Dv=%d splits=%d", (long long)bs, hq,
+                v_head_dim, num_splits);
   // partial outputs [bs, hq, splits, Dv] followed by log-sum-exps [bs, hq, splits], the latter
   // starting on a 256-byte boundary
   const int64_t n_o = bs * hq * (int64_t)num_splits * v_head_dim;
@@ -2145,7 +2158,7 @@ int mi355_decode_attention_static(const void* q, const void* k_buffer, const voi
                 (long long)MI355_DECODE_STATIC_SCRATCH_BYTES);
   float* base = nullptr;
   if (num_splits > 1) {
-    const int rc = static_scratch_ptr(&base);
+    const int rc = static_scratch_ptr((hipStream_t)stream, &base);
     if (rc != MI355_OK) return rc;
   }
   // Every (sequence, head, split) cell is written by stage 1 before stage 2 reads it (an empty
@@ -2219,10 +2232,8 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
   fz.cache_f32 = cache_dtype == MI355_F32;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  g_kv8 = kv8;
-  if (dtype == MI355_BF16) rc = launch_decode_fused<bf16_t>((const bf16_t*)k_buffer, (const bf16_t*)v_buffer, (bf16_t*)o, p, fz, bs, st);
-  else rc = launch_decode_fused<f16_t>((const f16_t*)k_buffer, (const f16_t*)v_buffer, (f16_t*)o, p, fz, bs, st);
-  g_kv8 = false;
+  if (dtype == MI355_BF16) rc = launch_decode_fused<bf16_t>((const bf16_t*)k_buffer, (const bf16_t*)v_buffer, (bf16_t*)o, p, fz, bs, kv8, st);
+  else rc = launch_decode_fused<f16_t>((const f16_t*)k_buffer, (const f16_t*)v_buffer, (f16_t*)o, p, fz, bs, kv8, st);
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("decode_attention_fused_qkv");
   return MI355_OK;

@@ -816,12 +816,11 @@ int g_extend_variant = 0;
 #else
 static constexpr int g_extend_variant = 0;
 #endif
-static thread_local bool g_ext_kv8 = false;   // fp8 KV cache, set by the entry point around one launch
 
 template <typename T>
 static int launch_extend(const void* q, const void* k, const void* v, void* o, const void* kb,
                          const void* vb, const ExtendParams& p, int64_t bs, int64_t max_len_extend,
-                         hipStream_t st) {
+                         bool kv8, hipStream_t st) {   // kv8: the KV cache holds e4m3fn bytes
   constexpr int VE = V16<T>::n;
   const int dmax = p.D > p.Dv ? p.D : p.Dv;
   const bool vec = p.D % VE == 0 && p.Dv % VE == 0 && p.q_stride % VE == 0 &&
@@ -836,7 +835,7 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
       const int64_t wgs = 8 * ((npairs + 7) / 8) * (p.hq / p.hkv) * nqb;
       if (wgs < (int64_t)1 << 31) {
         const dim3 grid1((unsigned)wgs);
-        if (g_ext_kv8)
+        if (kv8)
           hipLaunchKernelGGL((extend_attn_mfma32_kernel<T, true>), grid1, dim3(256), 0, st, (const T*)q, (const T*)k,
                              (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p, nqb, (int)npairs);
         else
@@ -847,7 +846,7 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
     }
     if (vec && p.D == 128 && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 && p.logit_cap <= 0.f) {
       const dim3 grid((unsigned)((max_len_extend + 63) / 64), (unsigned)p.hq, (unsigned)bs);
-      if (g_ext_kv8)
+      if (kv8)
         hipLaunchKernelGGL((extend_attn_mfma_kernel<T, true>), grid, dim3(256), 0, st, (const T*)q, (const T*)k,
                            (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p);
       else
@@ -856,7 +855,7 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
       return MI355_OK;
     }
   }
-  if (g_ext_kv8) {
+  if (kv8) {
     set_error("extend_attention: an fp8 KV cache needs head_dim 128, a 16-bit dtype, a causal or full mask, "
               "no sliding window and no logit cap");
     return MI355_ERR_UNSUPPORTED;
@@ -925,12 +924,11 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
   p.sm_scale = sm_scale;
   p.logit_cap = logit_cap;
   int rc = MI355_OK;
-  g_ext_kv8 = (dtype & MI355_KV_FP8) != 0;
+  const bool kv8 = (dtype & MI355_KV_FP8) != 0;
   dtype &= 0xff;
   MI355_DISPATCH_DTYPE(dtype, "extend_attention",
                        rc = launch_extend<T>(q_extend, k_extend, v_extend, o_extend, k_buffer,
-                                             v_buffer, p, bs, max_len_extend, (hipStream_t)stream));
-  g_ext_kv8 = false;
+                                             v_buffer, p, bs, max_len_extend, kv8, (hipStream_t)stream));
   if (rc != MI355_OK) return rc;
   MI355_CHECK_LAUNCH("extend_attention");
   return MI355_OK;

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(T* __restrict__ out,
 // (python/sglang/srt/layers/logits_processor.py:579-604).  The exponent is clamped at 40: beyond
 // |y| = 10 the quotient is +-1 in fp32, and without the clamp e^{2y} overflows to inf / inf.
 __device__ __forceinline__ float softcap_one(float x, float cap) {
-  const float y = fminf(2.f * (x / cap), 40.f);
+  const float y2 = 2.f * (x / cap);
+  const float y = y2 > 40.f ? 40.f : y2;   // not fminf: a NaN logit must stay NaN (fminf would turn it into +cap)
   const float e = expf(y);
   return (e - 1.f) / (e + 1.f) * cap;
 }

@@ -231,7 +231,10 @@ class CustomAllreduce:
         _lib.check(self._lib.mi355_ar_set_timeout_ms(self._comm, int(ms)), "mi355_ar_set_timeout_ms")
 
     def check_status(self, wait: bool = True) -> None:
-        """Raises if any barrier wait has timed out.  wait=True synchronises the current stream first;
+        """Raises if any barrier wait has timed out.  A raised status is terminal for this communicator:
+        the counter is never reset (the ranks' barrier epochs no longer agree after a timeout), so the
+        owner must close() it and build a new one, or fall back to the process group's collectives.
+        wait=True synchronises the current stream first;
         wait=False reads the counter beside whatever is running (the caller has already waited for the
         work it asks about)."""
         if wait:

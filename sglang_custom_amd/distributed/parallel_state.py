@@ -87,6 +87,21 @@ def check_collectives(wait: bool = True) -> None:
         _CA_COMM.check_status(wait)
 
 
+def tp_barrier() -> None:
+    """Host-side barrier over the TP ranks (no-op for one rank or a simulated shard).  Used before
+    phases whose first device collective must not find the ranks seconds apart -- the warm-up runs
+    of graph capture above all: the custom collectives give up after a bounded wait, and a timeout
+    raises their status word for good (there is no reset; the process group has to be rebuilt)."""
+    if _TP_SIZE == 1 or _SIMULATED or _TP_GROUP is None:
+        return
+    if _CA_COMM is not None and not _CA_COMM.disabled:
+        dist.barrier(group=_CA_COMM.group)      # the CPU side group: no device work queued
+    elif _BACKEND == "gloo":
+        dist.barrier(group=_TP_GROUP)
+    else:
+        dist.barrier(group=_TP_GROUP, device_ids=[torch.cuda.current_device()])
+
+
 _SIMULATED = False
 
 

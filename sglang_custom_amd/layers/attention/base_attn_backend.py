@@ -46,3 +46,17 @@ class AttentionBackend(ABC):
 
     def support_triton(self):
         return False
+
+    # ---- extension beyond the reference's surface (optional; the default declines) ----
+    @staticmethod
+    def supports_fused_qkv(layer, rotary_emb, dtype) -> bool:
+        """Whether forward_decode_fused_qkv (decode attention straight from the qkv projection's
+        split-K partial sums: reduction, RoPE, KV-cache write and attention in one launch) serves this
+        layer.  Backends that do not have it inherit this False and the model takes the plain
+        qkv -> rotary_emb -> forward_decode sequence."""
+        return False
+
+    def forward_decode_fused_qkv(self, qkv_part, positions, cos_sin_cache, layer, forward_batch,
+                                 part_x_scale=None, part_w_scale=None, out_dtype=None):
+        raise NotImplementedError()
+

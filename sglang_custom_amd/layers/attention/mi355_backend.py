@@ -70,6 +70,7 @@ class Mi355AttnBackend(AttentionBackend):
         self._lse = None
         self._tickets = None
         self._retired = []      # outgrown scratch: captured graphs may still point into it
+        self._retired_tickets = []   # outgrown counter arrays, for the same reason; cleared with the live one
         self._dummy_idx = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.graph_num_splits = {}
         self.graph_window_indptr = None
@@ -86,7 +87,8 @@ class Mi355AttnBackend(AttentionBackend):
         if self._tickets is None or self._tickets.numel() < bs * self.num_head:
             # one counter per (sequence, head); the kernels hand them back zeroed.  An outgrown array
             # stays alive: captured graphs may still point into it.
-            self._retired.append(self._tickets)
+            if self._tickets is not None:
+                self._retired_tickets.append(self._tickets)
             self._tickets = torch.zeros(max(bs * self.num_head, 1024), dtype=torch.int32, device=self.device)
         return self._logits, self._lse
 
@@ -192,6 +194,9 @@ class Mi355AttnBackend(AttentionBackend):
         fire.  One small fill per forward makes the next step start clean whatever happened before."""
         if splits > 1 and self._tickets is not None:
             self._tickets.zero_()
+            # graphs captured before the array was outgrown still count in the old one
+            for t in self._retired_tickets:
+                t.zero_()
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1

@@ -54,6 +54,8 @@ class HipGraphRunner:
             token_to_kv_pool=mr.token_to_kv_pool, attn_backend=mr.attn_backend)
 
     def capture(self):
+        from ..distributed.parallel_state import check_collectives, tp_barrier
+
         mr = self.model_runner
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
@@ -63,6 +65,11 @@ class HipGraphRunner:
                 mr.attn_backend.init_forward_metadata_capture_cuda_graph(
                     bs, bs, fb.req_pool_indices, fb.seq_lens, None, ForwardMode.DECODE, None)
                 run = lambda: mr.model.forward(fb.input_ids, fb.positions, fb).next_token_logits
+                # ranks reach this point at different times (one may still be compiling or paging in the
+                # library); line them up on the host so that the first collective of the warm-up runs does
+                # not spend its bounded wait on that skew
+                torch.cuda.current_stream().synchronize()
+                tp_barrier()
                 for _ in range(2):  # warm-up: grow every workspace before capture
                     run()
                 torch.cuda.current_stream().synchronize()
@@ -76,8 +83,6 @@ class HipGraphRunner:
         torch.cuda.synchronize()
         # ranks capture at different speeds: a collective of the warm-up runs that gave up waiting
         # for a slow peer must fail here, not as wrong tokens later
-        from ..distributed.parallel_state import check_collectives
-
         check_collectives()
 
     def replay(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:

@@ -108,7 +108,7 @@ class LlamaAttention(nn.Module):
         the reduction, RoPE, the KV-cache write and the attention.  None when it does not apply."""
         backend = forward_batch.attn_backend
         pool = forward_batch.token_to_kv_pool
-        if (not forward_batch.forward_mode.is_decode() or not hasattr(backend, "forward_decode_fused_qkv")
+        if (not forward_batch.forward_mode.is_decode()
                 or getattr(pool, "dtype", None) not in (hidden_states.dtype, torch.float8_e4m3fn)
                 or not backend.supports_fused_qkv(self.attn, self.rotary_emb, hidden_states.dtype)):
             return None
@@ -139,7 +139,7 @@ class LlamaAttention(nn.Module):
         rope = self.rotary_emb
         ops = get_ops()
         n_tiles = ((m + 255) // 256) * (w.shape[0] // 256)
-        if (kb.dtype != x.dtype or n_tiles < PREFILL_QKV_MIN_TILES or not hasattr(ops, "qkv_proj_rope_tiled")
+        if (kb.dtype != x.dtype or n_tiles < PREFILL_QKV_MIN_TILES
                 or not ops.qkv_proj_rope_tiled_supported(m, k, self.num_heads, self.num_kv_heads, self.head_dim,
                                                          rope.cos_sin_cache.shape[1], rope.is_neox_style, x.dtype, fp8)):
             return None

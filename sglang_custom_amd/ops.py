@@ -290,18 +290,26 @@ def _tickets(t, need: int):
     """Device pointer of the split-merge arrival counters (None: the splits are merged by a second launch)."""
     if t is None:
         return None
-    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() >= need
+    if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() >= need):
+        raise _lib.Mi355Error(f"split tickets must be >= {need} contiguous int32 counters on the GPU")
     return t.data_ptr()
 
 
 def _split_scratch(attn_logits, attn_lse, rows: int, dv: int, splits: int) -> None:
     """The kernels write rows * splits partial outputs of dv floats and as many log-sum-exps: refuse a
-    scratch pair that cannot hold them (the C ABI sees raw pointers and cannot)."""
-    if splits > 1:
-        assert attn_logits is not None and attn_lse is not None, "num_kv_splits > 1 needs attn_logits / attn_lse"
-        assert attn_logits.is_cuda and attn_lse.is_cuda and attn_logits.dtype == attn_lse.dtype == torch.float32
-        assert attn_logits.numel() >= rows * splits * dv and attn_lse.numel() >= rows * splits, \
-            f"split scratch too small for {rows} rows x {splits} splits x {dv}"
+    scratch pair that cannot hold them (the C ABI sees raw pointers and cannot).  Raises Mi355Error
+    before anything is launched; not an assert, so that `python -O` keeps the refusal."""
+    if splits <= 1:
+        return
+    if attn_logits is None or attn_lse is None:
+        raise _lib.Mi355Error(f"num_kv_splits = {splits} needs attn_logits / attn_lse scratch")
+    if not (attn_logits.is_cuda and attn_lse.is_cuda and attn_logits.dtype == attn_lse.dtype == torch.float32
+            and attn_logits.is_contiguous() and attn_lse.is_contiguous()):
+        raise _lib.Mi355Error("split scratch must be contiguous float32 tensors on the GPU")
+    if attn_logits.numel() < rows * splits * dv or attn_lse.numel() < rows * splits:
+        raise _lib.Mi355Error(
+            f"split scratch too small for {rows} rows x {splits} splits x {dv}: attn_logits holds "
+            f"{attn_logits.numel()} floats (needs {rows * splits * dv}), attn_lse {attn_lse.numel()} (needs {rows * splits})")
 
 
 def decode_num_splits(bs: int, hkv: int, max_seq_len: int, max_splits: int) -> int:
@@ -321,9 +329,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
     assert kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
     assert num_kv_splits <= max_kv_splits
-    if num_kv_splits > 1:
-        assert attn_logits.dtype == torch.float32 and attn_lse.dtype == torch.float32
-        assert attn_logits.numel() >= B * Hq * num_kv_splits * Dv and attn_lse.numel() >= B * Hq * num_kv_splits
+    _split_scratch(attn_logits, attn_lse, B * Hq, Dv, num_kv_splits)
     check(_lib_().mi355_decode_attention(
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         kv_indices.data_ptr(), 1, None, None, kv_indptr.data_ptr(), 0, _p(attn_logits),

@@ -156,3 +156,9 @@ def alloc_extend_pages(prefix_lens, seq_lens, last_loc, free_pages, page_size, e
 def alloc_decode_pages(seq_lens, last_loc, free_pages, page_size):
     return ops_ref.alloc_decode_pages(seq_lens, last_loc, free_pages, page_size)
 
+
+def qkv_proj_rope_tiled_supported(m, k, num_heads, num_kv_heads, head_dim, rotary_dim, is_neox, dtype, fp8):
+    """The fused prefill projection + RoPE + cache write is a GPU kernel only: the double declines and the
+    model takes the unfused sequence, which is what the oracle restates."""
+    return False
+

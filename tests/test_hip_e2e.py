@@ -445,8 +445,7 @@ def test_real_shape_llama_1b_fp32_128_in_128_out(graphs):
     scaling; one request, 128-token prompt, 128 greedy tokens) in fp32 against the reference's CPU run:
     under teacher forcing every one of the 128 steps reproduces the reference's five largest logits to
     1e-3 (prefill and last step: all 128256 logits) and its token wherever the top-2 margin exceeds
-    2e-3; free-running, the runs may only part at a step where the reference itself was within 2e-3
-    of a tie (with 128256 near-Gaussian logits that happens about once in a hundred steps)."""
+    2e-3; free-running, all 128 greedy tokens equal the reference's."""
     name, preset, dtn, lens, steps = [c for c in cases.E2E_LONG_CASES if c[2] == "f32"][0]
     g = load_e2e(preset, dtn)
     mr = _real_shape_runner(preset, dtn, graphs)
@@ -461,8 +460,10 @@ def test_real_shape_llama_1b_fp32_128_in_128_out(graphs):
         assert logits[s].max().item() <= tv[0, s, 0].item() + 1e-3, s
         if tv[0, s, 0] - tv[0, s, 1] > 2e-3:
             assert toks[0, s] == ref_toks[0, s], s
+    # free-running: token for token over all 128 steps (observed on MI355X, eager and graph), asserted as such
     free, _, _, _ = run_steps(mr, prompts, steps)
-    _first_divergence_is_a_near_tie(free, ref_toks, tv, ti, steps, 2e-3)
+    assert torch.equal(free[:, :steps].cpu(), ref_toks[:, :steps].cpu()), \
+        f"free-running fp32 parts from the reference at step {int((free[0] != ref_toks[0]).nonzero()[0])}"
 
 
 @pytest.mark.parametrize("graphs", [False, True])
@@ -472,8 +473,9 @@ def test_real_shape_llama_1b_bf16_128_in_128_out(graphs):
     0.10 at worst (0.024 rms) on the prefill logits.  The bar here is that distance: the GPU's bf16
     logits must be no further from the reference's fp32 logits than 1.5x what the reference's own bf16
     logits are (worst case and rms), and under teacher forcing each step's reference top-5 logits are
-    reproduced within 1.5x that worst case.  Free-running, the first divergence must be a near-tie by
-    the same measure."""
+    reproduced within 1.5x that worst case.  Free-running, bf16 does NOT stay token for token: the runs
+    part early (step 3 eager, step 5 under the graph on MI355X, whose fused decode launch rounds in other
+    places) and the test requires that first divergence to be a near-tie of the reference by the same measure."""
     name, preset, dtn, lens, steps = [c for c in cases.E2E_LONG_CASES if c[2] == "bf16"][0]
     g, g32 = load_e2e(preset, "bf16"), load_e2e(preset, "f32")
     truth = t(g32["e2e/llama1b_f32/prefill_logits"])

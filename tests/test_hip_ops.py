@@ -1012,6 +1012,14 @@ def test_final_logit_softcap(ops):
         assert torch.isfinite(got).all()
         assert (got - ops_ref.softcap(x, cap)).abs().max().item() <= 4e-6 * cap
         assert (got.double() - cap * torch.tanh(x.double() / cap)).abs().max().item() <= 1e-6 * cap
+    # a NaN logit stays NaN (the reference's kernel and the oracle keep it; a barrier timeout of the custom
+    # all-reduce poisons its output with NaN and that poison must not turn into a valid +cap logit); infinities saturate
+    x = torch.tensor([float("nan"), 1.0, float("inf"), float("-inf"), float("nan"), 2.0, -3.0])
+    got = ops.softcap_inplace(x.clone().to(DEV), 30.0).cpu()
+    want = ops_ref.softcap(x, 30.0)
+    assert torch.isnan(want[[0, 4]]).all() and torch.isnan(got[[0, 4]]).all()
+    assert got[2].item() == 30.0 and got[3].item() == -30.0
+    assert (got[[1, 5, 6]] - want[[1, 5, 6]]).abs().max().item() <= 4e-6 * 30
     V, H = 1000, 64
     w = (torch.randn((V, H), generator=g) * 0.5).to(DEV)
     h = (torch.randn((5, H), generator=g) * 4.0).to(DEV)

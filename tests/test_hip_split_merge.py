@@ -196,3 +196,60 @@ def test_mla_in_kernel_merge_equals_merge_launch(ops, dtn):
             assert not torch.isnan(got.float()).any(), (dtn, H, splits, rep)
             assert torch.equal(_bits(got), _bits(want)), (dtn, H, splits, rep, (got.float() - want.float()).abs().max().item())
             assert int(tickets.abs().sum()) == 0
+
+
+def test_undersized_split_scratch_is_refused_before_any_launch(ops):
+    """Every decode-attention wrapper refuses a scratch pair one element short of rows x splits x Dv (and one
+    log-sum-exp short) with Mi355Error, launches nothing (the output keeps its fill), and keeps refusing
+    under `python -O` because the check is not an assert."""
+    from sglang_custom_amd._lib import Mi355Error
+
+    dt, D, Hq, Hkv, splits = torch.bfloat16, 128, 8, 2, 4
+    lens = [200, 31]
+    B = len(lens)
+    q, kc, vc, r2t, pool, lt = (x.to(DEV) for x in _paged(900, dt, B, Hq, Hkv, D, lens))
+    need_o, need_l = B * Hq * splits * D, B * Hq * splits
+    full_o = torch.zeros(need_o, dtype=torch.float32, device=DEV)
+    full_l = torch.zeros(need_l, dtype=torch.float32, device=DEV)
+    indptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    indptr[1:] = torch.cumsum(lt, 0)
+    indices = torch.cat([r2t[pool[b], : lens[b]] for b in range(B)]).contiguous()
+    # fused launch inputs
+    n = (Hq + 2 * Hkv) * D
+    part = torch.zeros(2, B, n, dtype=torch.float32, device=DEV)
+    cache = torch.zeros(256, D, dtype=torch.float32, device=DEV)
+    loc = torch.stack([r2t[pool[b], lens[b] - 1] for b in range(B)]).to(torch.int64)
+    # MLA inputs
+    rank, rope, H = 512, 64, 16
+    kvb = torch.zeros(kc.shape[0], 1, rank + rope, dtype=dt, device=DEV)
+    qm = torch.zeros(B, H, rank + rope, dtype=dt, device=DEV)
+    om = torch.full((B, H, rank), 7.0, dtype=dt, device=DEV)
+    mla_o = torch.zeros(B * H * splits * rank, dtype=torch.float32, device=DEV)
+    mla_l = torch.zeros(B * H * splits, dtype=torch.float32, device=DEV)
+
+    o = torch.full((B, Hq, D), 7.0, dtype=dt, device=DEV)
+    calls = {
+        "paged": lambda a, l: ops.decode_attention_paged(q, kc, vc, o, r2t, pool, lt, a, l, splits, D ** -0.5),
+        "fwd": lambda a, l: ops.decode_attention_fwd(q, kc, vc, o, indptr, indices, a, l, splits, 8, D ** -0.5),
+        "fused": lambda a, l: ops.decode_attention_fused_qkv(part, lt - 1, loc, cache, kc, vc, o, r2t, pool, lt, a, l,
+                                                             splits, D ** -0.5),
+    }
+    for name, call in calls.items():
+        for a, l in ((full_o[:-1], full_l), (full_o, full_l[:-1]), (None, None), (full_o.double(), full_l.double())):
+            with pytest.raises(Mi355Error):
+                call(a, l)
+        torch.cuda.synchronize()
+        assert bool((o == 7.0).all()), f"{name}: something was launched despite the refusal"
+    for a, l in ((mla_o[:-1], mla_l), (mla_o, mla_l[:-1]), (None, None)):
+        with pytest.raises(Mi355Error):
+            ops.decode_attention_mla(qm, kvb, om, r2t, pool, lt, a, l, splits, rank, (rank + rope) ** -0.5)
+    torch.cuda.synchronize()
+    assert bool((om == 7.0).all())
+    # a counter array too short for rows x heads is refused the same way
+    with pytest.raises(Mi355Error):
+        ops.decode_attention_paged(q, kc, vc, o, r2t, pool, lt, full_o, full_l, splits, D ** -0.5,
+                                   tickets=torch.zeros(B * Hq - 1, dtype=torch.int32, device=DEV))
+    # the exact size is accepted
+    ops.decode_attention_paged(q, kc, vc, o, r2t, pool, lt, full_o, full_l, splits, D ** -0.5)
+    torch.cuda.synchronize()
+    assert not bool((o == 7.0).all())
