@@ -65,6 +65,11 @@ def parse_args():
     ap.add_argument("--prefill-gemm", default=None, choices=["auto", "library", "tiled"],
                     help="prefill (M > 64) 16-bit GEMMs: auto (default: hand-written gate_up with fused SiLU-mul, "
                          "hipBLASLt elsewhere), the hand-written 256x256-tile kernel everywhere, or hipBLASLt everywhere")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank runs on GPU 0 (process group on gloo, since RCCL "
+                         "refuses two ranks per device; the one-launch collectives 'on' with their self-test "
+                         "against that group).  Exercises spawn -> TP model -> graph capture -> timed loop -> "
+                         "the collectives object; its tok/s is NOT a multi-GPU number and the line says so")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous rehearsal without a GPU: every rank joins a gloo group, meets at the "
                          "barriers and rank 0 prints the line's bookkeeping fields (value null)")
@@ -120,11 +125,13 @@ def gemm_shapes(cfg, tp):
     return [((hq + 2 * hkv) * d, h), (h, hq * d), (2 * inter, h), (h, inter)]
 
 
-def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
-    """Average duration of the decode projection kernel (gemm_ring_kernel) over one step's worth
-    of launches -- every layer's real weights in order, M = bs, through the same call the model
-    makes -- bracketed by HIP events on the stream the kernels are launched on."""
-    from sglang_custom_amd.layers.quantization.unquant import decode_linear, decode_linear_deferred, gate_up_silu_mul
+def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes, quant=None):
+    """Average duration of the decode projection kernel (gemm_ring_kernel; its fp8 instances under
+    w8a8_fp8) over one step's worth of launches -- every layer's real weights in order, M = bs, through
+    the same call the model makes -- bracketed by HIP events on the stream the kernels are launched on."""
+    from sglang_custom_amd.layers.quantization.unquant import (QuantizedAct, decode_linear, decode_linear_deferred,
+                                                              gate_up_silu_mul)
+    from sglang_custom_amd.ops_backend import get_ops
 
     dev = mr.device
     layers = mr.model.model.layers
@@ -132,19 +139,33 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
     x_attn = torch.randn(bs, layers[0].self_attn.o_proj.weight.shape[1], device=dev).to(mr.dtype)
     x_mlp = torch.randn(bs, layers[0].mlp.down_proj.weight.shape[1], device=dev).to(mr.dtype)
     head = mr.model.lm_head
+    if quant == "w8a8_fp8":
+        # the decode path hands the fp8 projections rows that their producers already quantised
+        ops = get_ops()
+        q_h, q_attn, q_mlp = (QuantizedAct(*ops.per_token_quant_fp8(x), mr.dtype) for x in (x_h, x_attn, x_mlp))
 
     def proj(layer, x, needs_all_reduce=True):
         # the call the decode path makes: split-K partials left to the consuming kernel when the
         # layer qualifies, the in-kernel combine otherwise
         if decode_linear_deferred(layer, x, needs_all_reduce=needs_all_reduce) is None:
-            decode_linear(layer, x, None)
+            if isinstance(x, QuantizedAct):
+                layer.quant_method.apply(layer, x, None)
+            else:
+                decode_linear(layer, x, None)
 
     def one_pass():
         for layer in layers:
-            proj(layer.self_attn.qkv_proj, x_h, needs_all_reduce=False)
-            proj(layer.self_attn.o_proj, x_attn)
-            gate_up_silu_mul(layer.mlp.gate_up_proj, layer.mlp.act_fn, x_h)
-            proj(layer.mlp.down_proj, x_mlp)
+            if quant == "w8a8_fp8":
+                proj(layer.self_attn.qkv_proj, q_h, needs_all_reduce=False)
+                proj(layer.self_attn.o_proj, q_attn)
+                gu = layer.mlp.gate_up_proj
+                gu.quant_method.apply(gu, q_h, None)
+                proj(layer.mlp.down_proj, q_mlp)
+            else:
+                proj(layer.self_attn.qkv_proj, x_h, needs_all_reduce=False)
+                proj(layer.self_attn.o_proj, x_attn)
+                gate_up_silu_mul(layer.mlp.gate_up_proj, layer.mlp.act_fn, x_h)
+                proj(layer.mlp.down_proj, x_mlp)
         decode_linear(head, x_h, None, out_dtype=torch.float32)
 
     stream = torch.cuda.current_stream()
@@ -164,10 +185,15 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
     torch.cuda.synchronize()
     launches = 4 * len(layers) + 1
     total_ms = e0.elapsed_time(e1) / reps
-    wbytes, _ = weight_bytes_per_step(cfg, tp, dtype_bytes, None)
-    # algorithmic bytes: weights once + activations in/out (small)
-    act = sum(bs * (n + k) * dtype_bytes for (n, k) in gemm_shapes(cfg, tp)) * len(layers) \
+    wbytes, _ = weight_bytes_per_step(cfg, tp, dtype_bytes, quant)
+    # algorithmic bytes: weights once (fp8: one byte each, plus the per-channel scales) + activations in
+    # (fp8: one byte each plus per-token scales) / out (16-bit, or fp32 partial sums are NOT counted: they are
+    # this implementation's choice, not the algorithm's)
+    in_b = 1 if quant == "w8a8_fp8" else dtype_bytes
+    act = sum(bs * (k * in_b + n * dtype_bytes) for (n, k) in gemm_shapes(cfg, tp)) * len(layers) \
         + bs * (cfg["hidden_size"] * dtype_bytes + cfg["vocab_size"] // tp * 4)
+    if quant == "w8a8_fp8":
+        act += sum(4 * (n + bs) for (n, _) in gemm_shapes(cfg, tp)) * len(layers)
     bytes_per_launch = (wbytes + act) / launches
     dur_s = total_ms * 1e-3 / launches
     return dict(kernel="gemm_ring_kernel", launches_per_step=launches,
@@ -175,7 +201,7 @@ def measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes):
                 achieved_gbs=bytes_per_launch / dur_s / 1e9)
 
 
-def committed_pmc_traffic(kernel: str):
+def committed_pmc_traffic(kernel: str, quant=None):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc FETCH_SIZE pass
     over this same command (profiles/rNN_pmc_fetch.csv, already x2-corrected for gfx950's 64-B
     tally of 128-B requests).  PMC counters cannot be read from inside the process, so this is the
@@ -183,7 +209,7 @@ def committed_pmc_traffic(kernel: str):
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_fp8.csv" if quant else "r*_pmc_fetch.csv")))
     if not files:
         return None, None
     tot = n = 0
@@ -195,9 +221,10 @@ def committed_pmc_traffic(kernel: str):
     return (int(tot / n), os.path.basename(files[-1])) if n else (None, None)
 
 
-def cpu_baseline(cfg, bs, ctx, dtype):
+def cpu_baseline(cfg, bs, ctx, dtype, quant=None):
     """Oracle decode step on the host cores: time `nl` layers + the LM head and scale to the full
-    depth (every layer does identical work)."""
+    depth (every layer does identical work).  quant = "w8a8_fp8": the oracle's fp8 W8A8 linears (per-token
+    quantisation, fp8 x fp8 products in fp32, scales), the reference's non-CUDA apply_fp8_linear branch."""
     from oracle.llama_ref import OracleLlama
     from oracle import ops_ref
 
@@ -211,7 +238,8 @@ def cpu_baseline(cfg, bs, ctx, dtype):
     for name, shape in llama_param_shapes(small).items():
         w[name] = (torch.randn(shape, dtype=torch.bfloat16) * 0.02).to(dtype) if len(shape) > 1 \
             else torch.ones(shape, dtype=dtype)
-    m = OracleLlama(small, w, dtype, max_total_tokens=bs * (ctx + 16), max_reqs=bs, context_len=ctx + 24)
+    m = OracleLlama(small, w, dtype, max_total_tokens=bs * (ctx + 16), max_reqs=bs, context_len=ctx + 24,
+                    fp8_w8a8=quant == "w8a8_fp8")
     # fill the cache as if `ctx` tokens per request were already there (contents are irrelevant
     # to the timing): allocate slots and table entries without running a prefill
     m.req_pool_indices = torch.arange(bs, dtype=torch.int64)
@@ -248,7 +276,7 @@ def cpu_baseline(cfg, bs, ctx, dtype):
     lo, hi = bs / scaled(max(t_steps)), bs / scaled(min(t_steps))
     return dict(value=round(bs / full, 2), unit="tok/s", cores=threads, kind="port",
                 spread=[round(lo, 2), round(hi, 2)],
-                sample=f"oracle decode step bs={bs} ctx={ctx}: {nl} of {L} layers + LM head, median of {reps} runs "
+                sample=f"oracle {'fp8-W8A8 ' if quant else ''}decode step bs={bs} ctx={ctx}: {nl} of {L} layers + LM head, median of {reps} runs "
                        f"({(statistics.median(t_steps) - t_head) / nl * 1e3:.0f} ms/layer, LM head {t_head * 1e3:.0f} ms) on "
                        f"{threads} threads, scaled to {L} layers; spread = slowest..fastest run")
 
@@ -298,6 +326,11 @@ def main():
                   flush=True)
         dist.destroy_process_group()
         return
+    share = bool(args.ranks_share_gpu and world > 1)
+    if share:
+        if args.parallelism != "tp":
+            sys.exit("--ranks-share-gpu rehearses the tensor-parallel branch only")
+        local_rank = 0          # every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     tp = world if (args.parallelism == "tp" and world > 1) else 1
     sim = args.simulate_tp if (args.simulate_tp > 1 and world == 1) else 0
@@ -319,19 +352,18 @@ def main():
                     quantization=args.quantization, random_seed=rank if tp == 1 else 0,
                     simulate_tp_shard=bool(sim), kv_cache_dtype=args.kv_cache_dtype,
                     disable_custom_all_reduce=args.custom_all_reduce == "off",
-                    custom_all_reduce_self_test=args.custom_all_reduce == "auto")
+                    custom_all_reduce_self_test=args.custom_all_reduce == "auto",
+                    # a failed graph capture (collectives inside a capture can fail on a machine this build has not
+                    # seen) means eager launches on the SAME runner, decided by all ranks together
+                    graph_capture_fallback=True,
+                    # two ranks on one device: RCCL refuses, so the process group is gloo (device tensors staged
+                    # through the host) and the one-launch collectives carry the decode step
+                    dist_backend="gloo" if share else None)
     mc = ModelConfig(cfg, dtype=args.dtype, context_length=in_len + out_len + 16)
-    graph_ok = True
-    try:
-        mr = ModelRunner(mc, sa, gpu_id=local_rank, tp_rank=rank if tp > 1 else 0, tp_size=tp)
-    except Exception as e:  # graph capture of collectives can fail: fall back to eager launches
-        if args.no_graph:
-            raise
-        print(f"[bench] HIP-graph capture failed ({e!r}); running eager", file=sys.stderr)
-        sa.disable_cuda_graph = True
-        graph_ok = False
-        mr = ModelRunner(mc, sa, gpu_id=local_rank, tp_rank=rank if tp > 1 else 0, tp_size=tp)
-    graph_ok = graph_ok and mr.graph_runner is not None
+    mr = ModelRunner(mc, sa, gpu_id=local_rank, tp_rank=rank if tp > 1 else 0, tp_size=tp)
+    if mr.graph_capture_error and rank == 0:
+        print(f"[bench] HIP-graph capture failed ({mr.graph_capture_error}); running eager", file=sys.stderr)
+    graph_ok = mr.graph_runner is not None
 
     def barrier():
         if world > 1:
@@ -364,7 +396,7 @@ def main():
         next_ids, _ = bob.decode(next_ids, batch, mr)
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device="cuda")
+    t = torch.tensor([elapsed], device="cpu" if (world > 1 and dist.get_backend() == "gloo") else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -395,6 +427,7 @@ def main():
                                f"greedy, context {in_len + args.warmup}..{in_len + args.warmup + args.steps}",
                    "global_batch": bs * replicas, "seq_len": in_len,
                    "parallelism": (f"ONE shard of tp{tp}, collectives stubbed (not a job-level number)" if sim else
+                                   f"tp{tp} REHEARSAL: all {world} ranks share GPU 0 (not a multi-GPU number)" if share else
                                    f"tp{tp}" if tp > 1 else (f"dp{world}" if world > 1 else "tp1")),
                    "hip_graph": bool(graph_ok)},
         "ttft_p50_ms": round(ttft * 1e3, 2),
@@ -417,10 +450,10 @@ def main():
                               "ranks": world, "all_reduces_per_step": n_ar,
                               "all_reduce_message_bytes": bs * cfg["hidden_size"] * dtype_bytes,
                               "all_gather_bytes_per_rank": bs * (cfg["vocab_size"] // tp) * dtype_bytes}
-    if rank == 0 and not args.no_roofline and args.quantization is None:
+    if rank == 0 and not args.no_roofline:
         # rank 0's shard: the projection kernels launch no collective, so measuring on one rank is safe
-        k = measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes)
-        traffic, traffic_src = committed_pmc_traffic(k["kernel"]) if tp == 1 else (None, None)
+        k = measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes, args.quantization)
+        traffic, traffic_src = committed_pmc_traffic(k["kernel"], args.quantization) if tp == 1 else (None, None)
         out["roofline"] = {"bound": "hbm", "achieved": round(k["achieved_gbs"], 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(k["achieved_gbs"] / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_source": traffic_src, "kernel": k["kernel"],
@@ -431,7 +464,8 @@ def main():
         del mr
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(cfg, bs, in_len + args.warmup + args.steps // 2,
-                                           torch.bfloat16 if args.dtype == "bfloat16" else torch.float32)
+                                           torch.bfloat16 if args.dtype == "bfloat16" else torch.float32,
+                                           args.quantization)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 and dist.is_initialized():

@@ -15,6 +15,7 @@ _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANK = 0
 _TP_SIZE = 1
 _CA_COMM = None      # CustomAllreduce over the TP group, when enabled
+_CPU_GROUP: Optional[dist.ProcessGroup] = None   # gloo group of the same ranks: host-side agreement, no device work
 _CA_STATE = "off"
 _BACKEND = "nccl"
 
@@ -28,20 +29,25 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: st
     limit (the reference's GroupCoordinator does the same, parallel_state.py:285-297); handles are
     exchanged over a gloo group created beside the device group.  All ranks must be in one node.
     custom_all_reduce_self_test: keep those kernels only if CustomAllreduce.self_test passes."""
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM, _BACKEND, _CA_STATE
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM, _BACKEND, _CA_STATE, _CPU_GROUP
     _TP_RANK, _TP_SIZE, _BACKEND = rank, world_size, backend
     if world_size == 1:
         _TP_GROUP = None
         return
+    if _CA_COMM is not None:       # a second set-up in one process: never leave the first communicator mapped
+        _CA_COMM.close()
+        _CA_COMM = None
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, init_method=init_method or "env://",
                                 world_size=world_size, rank=rank)
     _TP_GROUP = dist.group.WORLD
     _CA_STATE = "off"
+    if _CPU_GROUP is None:
+        _CPU_GROUP = _TP_GROUP if backend == "gloo" else dist.new_group(backend="gloo")
     if use_custom_all_reduce:
         from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
 
-        side = _TP_GROUP if backend == "gloo" else dist.new_group(backend="gloo")
+        side = _CPU_GROUP
         try:
             _CA_COMM = CustomAllreduce(side, local_device)
         except Exception as e:  # noqa: BLE001 -- e.g. a peer's memory cannot be mapped on this machine
@@ -91,15 +97,43 @@ def tp_barrier() -> None:
     """Host-side barrier over the TP ranks (no-op for one rank or a simulated shard).  Used before
     phases whose first device collective must not find the ranks seconds apart -- the warm-up runs
     of graph capture above all: the custom collectives give up after a bounded wait, and a timeout
-    raises their status word for good (there is no reset; the process group has to be rebuilt)."""
-    if _TP_SIZE == 1 or _SIMULATED or _TP_GROUP is None:
+    raises their status word for good (there is no reset; the communicator has to be dropped)."""
+    if _TP_SIZE == 1 or _SIMULATED or _CPU_GROUP is None:
         return
-    if _CA_COMM is not None and not _CA_COMM.disabled:
-        dist.barrier(group=_CA_COMM.group)      # the CPU side group: no device work queued
-    elif _BACKEND == "gloo":
-        dist.barrier(group=_TP_GROUP)
-    else:
-        dist.barrier(group=_TP_GROUP, device_ids=[torch.cuda.current_device()])
+    dist.barrier(group=_CPU_GROUP)      # the CPU side group: no device work queued
+
+
+def tp_any(flag: bool) -> bool:
+    """True on every rank when `flag` is true on at least one (host-side, over the gloo group): how the
+    ranks agree on a decision that one of them may have been forced into (a failed graph capture)."""
+    if _TP_SIZE == 1 or _SIMULATED or _CPU_GROUP is None:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CPU_GROUP)
+    return bool(t.item())
+
+
+def drop_custom_all_reduce(reason: str) -> None:
+    """Collective: every rank closes the one-launch collectives (after a barrier timeout their status
+    word stays raised for good) and the process group's own collectives serve every later call."""
+    global _CA_COMM, _CA_STATE
+    if _CA_COMM is not None:
+        _CA_COMM.close()
+        _CA_COMM = None
+    _CA_STATE = f"off ({reason})"
+
+
+def sync_token_ids_across_tp(ids: torch.Tensor) -> torch.Tensor:
+    """MIN all-reduce of the sampled ids over the TP group (layers/sampler.py:137-149 of the reference):
+    ranks that disagree on a tie all continue with the smallest id instead of drifting apart."""
+    if _TP_SIZE == 1 or _SIMULATED or _TP_GROUP is None:
+        return ids
+    if _BACKEND == "gloo" and ids.is_cuda:
+        h = ids.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN, group=_TP_GROUP)
+        return ids.copy_(h)
+    dist.all_reduce(ids, op=dist.ReduceOp.MIN, group=_TP_GROUP)
+    return ids
 
 
 _SIMULATED = False
@@ -115,10 +149,10 @@ def init_simulated_shard(world_size: int, rank: int = 0) -> None:
 
 
 def destroy_model_parallel() -> None:
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM, _CPU_GROUP
     if _CA_COMM is not None:
         _CA_COMM.close()
-    _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM = None, 0, 1, None
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _CA_COMM, _CPU_GROUP = None, 0, 1, None, None
 
 
 def get_tensor_model_parallel_world_size() -> int:

@@ -6,12 +6,17 @@ from a torch.Generator the caller may seed; it samples from the same filtered, r
 distribution as top_k_top_p_min_p_sampling_from_probs_torch (:154-178), except that entries
 exactly tied with the cut-off probability are all kept (the reference keeps an unspecified
 subset of ties, decided by its unstable sort)."""
+import os
 from typing import Optional
 
 import torch
 from torch import nn
 
 from ..ops_backend import get_ops
+
+# The reference's switch, same name (layers/sampler.py:26): off by default -- every kernel on the path is
+# deterministic and all ranks see the same gathered logits -- on as cheap insurance for a first multi-GPU run.
+SYNC_TOKEN_IDS_ACROSS_TP = os.environ.get("SYNC_TOKEN_IDS_ACROSS_TP", "").lower() in ("1", "true", "yes")
 
 
 class Sampler(nn.Module):
@@ -41,4 +46,8 @@ class Sampler(nn.Module):
         if return_logprob:
             idx = torch.arange(len(batch_next_token_ids), device=logits.device)
             logits_output.next_token_logprobs = logprobs[idx, batch_next_token_ids.long()]
+        if SYNC_TOKEN_IDS_ACROSS_TP or getattr(sampling_info, "grammars", None):
+            from ..distributed.parallel_state import sync_token_ids_across_tp
+
+            batch_next_token_ids = sync_token_ids_across_tp(batch_next_token_ids)
         return batch_next_token_ids

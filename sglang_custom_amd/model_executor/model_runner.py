@@ -61,10 +61,35 @@ class ModelRunner:
         self.init_memory_pool()
         self.attn_backend = (attn_backend_cls or Mi355AttnBackend)(self)
         self.graph_runner = None
+        self.graph_capture_error = None
         if not server_args.disable_cuda_graph and str(self.device).startswith("cuda"):
-            from .hip_graph_runner import HipGraphRunner
+            self.init_cuda_graphs()
 
+    def init_cuda_graphs(self):
+        """Capture the decode graphs (model_runner.py:1393-1420 of the reference).  The outcome is agreed on
+        by all TP ranks: a capture that failed on ONE rank (or a collective of its warm-up runs that gave up
+        waiting for that rank) makes every rank take the same road -- raise together, or, with
+        server_args.graph_capture_fallback, run eager on this same runner (no second process group, the
+        one-launch collectives dropped because a timed-out barrier leaves them unusable)."""
+        from .hip_graph_runner import HipGraphRunner
+
+        err = None
+        try:
             self.graph_runner = HipGraphRunner(self)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+            self.graph_runner = None
+        if not parallel_state.tp_any(err is not None):
+            return
+        self.graph_runner = None
+        self.graph_capture_error = err or "graph capture failed on another rank"
+        torch.cuda.synchronize()
+        if parallel_state.get_custom_all_reduce() is not None:
+            parallel_state.drop_custom_all_reduce("dropped after a failed graph capture")
+        if not getattr(self.server_args, "graph_capture_fallback", False):
+            raise RuntimeError(f"HIP-graph capture failed ({self.graph_capture_error}); "
+                               "set disable_cuda_graph or graph_capture_fallback")
+        logger.warning("HIP-graph capture failed (%s); running eager", self.graph_capture_error)
 
     # ---- set-up ----
     def init_torch_distributed(self):

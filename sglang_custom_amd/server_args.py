@@ -20,6 +20,7 @@ class ServerArgs:
     disable_cuda_graph: bool = False
     cuda_graph_max_bs: int = 64
     cuda_graph_bs: Optional[list] = None
+    graph_capture_fallback: bool = False        # not in the reference: a failed graph capture -> eager on all ranks instead of raising
     random_seed: int = 0
     simulate_tp_shard: bool = False             # measurement aid: one TP rank, collectives stubbed
     chunked_prefill_size: Optional[int] = None   # None / -1: prompts are never split

@@ -512,6 +512,57 @@ def test_reference_op_set_two_ranks_on_one_gpu():
     _run_ranks(_ops_rank_main, 2)
 
 
+def _bench_launcher(queue, extra):
+    """Runs inside a fork-server child (a process that has never touched the GPU): starts bench.py as the
+    driver would, without a launcher, and hands its output back."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(extra), env=env, capture_output=True,
+                           text=True, timeout=420)
+        queue.put((r.returncode, r.stdout, r.stderr[-4000:]))
+    except Exception:  # noqa: BLE001
+        queue.put((-1, "", traceback.format_exc()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sync_ids", [False, True])
+def test_bench_tensor_parallel_branch_with_ranks_sharing_the_gpu(sync_ids):
+    """bench.py's own TP branch end to end on the one GPU of the box: spawn two fresh ranks -> sharded model
+    -> one-launch collectives (self-test against the gloo group) -> HIP-graph capture with the collectives
+    inside -> timed loop -> ONE JSON line carrying the `collectives` object.  Llama-3.2-1B shapes, batch 8,
+    128-token prompts.  With SYNC_TOKEN_IDS_ACROSS_TP the sampled ids also cross the MIN all-reduce."""
+    import json
+
+    queue = _CTX.Queue()
+    args = ["--gpus", "2", "--ranks-share-gpu", "--model", "llama-3.2-1b", "--batch-size", "8", "--input-len", "128",
+            "--steps", "6", "--warmup", "2", "--ttft-repeats", "1", "--no-cpu-baseline", "--custom-all-reduce", "auto"]
+    if sync_ids:
+        os.environ["SYNC_TOKEN_IDS_ACROSS_TP"] = "1"
+    try:
+        p = _CTX.Process(target=_bench_launcher, args=(queue, args))
+        p.start()
+        rc, out, err = queue.get(timeout=450)
+        p.join(timeout=10)
+    finally:
+        os.environ.pop("SYNC_TOKEN_IDS_ACROSS_TP", None)
+    assert rc == 0, err
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "strong"
+    assert line["value"] > 0 and abs(line["value"] - 8 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-2 * line["value"]
+    assert "REHEARSAL" in line["config"]["parallelism"] and line["config"]["hip_graph"] is True, line["config"]
+    col = line["collectives"]
+    assert col["ranks"] == 2 and col["all_reduces_per_step"] == 2 * 16 + 1
+    assert col["custom_all_reduce"].startswith("on (self-test passed)"), col
+    assert line["roofline"]["kernel"] == "gemm_ring_kernel" and 0 < line["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in line
+
+
 def _hive_size():
     import torch
 

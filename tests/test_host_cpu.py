@@ -81,6 +81,13 @@ def _tp_worker(rank, world, port, q):
         shapes = dict(qkv=tuple(layer.self_attn.qkv_proj.weight.shape), o=tuple(layer.self_attn.o_proj.weight.shape),
                       kv=tuple(mr.token_to_kv_pool.get_key_buffer(0).shape[1:]),
                       head=tuple(mr.model.lm_head.weight.shape))
+        # host-side agreement helpers and the token-id sync (sampler.py:137-149 of the reference)
+        from sglang_custom_amd.distributed import parallel_state as ps
+
+        ps.tp_barrier()
+        assert ps.tp_any(rank == 1) is True and ps.tp_any(False) is False
+        ids = torch.tensor([5, 3, 9] if rank == 0 else [4, 7, 9], dtype=torch.int64)
+        assert ps.sync_token_ids_across_tp(ids).tolist() == [4, 3, 9]
         q.put((rank, toks.numpy(), torch.stack(lg).numpy(), shapes, (hq, hkv, d)))  # by value
     except Exception as e:  # noqa: BLE001
         import traceback
