@@ -1163,7 +1163,11 @@ constexpr int MLA_V_BYTES = 4 * 16 * MLA_ROW * 2;     // four waves' value tiles
 constexpr int MLA_LDS_BYTES = MLA_V_BYTES + 16 * MLA_QROW * 2;
 static_assert(MLA_V_BYTES >= 16 * MLA_RANK * 4, "the merge buffer reuses the value tiles");
 
-template <typename T, bool CAP>
+// KV8: the latent cache holds OCP e4m3fn bytes (576 per row).  A lane then fetches 8 bytes per
+// fragment instead of 16, keeps the two buffered tiles as raw bytes (half the registers) and widens a
+// tile to T -- exactly, every e4m3 value is a T value -- when it is computed: same results as this
+// kernel over a 16-bit cache that holds the widened values.
+template <typename T, bool CAP, bool KV8 = false>
 __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __restrict__ q,
                                                                    const T* __restrict__ kvbuf,
                                                                    T* __restrict__ o, DecodeParams p) {
@@ -1171,6 +1175,7 @@ __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __re
   constexpr int NDT = MLA_RANK / 16;  // 32 value feature tiles
   using frag = typename Mfma<T>::frag;
   using frag4 = typename Mfma16<T>::frag;
+  using rawfrag = typename std::conditional<KV8, uint2, frag>::type;   // one lane's 8 features of a row as loaded
   // the value tiles during the key loop; afterwards the cross-wave accumulator [16 heads][512]
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // MLA_LDS_BYTES (> 64 KiB: dynamic)
   __shared__ float sm_m[4][16];
@@ -1223,12 +1228,28 @@ __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __re
     const int64_t key = wave_first + (int64_t)it * 64 + r16;
     return pt[key < last_key ? key : last_key];
   };
-  auto load_row = [&](int32_t slot, frag (&kf)[NS]) {
-    const T* krow = kbase + (int64_t)slot * p.k_slot_stride;
+  auto load_row = [&](int32_t slot, rawfrag (&kf)[NS]) {
+    if constexpr (KV8) {
+      const uint8_t* krow = reinterpret_cast<const uint8_t*>(kvbuf) + 8 * c4 + (int64_t)slot * p.k_slot_stride;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+      for (int s = 0; s < NS; ++s) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(krow + 32 * s));
+        kf[s] = uint2{v[0], v[1]};
+      }
+    } else {
+      const T* krow = kbase + (int64_t)slot * p.k_slot_stride;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const frag*>(krow + 32 * s);
+    }
   };
-  auto compute = [&](const frag (&kf)[NS], int it) {
+  auto compute = [&](const rawfrag (&kraw)[NS], int it) {
+    frag kf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if constexpr (KV8) kf[s] = __builtin_bit_cast(frag, cvt8_from_fp8<T>(kraw[s]));
+      else kf[s] = kraw[s];
+    }
     f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) sc = Mfma<T>::run(kf[s], *reinterpret_cast<const frag*>(q_rd + 32 * s), sc);
@@ -1279,7 +1300,7 @@ __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __re
   };
 
   if (n_iter > 0) {
-    frag kfA[NS], kfB[NS];
+    rawfrag kfA[NS], kfB[NS];
     int32_t sA = load_slot(0), sB = load_slot(1);
     load_row(sA, kfA);
     load_row(sB, kfB);
@@ -2254,6 +2275,8 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   else
     MI355_REQUIRE(kv_indptr, MI355_ERR_INVALID, "decode_attention_mla: mode 1 needs kv_indptr");
   const int D = kv_lora_rank + rope_dim;
+  const bool kv8 = (dtype & MI355_KV_FP8) != 0;   // the latent cache holds e4m3fn bytes
+  dtype &= 0xff;
   MI355_REQUIRE(bs >= 0 && bs <= 65535 && hq > 0 && kv_lora_rank > 0 && rope_dim >= 0 && num_slots > 0 &&
                     q_stride >= (int64_t)hq * D,
                 MI355_ERR_INVALID, "decode_attention_mla: bad shape hq=%d rank=%d rope=%d", hq, kv_lora_rank, rope_dim);
@@ -2279,6 +2302,28 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   p.k_slot_stride = D;   // one latent row per slot; the value is its first kv_lora_rank features
   p.v_slot_stride = D;
   hipStream_t st = (hipStream_t)stream;
+  if (kv8) {
+    // e4m3fn latent rows: the register kernel, widening on use (the LDS-ring kernel lands raw 16-bit rows)
+    MI355_REQUIRE(kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
+                      aligned16(q) && (reinterpret_cast<uintptr_t>(kv_buffer) & 7) == 0 && q_stride % 8 == 0,
+                  MI355_ERR_UNSUPPORTED,
+                  "decode_attention_mla: an fp8 latent cache needs rank 512 + rope 64, a 16-bit dtype and aligned pointers");
+    const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)num_splits, (unsigned)bs);
+#define MLA8_LAUNCH(T_, CAP_)                                                                                  \
+  do {                                                                                                         \
+    auto kern = decode_attn_mla_mfma_kernel<T_, CAP_, true>;                                                   \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MLA_LDS_BYTES);   \
+    hipLaunchKernelGGL(kern, grid, dim3(256), MLA_LDS_BYTES, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p); \
+    if (num_splits > 1)                                                                                        \
+      hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
+                         p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
+  } while (0)
+    if (dtype == MI355_BF16) { if (logit_cap > 0.f) MLA8_LAUNCH(bf16_t, true); else MLA8_LAUNCH(bf16_t, false); }
+    else { if (logit_cap > 0.f) MLA8_LAUNCH(f16_t, true); else MLA8_LAUNCH(f16_t, false); }
+#undef MLA8_LAUNCH
+    MI355_CHECK_LAUNCH("decode_attention_mla");
+    return MI355_OK;
+  }
   if (kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
       aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && (g_decode_variant == 0 || g_decode_variant == 2 || g_decode_variant == 5)) {
     const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)num_splits, (unsigned)bs);

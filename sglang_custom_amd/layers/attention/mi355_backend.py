@@ -56,6 +56,7 @@ class Mi355AttnBackend(AttentionBackend):
         self.num_head = cfg.num_attention_heads // tp
         self.num_kv_head = max(1, cfg.num_key_value_heads // tp)
         self.is_mla = hasattr(model_runner.token_to_kv_pool, "kv_lora_rank")
+        self.kv_fp8 = getattr(model_runner.token_to_kv_pool, "dtype", None) == torch.float8_e4m3fn
         if self.is_mla:
             # what the split plan counts is workgroups per sequence, one per 16 query heads
             self.num_kv_head = (self.num_head + 15) // 16
@@ -113,7 +114,10 @@ class Mi355AttnBackend(AttentionBackend):
             # 512 workgroups (64 sequences x 16 heads x 4096 keys: 190 / 107 / 75 / 68 us at 1 / 2 / 4 / 8 splits,
             # 91 at 10) with at least 256 keys per split (64 x 1024 keys: 31.6 us at 4 splits, 34.5 at 8)
             wgs = max(1, bs * self.num_kv_head)
-            return max(1, min(MAX_KV_SPLITS, (512 + wgs - 1) // wgs, max(1, max_seq_len // 256)))
+            # an e4m3fn latent cache runs on the register kernel (one workgroup per CU, merge as a second
+            # launch): fastest at 256 workgroups (64 x 16 x 4096: 171 / 102 / 75 / 99 us at 1 / 2 / 4 / 8 splits)
+            target = 256 if self.kv_fp8 else 512
+            return max(1, min(MAX_KV_SPLITS, (target + wgs - 1) // wgs, max(1, max_seq_len // 256)))
         return get_ops().decode_num_splits(bs, self.num_kv_head, max_seq_len, MAX_KV_SPLITS)
 
     # ---- eager ----
@@ -289,7 +293,7 @@ class Mi355AttnBackend(AttentionBackend):
             # serves it with per-token table rows and lengths.  Causal by construction.
             assert save_kv_cache, "the absorbed MLA extend reads the new tokens from the cache"
             q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
-            if (MLA_EXTEND_TILED
+            if (MLA_EXTEND_TILED and pool.dtype != torch.float8_e4m3fn   # (the tiled kernel lands raw 16-bit rows)
                     and (q3.shape[0] // 4) * ((layer.tp_q_head_num + 15) // 16) >= MLA_EXTEND_TILED_MIN_WGS
                     and ops.extend_attention_mla_supported(layer.tp_q_head_num, pool.kv_lora_rank,
                                                            pool.qk_rope_head_dim, q.dtype)):
@@ -311,12 +315,18 @@ class Mi355AttnBackend(AttentionBackend):
         if hasattr(pool, "kv_lora_rank") and sum(forward_batch.extend_prefix_lens_cpu) > 0:
             raise NotImplementedError("MLA multi-head prefill cannot read a cached prefix: use the absorbed form (attn_mqa)")
         windowed = self._windowed(layer)
+        if hasattr(pool, "kv_lora_rank"):
+            # multi-head prefill over an MLA pool: there is no prefix (checked above), so the cache buffers are
+            # never read -- and they are latent rows (possibly e4m3fn bytes), not per-head keys.  The kernel
+            # still wants valid pointers: hand it the new tokens' own keys / values.
+            kbuf = k.reshape(k.shape[0], -1, layer.qk_head_dim).contiguous()
+            vbuf = v.reshape(v.shape[0], -1, layer.v_head_dim).contiguous()
+        else:
+            kbuf, vbuf = pool.get_key_buffer(layer.layer_id), pool.get_value_buffer(layer.layer_id)
         ops.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k, v,
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
-            pool.get_key_buffer(layer.layer_id),
-            # (an MLA pool has no separate value rows; without a prefix neither buffer is read)
-            pool.get_key_buffer(layer.layer_id) if hasattr(pool, "kv_lora_rank") else pool.get_value_buffer(layer.layer_id),
+            kbuf, vbuf,
             md.qo_indptr, md.window_kv_indptr if windowed else md.kv_indptr,
             md.window_kv_indices if windowed else md.kv_indices, None, True, None, md.max_extend_len,
             layer.scaling, layer.logit_cap, sliding_window_size=layer.sliding_window_size if windowed else -1)

@@ -132,7 +132,10 @@ class MLATokenToKVPool:
         """cache_k [T, 1, rank + rope] is the whole latent row; cache_v is ignored (:895-909)."""
         layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
         buf = self.kv_buffer[layer_id]
-        row = cache_k.to(self.dtype).reshape(loc.numel(), 1, self.head_dim)
+        # an fp8 pool (memory_pool.py:895-909 casts with cache_k.to(dtype)) is written by the scatter kernel
+        # itself: round to nearest even, saturating at +-448
+        row = cache_k if self.dtype == torch.float8_e4m3fn else cache_k.to(self.dtype)
+        row = row.reshape(loc.numel(), 1, self.head_dim)
         # the generic scatter kernel copies a K row and a V row per token: hand it the row twice
         get_ops().set_kv_buffer(buf, buf, loc, row, row)
 

@@ -117,8 +117,6 @@ class ModelRunner:
         self.kv_cache_dtype = torch.float8_e4m3fn if kvd == "fp8_e4m3" else self.dtype
         mla = getattr(cfg, "is_mla", False)
         if mla:
-            if kvd != "auto":
-                raise NotImplementedError("fp8 latent cache")
             # one latent row per token and layer (model_runner.py:950-957)
             cell = (cfg.kv_lora_rank + cfg.qk_rope_head_dim) * cfg.num_hidden_layers * torch.finfo(self.kv_cache_dtype).bits // 8
         else:

@@ -416,7 +416,8 @@ def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_le
                          attn_lse, num_kv_splits: int, kv_lora_rank: int, sm_scale: float,
                          logit_cap: float = 0.0, tickets=None) -> None:
     """MQA over the compressed MLA cache (deepseek_v2.py:866-875): kv_buffer [slots, 1, rank + rope],
-    q [B, H, rank + rope], o [B, H, rank]; the value is kv_buffer[..., :rank]."""
+    q [B, H, rank + rope], o [B, H, rank]; the value is kv_buffer[..., :rank].  kv_buffer may hold
+    e4m3fn bytes (kv_cache_dtype fp8_e4m3): the rows are widened exactly on use."""
     _gpu(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens)
     B, Hq, D = q.shape
     assert kv_buffer.is_contiguous() and kv_buffer.shape[1] == 1 and kv_buffer.shape[2] == D
@@ -428,7 +429,7 @@ def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_le
         q.data_ptr(), kv_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0),
         _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, kv_lora_rank, D - kv_lora_rank,
-        q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap), _dt(q), _stream(q)),
+        q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, kv_buffer), _stream(q)),
         "decode_attention_mla")
 
 

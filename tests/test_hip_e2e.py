@@ -500,6 +500,44 @@ def test_real_shape_llama_1b_bf16_128_in_128_out(graphs):
 
 
 @pytest.mark.parametrize("graphs", [False, True])
+def test_deepseek_fp8_latent_cache_end_to_end_close_to_16bit_cache(graphs):
+    """kv_cache_dtype fp8_e4m3 on the bf16 DeepSeek stack (MLATokenToKVPool holding e4m3fn rows): prefill,
+    decode (eager and under graphs), then an extend over the cached prefix.  Logits stay within fp8 rounding
+    of the 16-bit-cache run under the same forced tokens, and the greedy tokens agree wherever the top-2
+    margin is decisive."""
+    from sglang_custom_amd import bench_one_batch as bob
+    from sglang_custom_amd.managers.schedule_batch import Req
+
+    preset, dtn, steps = "tiny-deepseek-yarn", "bf16", 6
+    runs = {}
+    for kvd in ("auto", "fp8_e4m3"):
+        mr, cfg, _ = make_runner(preset, dtn, graphs, max_total_tokens=1024, kv_cache_dtype=kvd)
+        prompts = cases.e2e_prompts(cfg["vocab_size"], (5, 33, 70))
+        forced = runs["auto"][0] if kvd != "auto" else None
+        toks, logits, _, _ = run_steps(mr, prompts, steps, forced_tokens=forced)
+        # extend over a cached prefix (absorbed form over the cached rows)
+        cut, longer = 20, [p for p in prompts if len(p) > 20]
+        bob.clear_pools(mr)
+        reqs = [Req(i, p[:cut]) for i, p in enumerate(longer)]
+        bob.extend(reqs, mr)
+        for i, r in enumerate(reqs):
+            r.fill_ids = r.fill_ids + longer[i][cut:]
+            r.origin_input_ids = list(r.fill_ids)
+            r.prefix_indices = mr.req_to_token_pool.req_to_token[i, :cut].clone()
+            r.extend_input_len = len(r.fill_ids) - cut
+        mr.req_to_token_pool.clear()
+        _, ext, _ = bob.extend(reqs, mr)
+        runs[kvd] = (toks, logits, ext.cpu(), mr.token_to_kv_pool.get_key_buffer(0).dtype)
+    assert runs["fp8_e4m3"][3] == torch.float8_e4m3fn and runs["auto"][3] == torch.bfloat16
+    for s, (a, b) in enumerate(zip(runs["auto"][1], runs["fp8_e4m3"][1])):
+        assert (a - b).abs().max() < 0.25, s
+        top2 = a.topk(2, dim=-1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > 0.5
+        assert torch.equal(runs["auto"][0][decisive, s], runs["fp8_e4m3"][0][decisive, s])
+    assert (runs["auto"][2] - runs["fp8_e4m3"][2]).abs().max() < 0.25
+
+
+@pytest.mark.parametrize("graphs", [False, True])
 @pytest.mark.parametrize("preset,dtn", [("tiny-deepseek", "f32"), ("tiny-deepseek-yarn", "f32"), ("tiny-deepseek-yarn", "bf16")])
 def test_deepseek_mla_stack_through_model_runner(preset, dtn, graphs):
     """A dense-layer DeepSeek model through ModelRunner: DeepseekV3ForCausalLM picked from

@@ -408,3 +408,80 @@ def test_mla_extend_tiled_refuses_other_latent_shapes():
         ops.extend_attention_mla(q, kv, o, r2t, torch.zeros(1, dtype=torch.int64, device=DEV),
                                  torch.full((1,), 4, dtype=torch.int64, device=DEV),
                                  torch.tensor([0, 4], dtype=torch.int32, device=DEV), 4, 256, 0.1)
+
+
+@pytest.mark.parametrize("H", [16, 20, 128])
+@pytest.mark.parametrize("dt,cap", [(torch.bfloat16, 0.0), (torch.float16, 0.0), (torch.bfloat16, 30.0)])
+def test_mla_decode_over_fp8_latent_cache(H, dt, cap):
+    """kv_cache_dtype fp8_e4m3 for the compressed cache (memory_pool.py:118-122, 769-909 of the reference):
+    the rows are e4m3fn bytes, written by the scatter kernel (round to nearest even, saturating) and widened
+    exactly when a tile is computed.  Bit for bit the same kernel over a 16-bit cache that holds the widened
+    values (that kernel is selected for a 16-bit cache by handing it split scratch that is not 16-byte
+    aligned), one and three KV splits, and within one output rounding of float64 attention over the widened rows."""
+    from sglang_custom_amd import ops
+
+    rank, rope = 512, 64
+    D = rank + rope
+    lens = [1, 15, 300, 65, 1029]
+    total = sum(lens)
+    rows = (_CASES.randn((total + 1, 1, D), 31, dt).float() * 3.0).to(dt).to(DEV)
+    rows[5, 0, :4] = torch.tensor([1000.0, -1000.0, 448.0, 1e-3], dtype=dt, device=DEV)   # saturation and a tiny value
+    cache8 = torch.zeros((total + 1, 1, D), dtype=torch.float8_e4m3fn, device=DEV)
+    loc = torch.arange(total + 1, dtype=torch.int64, device=DEV)
+    ops.set_kv_buffer(cache8, cache8, loc, rows, rows)
+    wide = cache8.float()
+    assert torch.isfinite(wide).all() and wide[5, 0, 0].item() == 448.0 and wide[5, 0, 1].item() == -448.0
+    # round to nearest even at e4m3 precision: equal to torch's cast wherever the value is inside the range
+    inside = rows.float().abs() <= 448.0
+    assert torch.equal(wide[inside], rows.to(torch.float8_e4m3fn).float()[inside])
+    cache16 = wide.to(dt)
+    assert torch.equal(cache16.float(), wide)   # every e4m3 value is a 16-bit value
+    r2t = torch.zeros((len(lens), max(lens)), dtype=torch.int32)
+    perm = torch.randperm(total, generator=torch.Generator().manual_seed(4)) + 1
+    pos = 0
+    for b, n in enumerate(lens):
+        r2t[b, :n] = perm[pos: pos + n].int()
+        pos += n
+    r2t = r2t.to(DEV)
+    rpi = torch.arange(len(lens), dtype=torch.int64, device=DEV)
+    lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    q = _CASES.randn((len(lens), H, D), 32, dt).to(DEV)
+    scale = D ** -0.5
+    for splits in (1, 3):
+        n = len(lens) * H * max(splits, 2)
+        lg = torch.empty(n * rank + 1, dtype=torch.float32, device=DEV)
+        ls = torch.empty(n, dtype=torch.float32, device=DEV)
+        got = torch.full((len(lens), H, rank), float("nan"), dtype=dt, device=DEV)
+        ops.decode_attention_mla(q, cache8, got, r2t, rpi, lt, lg, ls, splits, rank, scale, cap)
+        if splits > 1:
+            same = torch.full_like(got, float("nan"))
+            ops.decode_attention_mla(q, cache16, same, r2t, rpi, lt, lg[1:], ls, splits, rank, scale, cap)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int16), same.view(torch.int16)), (H, splits)
+        ring = torch.full_like(got, float("nan"))
+        ops.decode_attention_mla(q, cache16, ring, r2t, rpi, lt, lg, ls, splits, rank, scale, cap)
+        torch.cuda.synchronize()
+        assert not torch.isnan(got.float()).any()
+        # float64 attention over the widened rows
+        for b, nkeys in enumerate(lens):
+            kv = wide[r2t[b, :nkeys].long(), 0].double()
+            sc = (q[b].double() @ kv.t()) * scale
+            if cap > 0:
+                sc = cap * torch.tanh(sc / cap)
+            ref = torch.softmax(sc, -1) @ kv[:, :rank]
+            tol = (2e-2 if dt == torch.bfloat16 else 3e-3) * max(ref.abs().max().item(), 1.0)
+            assert (got[b].double() - ref).abs().max().item() <= tol, (H, splits, b)
+            assert (ring[b].double() - ref).abs().max().item() <= tol
+
+
+def test_fp8_latent_cache_refuses_other_shapes():
+    from sglang_custom_amd import ops
+    from sglang_custom_amd._lib import Mi355Error
+
+    q = torch.zeros((1, 16, 128 + 64), dtype=torch.bfloat16, device=DEV)
+    cache = torch.zeros((8, 1, 128 + 64), dtype=torch.float8_e4m3fn, device=DEV)
+    o = torch.zeros((1, 16, 128), dtype=torch.bfloat16, device=DEV)
+    r2t = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
+    with pytest.raises(Mi355Error):
+        ops.decode_attention_mla(q, cache, o, r2t, torch.zeros(1, dtype=torch.int64, device=DEV),
+                                 torch.ones(1, dtype=torch.int64, device=DEV), None, None, 1, 128, 0.1)
