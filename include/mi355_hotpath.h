@@ -190,6 +190,14 @@ int mi355_prepare_decode(int32_t* req_to_token, const int64_t* req_pool_indices,
  * workgroup of a (sequence, head group) to finish does it -- and no second launch follows; without them,
  * above 64 splits, and for every other shape, a merge kernel is launched behind the first.  Same bits
  * either way.  Calls that may overlap on the GPU need arrays of their own.
+ * kv_chunk_keys (may be NULL): ONE int32 in device memory, read by the kernels when they run: the batch's
+ * keys per split.  Sequence b is then cut into ceil(len(b) / *kv_chunk_keys) splits (at most num_splits; a
+ * value too small to cover a sequence in num_splits pieces is raised to the even cut), so a ragged batch --
+ * or a captured graph planned for the longest context -- does not cut its short sequences into num_splits
+ * slivers.  The grid and the scratch layout do not change; the host writes the value (normally
+ * ceil(longest sequence / num_splits)) before each launch or graph replay.  This is the per-sequence
+ * num_kv_splits of the reference (get_num_kv_splits_triton, layers/attention/triton_backend.py:875-924: one
+ * chunk size for the batch, cdiv(seq_len, chunk) splits per sequence).
  * replaces: decode_attention_fwd (layers/attention/triton_ops/decode_attention.py:677-728),
  *           decode_attention_cpu (sgl-kernel/csrc/cpu/decode.cpp:1375-1575),
  *           TorchNativeAttnBackend._run_sdpa_forward_decode (torch_native_backend.py:112-180). */
@@ -197,8 +205,8 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
                            const int32_t* page_table, int mode, const int64_t* req_pool_indices,
                            const int64_t* seq_lens, const int32_t* kv_indptr,
                            int64_t table_stride, float* attn_logits, float* attn_lse,
-                           uint32_t* split_tickets, int num_splits, int64_t bs, int hq, int hkv,
-                           int head_dim, int v_head_dim, int64_t q_stride, int64_t num_slots,
+                           uint32_t* split_tickets, const int32_t* kv_chunk_keys, int num_splits, int64_t bs,
+                           int hq, int hkv, int head_dim, int v_head_dim, int64_t q_stride, int64_t num_slots,
                            float sm_scale, float logit_cap, int dtype, void* stream);
 
 /* Number of KV splits mi355_decode_attention should be given for this batch (host-side
@@ -256,7 +264,7 @@ int mi355_decode_attention_static(const void* q, const void* k_buffer, const voi
  * slot out_cache_loc[b] (which the page table must name for position seq_len - 1, except for padding
  * rows, whose writes go to the sink slot they name), and runs mi355_decode_attention.  Output and
  * cache contents are bit-identical to mi355_linear_packed -> mi355_rope_inplace (fused KV write) ->
- * mi355_decode_attention (split_tickets as there).  Needs head_dim 128, a 16-bit dtype, hq / hkv in {1, 2, 4, 8}, no logit cap.
+ * mi355_decode_attention (split_tickets, kv_chunk_keys as there).  Needs head_dim 128, a 16-bit dtype, hq / hkv in {1, 2, 4, 8}, no logit cap.
  * replaces: LlamaAttention.forward's rotary_emb + attn sequence (models/llama.py:180-191) on the
  *           decode path; the reference has no fused counterpart. */
 int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const float* part_x_scale,
@@ -265,14 +273,14 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
                                      void* v_buffer, void* o, const int32_t* page_table, int mode,
                                      const int64_t* req_pool_indices, const int64_t* seq_lens,
                                      const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                                     float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs,
+                                     float* attn_lse, uint32_t* split_tickets, const int32_t* kv_chunk_keys, int num_splits, int64_t bs,
                                      int hq, int hkv, int head_dim, int64_t num_slots, float sm_scale,
                                      int dtype, void* stream);
 
 /* MLA (compressed-KV) decode: every query head attends over ONE latent row per token,
  * kv_buffer [num_slots, 1, kv_lora_rank + rope_dim]; the key is the whole row, the value its first
  * kv_lora_rank features (read from the same buffer, never materialised).  q [B, hq, rank + rope],
- * o [B, hq, kv_lora_rank]; addressing modes, split scratch and split_tickets as mi355_decode_attention
+ * o [B, hq, kv_lora_rank]; addressing modes, split scratch, split_tickets and kv_chunk_keys as mi355_decode_attention
  * (the rank-512 + rope-64 16-bit kernel merges the splits itself when given tickets).
  * replaces: attn_mqa = RadixAttention(H, 576, scaling, num_kv_heads=1, v_head_dim=512) on
  *           MLATokenToKVPool (python/sglang/srt/models/deepseek_v2.py:866-875,
@@ -281,7 +289,7 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                                const int32_t* page_table, int mode,
                                const int64_t* req_pool_indices, const int64_t* seq_lens,
                                const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                               float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs, int hq,
+                               float* attn_lse, uint32_t* split_tickets, const int32_t* kv_chunk_keys, int num_splits, int64_t bs, int hq,
                                int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
                                float sm_scale, float logit_cap, int dtype, void* stream);
 

@@ -31,7 +31,7 @@ _SIGNATURES = {
     "mi355_write_req_to_token": (I, [P, P, P, P, P, P, L, L, P]),
     "mi355_compute_position": (I, [P, P, P, P, L, P]),
     "mi355_prepare_decode": (I, [P, P, P, P, P, L, L, P]),
-    "mi355_decode_attention": (I, [P, P, P, P, P, I, P, P, P, L, P, P, P, I, L, I, I, I, I, L, L, F, F, I, P]),
+    "mi355_decode_attention": (I, [P, P, P, P, P, I, P, P, P, L, P, P, P, P, I, L, I, I, I, I, L, L, F, F, I, P]),
     "mi355_decode_num_splits": (I, [L, I, L, I]),
     "mi355_extend_attention": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, I, L, L, L,
                                    L, F, F, I, I, P]),
@@ -40,7 +40,7 @@ _SIGNATURES = {
     "mi355_packed_weight_elems": (L, [L, L]),
     "mi355_pack_weight": (I, [P, P, L, L, I, P]),
     "mi355_decode_attention_static": (I, [P, P, P, P, P, I, P, P, P, L, I, L, I, I, I, I, L, L, F, F, I, P]),
-    "mi355_decode_attention_mla": (I, [P, P, P, P, I, P, P, P, L, P, P, P, I, L, I, I, I, L, L, F, F, I, P]),
+    "mi355_decode_attention_mla": (I, [P, P, P, P, I, P, P, P, L, P, P, P, P, I, L, I, I, I, L, L, F, F, I, P]),
     "mi355_extend_attention_mla_supported": (I, [I, I, I, I]),
     "mi355_extend_attention_mla": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, L, L, F, F, I, P]),
     "mi355_linear_packed": (I, [P, P, P, P, L, L, L, L, P, L, I, I, P]),
@@ -54,7 +54,7 @@ _SIGNATURES = {
     "mi355_fp8_packed_workspace_bytes": (L, [L, L, L]),
     "mi355_fp8_scaled_mm_packed": (I, [P, P, P, P, P, P, L, L, L, P, L, I, P]),
     "mi355_prefetch_next": (I, [P, L, L, L, I, L]),
-    "mi355_decode_attention_fused_qkv": (I, [P, I, P, P, P, P, P, I, P, P, P, P, I, P, P, P, L, P, P, P, I, L, I, I, I, L, F, I, P]),
+    "mi355_decode_attention_fused_qkv": (I, [P, I, P, P, P, P, P, I, P, P, P, P, I, P, P, P, L, P, P, P, P, I, L, I, I, I, L, F, I, P]),
     "mi355_copy_decode_inputs": (I, [P, P, I, L, P]),
     "mi355_alloc_extend": (I, [P, P, P, P, P, P, L, L, P]),
     "mi355_alloc_decode": (I, [P, P, P, P, P, L, L, P]),

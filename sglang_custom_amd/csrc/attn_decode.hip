@@ -34,7 +34,22 @@ struct DecodeParams {
   // Arrival counters of the in-kernel merge, one per (sequence, blockIdx.x), zero between launches; null:
   // the splits are merged by decode_merge_kernel in a second launch.  Only the kernels that say so use them.
   unsigned* tickets = nullptr;
+  // Per-sequence split plan: when non-null, one int32 on the device = the batch's keys per split
+  // (ceil(longest sequence / num_splits), written by the host before the launch).  Sequence b is then cut
+  // into ceil(len(b) / that) splits instead of num_splits; its remaining split workgroups find nothing.
+  const int32_t* chunk_keys = nullptr;
 };
+
+// Keys per split of a sequence of `len` keys: the even cut into num_splits, or the batch's chunk when
+// that is larger (never smaller: num_splits chunks always cover the sequence).
+__device__ __forceinline__ int64_t split_chunk(const DecodeParams& p, int64_t len) {
+  int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  if (p.chunk_keys) {
+    const int64_t c = *p.chunk_keys;
+    chunk = c > chunk ? c : chunk;
+  }
+  return chunk;
+}
 
 // Inputs of the fused decode step: the qkv projection is still fp32 split-K partials, RoPE has
 // not been applied and the new token's K/V rows are not in the cache yet.
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 
   int64_t page_off, len;
   seq_range(p, b, page_off, len);
-  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t chunk = split_chunk(p, len);
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
 
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const T* __restri
 
   int64_t page_off, len;
   seq_range(p, b, page_off, len);
-  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t chunk = split_chunk(p, len);
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
@@ -717,7 +732,7 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
 
   int64_t page_off, len;
   seq_range(p, b, page_off, len);
-  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t chunk = split_chunk(p, len);
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
@@ -1095,7 +1110,7 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
   const int kvh = head / (p.hq / p.hkv);
   int64_t page_off, len;
   seq_range(p, b, page_off, len);
-  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t chunk = split_chunk(p, len);
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const T* qh = q + (int64_t)b * p.q_stride + (int64_t)head * D;
@@ -1188,7 +1203,7 @@ __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __re
 
   int64_t page_off, len;
   seq_range(p, b, page_off, len);
-  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t chunk = split_chunk(p, len);
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
@@ -1455,7 +1470,7 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
 
   int64_t page_off, len;
   seq_range(p, b, page_off, len);
-  const int64_t chunk = (len + p.num_splits - 1) / p.num_splits;
+  const int64_t chunk = split_chunk(p, len);
   const int64_t k0 = (int64_t)split * chunk;
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const int n_steps = k1 > k0 ? (int)((k1 - k0 + 31) / 32) : 0;   // 32 keys (two tiles) per step
@@ -2056,8 +2071,8 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
                            const int32_t* page_table, int mode, const int64_t* req_pool_indices,
                            const int64_t* seq_lens, const int32_t* kv_indptr,
                            int64_t table_stride, float* attn_logits, float* attn_lse,
-                           uint32_t* split_tickets, int num_splits, int64_t bs, int hq, int hkv,
-                           int head_dim, int v_head_dim, int64_t q_stride, int64_t num_slots,
+                           uint32_t* split_tickets, const int32_t* kv_chunk_keys, int num_splits, int64_t bs,
+                           int hq, int hkv, int head_dim, int v_head_dim, int64_t q_stride, int64_t num_slots,
                            float sm_scale, float logit_cap, int dtype, void* stream) {
   MI355_REQUIRE(q && k_buffer && v_buffer && o && page_table, MI355_ERR_INVALID,
                 "decode_attention: null pointer");
@@ -2089,6 +2104,7 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   p.part_o = attn_logits;
   p.part_lse = attn_lse;
   p.tickets = split_tickets;
+  p.chunk_keys = kv_chunk_keys;
   p.mode = mode;
   p.num_splits = num_splits;
   p.hq = hq;
@@ -2185,7 +2201,7 @@ int mi355_decode_attention_static(const void* q, const void* k_buffer, const voi
   // Every (sequence, head, split) cell is written by stage 1 before stage 2 reads it (an empty
   // split stores lse = -inf), so nothing in the array has to start at zero.
   return mi355_decode_attention(q, k_buffer, v_buffer, o, page_table, mode, req_pool_indices, seq_lens, kv_indptr,
-                                table_stride, base, base ? base + n_o_pad : nullptr, nullptr, num_splits, bs, hq, hkv,
+                                table_stride, base, base ? base + n_o_pad : nullptr, nullptr, nullptr, num_splits, bs, hq, hkv,
                                 head_dim, v_head_dim, q_stride, num_slots, sm_scale, logit_cap, dtype, stream);
 }
 
@@ -2195,9 +2211,9 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
                                      void* v_buffer, void* o, const int32_t* page_table, int mode,
                                      const int64_t* req_pool_indices, const int64_t* seq_lens,
                                      const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                                     float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs,
-                                     int hq, int hkv, int head_dim, int64_t num_slots, float sm_scale,
-                                     int dtype, void* stream) {
+                                     float* attn_lse, uint32_t* split_tickets, const int32_t* kv_chunk_keys,
+                                     int num_splits, int64_t bs, int hq, int hkv, int head_dim, int64_t num_slots,
+                                     float sm_scale, int dtype, void* stream) {
   MI355_REQUIRE(qkv_part && positions && out_cache_loc && cos_sin_cache && k_buffer && v_buffer && o && page_table,
                 MI355_ERR_INVALID, "decode_attention_fused_qkv: null pointer");
   MI355_REQUIRE(mode == 0 || mode == 1, MI355_ERR_INVALID, "decode_attention_fused_qkv: mode must be 0|1");
@@ -2232,6 +2248,7 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
   p.part_o = attn_logits;
   p.part_lse = attn_lse;
   p.tickets = split_tickets;
+  p.chunk_keys = kv_chunk_keys;
   p.mode = mode;
   p.num_splits = num_splits;
   p.hq = hq;
@@ -2264,9 +2281,9 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                                const int32_t* page_table, int mode,
                                const int64_t* req_pool_indices, const int64_t* seq_lens,
                                const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
-                               float* attn_lse, uint32_t* split_tickets, int num_splits, int64_t bs, int hq,
-                               int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
-                               float sm_scale, float logit_cap, int dtype, void* stream) {
+                               float* attn_lse, uint32_t* split_tickets, const int32_t* kv_chunk_keys,
+                               int num_splits, int64_t bs, int hq, int kv_lora_rank, int rope_dim, int64_t q_stride,
+                               int64_t num_slots, float sm_scale, float logit_cap, int dtype, void* stream) {
   MI355_REQUIRE(q && kv_buffer && o && page_table, MI355_ERR_INVALID, "decode_attention_mla: null pointer");
   MI355_REQUIRE(mode == 0 || mode == 1, MI355_ERR_INVALID, "decode_attention_mla: mode must be 0|1");
   if (mode == 0)
@@ -2299,6 +2316,7 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   p.hkv = 1;
   p.sm_scale = sm_scale;
   p.logit_cap = logit_cap;
+  p.chunk_keys = kv_chunk_keys;
   p.k_slot_stride = D;   // one latent row per slot; the value is its first kv_lora_rank features
   p.v_slot_stride = D;
   hipStream_t st = (hipStream_t)stream;

@@ -35,6 +35,7 @@ MLA_EXTEND_TILED_MIN_WGS = 256
 class ForwardMetadata:
     num_kv_splits: int = 1
     tickets: Optional[torch.Tensor] = None   # arrival counters of the in-kernel split merge (zero between launches)
+    kv_chunk_keys: Optional[torch.Tensor] = None   # int32 [1] on the device: the batch's keys per KV split (per-sequence split plan)
     attn_logits: Optional[torch.Tensor] = None
     attn_lse: Optional[torch.Tensor] = None
     qo_indptr: Optional[torch.Tensor] = None
@@ -73,6 +74,10 @@ class Mi355AttnBackend(AttentionBackend):
         self._retired = []      # outgrown scratch: captured graphs may still point into it
         self._retired_tickets = []   # outgrown counter arrays, for the same reason; cleared with the live one
         self._dummy_idx = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # keys per KV split of the current batch, read by the decode kernels when they run (also inside
+        # replayed graphs): a sequence shorter than the longest one is cut into fewer splits
+        # (get_num_kv_splits_triton of the reference, triton_backend.py:875-924)
+        self._chunk_keys = torch.ones(1, dtype=torch.int32, device=self.device)
         self.graph_num_splits = {}
         self.graph_window_indptr = None
         self.graph_window_indices = None
@@ -133,8 +138,10 @@ class Mi355AttnBackend(AttentionBackend):
             wsplits = self._plan_splits(bs, min(max_len, self.sliding_window_size + 1)) if self.sliding_window_size else 1
             logits, lse = self._scratch(bs, max(splits, wsplits)) if max(splits, wsplits) > 1 else (None, None)
             md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits,
-                                 tickets=self._tickets if logits is not None else None)
+                                 tickets=self._tickets if logits is not None else None,
+                                 kv_chunk_keys=self._chunk_keys if splits > 1 else None)
             self._reset_tickets(max(splits, wsplits))
+            self._set_chunk_keys(splits, max_len)
             if self.sliding_window_size:
                 cpu = forward_batch.seq_lens_cpu.tolist() if forward_batch.seq_lens_cpu is not None else None
                 md.window_kv_indptr, md.window_kv_indices = self._window(
@@ -178,7 +185,9 @@ class Mi355AttnBackend(AttentionBackend):
         wsplits = self._plan_splits(bs, self.sliding_window_size + 1) if self.sliding_window_size else 1
         logits, lse = self._scratch(bs, max(splits, wsplits)) if max(splits, wsplits) > 1 else (None, None)
         md = ForwardMetadata(num_kv_splits=splits, attn_logits=logits, attn_lse=lse, window_num_kv_splits=wsplits,
-                             tickets=self._tickets if logits is not None else None)
+                             tickets=self._tickets if logits is not None else None,
+                             kv_chunk_keys=self._chunk_keys if splits > 1 else None)
+        self._set_chunk_keys(splits, 1)   # the capture runs on fill-value lengths
         if self.sliding_window_size:
             md.window_kv_indptr, md.window_kv_indices = self._window(
                 seq_lens[:bs], None, req_pool_indices[:bs], bs, self.graph_window_indptr, self.graph_window_indices)
@@ -190,7 +199,19 @@ class Mi355AttnBackend(AttentionBackend):
         # window gather of sliding-window models is refreshed (into the buffers the graph captured)
         if self.sliding_window_size:
             self._window(seq_lens[:bs], None, req_pool_indices[:bs], bs, self.graph_window_indptr, self.graph_window_indices)
-        self._reset_tickets(max(self.graph_num_splits.get(bs, 1), 2 if self.sliding_window_size else 1))
+        splits = self.graph_num_splits.get(bs, 1)
+        self._reset_tickets(max(splits, 2 if self.sliding_window_size else 1))
+        if splits > 1:
+            # the graph was planned for the longest context the model can reach; the batch in front of us sets
+            # the chunk, so that its longest sequence uses every split and shorter ones proportionally fewer
+            if seq_lens_cpu is not None:
+                self._set_chunk_keys(splits, int(seq_lens_cpu.max()) if bs > 0 else 1)
+            else:
+                self._chunk_keys.copy_(((seq_lens[:bs].max() + (splits - 1)) // splits).clamp(min=1).to(torch.int32).view(1))
+
+    def _set_chunk_keys(self, splits: int, max_len: int):
+        if splits > 1:
+            self._chunk_keys.fill_(max(1, (max_len + splits - 1) // splits))
 
     def _reset_tickets(self, splits: int):
         """The kernels hand the split-merge counters back zeroed; a launch that died half-way (a failed
@@ -222,7 +243,7 @@ class Mi355AttnBackend(AttentionBackend):
                 o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
                 forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
                 forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, pool.kv_lora_rank,
-                layer.scaling, layer.logit_cap, tickets=md.tickets)
+                layer.scaling, layer.logit_cap, tickets=md.tickets, kv_chunk_keys=md.kv_chunk_keys)
             return o
         if self._windowed(layer):
             ops.decode_attention_fwd(
@@ -238,7 +259,7 @@ class Mi355AttnBackend(AttentionBackend):
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
             forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits,
-            layer.scaling, layer.logit_cap, tickets=md.tickets)
+            layer.scaling, layer.logit_cap, tickets=md.tickets, kv_chunk_keys=md.kv_chunk_keys)
         return o
 
     def _windowed(self, layer) -> bool:
@@ -267,7 +288,7 @@ class Mi355AttnBackend(AttentionBackend):
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
             forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, layer.scaling,
-            part_x_scale=part_x_scale, part_w_scale=part_w_scale, tickets=md.tickets)
+            part_x_scale=part_x_scale, part_w_scale=part_w_scale, tickets=md.tickets, kv_chunk_keys=md.kv_chunk_keys)
         return o
 
     @staticmethod

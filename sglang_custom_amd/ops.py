@@ -295,6 +295,15 @@ def _tickets(t, need: int):
     return t.data_ptr()
 
 
+def _chunk(t):
+    """Device pointer of the batch's keys-per-split value (None: every sequence is cut into num_kv_splits)."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.int32 and t.numel() >= 1):
+        raise _lib.Mi355Error("kv_chunk_keys must be an int32 tensor on the GPU")
+    return t.data_ptr()
+
+
 def _split_scratch(attn_logits, attn_lse, rows: int, dv: int, splits: int) -> None:
     """The kernels write rows * splits partial outputs of dv floats and as many log-sum-exps: refuse a
     scratch pair that cannot hold them (the C ABI sees raw pointers and cannot).  Raises Mi355Error
@@ -318,7 +327,7 @@ def decode_num_splits(bs: int, hkv: int, max_seq_len: int, max_splits: int) -> i
 
 def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
                          num_kv_splits: int, max_kv_splits: int, sm_scale: float,
-                         logit_cap: float = 0.0, tickets=None) -> None:
+                         logit_cap: float = 0.0, tickets=None, kv_chunk_keys=None) -> None:
     """decode_attention_fwd(...) of the Triton backend (triton_ops/decode_attention.py:677-728),
     kv_indptr/kv_indices addressing.  num_kv_splits is one int for the whole batch.
     tickets: see decode_attention_paged."""
@@ -333,13 +342,13 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     check(_lib_().mi355_decode_attention(
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         kv_indices.data_ptr(), 1, None, None, kv_indptr.data_ptr(), 0, _p(attn_logits),
-        _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), k_buffer.shape[0], float(sm_scale),
+        _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), k_buffer.shape[0], float(sm_scale),
         float(logit_cap), _dt(q), _stream(q)), "decode_attention")
 
 
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
                            attn_logits, attn_lse, num_kv_splits: int, sm_scale: float,
-                           logit_cap: float = 0.0, tickets=None) -> None:
+                           logit_cap: float = 0.0, tickets=None, kv_chunk_keys=None) -> None:
     """decode_attention_cpu-style addressing (sgl-kernel/csrc/cpu/decode.cpp:1375): the kernel
     reads req_to_token[req_pool_indices[b], :seq_lens[b]] directly, no kv_indices gather.
     tickets (optional): >= B * Hq int32 arrival counters, zero between calls (the kernel leaves them
@@ -355,7 +364,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
     check(_lib_().mi355_decode_attention(
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
-        req_to_token.stride(0), _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, Hkv, D, Dv,
+        req_to_token.stride(0), _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, Hkv, D, Dv,
         q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer), _stream(q)),
         "decode_attention")
 
@@ -382,7 +391,7 @@ def decode_attention_paged_static(q, k_buffer, v_buffer, o, req_to_token, req_po
 
 def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache, k_buffer, v_buffer, o, req_to_token,
                                req_pool_indices, seq_lens, attn_logits, attn_lse, num_kv_splits: int,
-                               sm_scale: float, part_x_scale=None, part_w_scale=None, tickets=None) -> None:
+                               sm_scale: float, part_x_scale=None, part_w_scale=None, tickets=None, kv_chunk_keys=None) -> None:
     """Decode attention straight from the qkv GEMM's split-K partials [splits, B, (Hq + 2 Hkv) * D]:
     sums them, applies neox RoPE to q and the new k, writes the new k / v rows into cache slot
     out_cache_loc[b] (= req_to_token[req_pool_indices[b], seq_lens[b] - 1] for real rows) and attends.  o: [B, Hq, D]."""
@@ -408,13 +417,13 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
         out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
         _dt(cos_sin_cache), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0), _p(attn_logits),
-        _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _kvdt(o, k_buffer), _stream(o)),
+        _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _kvdt(o, k_buffer), _stream(o)),
         "decode_attention_fused_qkv")
 
 
 def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
                          attn_lse, num_kv_splits: int, kv_lora_rank: int, sm_scale: float,
-                         logit_cap: float = 0.0, tickets=None) -> None:
+                         logit_cap: float = 0.0, tickets=None, kv_chunk_keys=None) -> None:
     """MQA over the compressed MLA cache (deepseek_v2.py:866-875): kv_buffer [slots, 1, rank + rope],
     q [B, H, rank + rope], o [B, H, rank]; the value is kv_buffer[..., :rank].  kv_buffer may hold
     e4m3fn bytes (kv_cache_dtype fp8_e4m3): the rows are widened exactly on use."""
@@ -428,7 +437,7 @@ def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_le
     check(_lib_().mi355_decode_attention_mla(
         q.data_ptr(), kv_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0),
-        _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), num_kv_splits, B, Hq, kv_lora_rank, D - kv_lora_rank,
+        _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, kv_lora_rank, D - kv_lora_rank,
         q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, kv_buffer), _stream(q)),
         "decode_attention_mla")
 

@@ -88,7 +88,7 @@ def decode_num_splits(bs, hkv, max_seq_len, max_splits):
 
 
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
-                           attn_logits, attn_lse, num_kv_splits, sm_scale, logit_cap=0.0, tickets=None):
+                           attn_logits, attn_lse, num_kv_splits, sm_scale, logit_cap=0.0, tickets=None, kv_chunk_keys=None):
     assert logit_cap == 0.0
     gqa = q.shape[1] != k_buffer.shape[1]
     o.copy_(ops_ref.decode_attention(q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens,
@@ -96,7 +96,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
 
 
 def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
-                         num_kv_splits, kv_lora_rank, sm_scale, logit_cap=0.0, tickets=None):
+                         num_kv_splits, kv_lora_rank, sm_scale, logit_cap=0.0, tickets=None, kv_chunk_keys=None):
     """Multi-query attention over latent rows: keys = whole rows, values = their first kv_lora_rank features."""
     assert not logit_cap
     o.copy_(ops_ref.decode_attention(q, kv_buffer, kv_buffer[..., :kv_lora_rank], req_to_token, req_pool_indices,

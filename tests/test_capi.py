@@ -52,9 +52,9 @@ def test_abi_version_and_error_codes(lib):
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.mi355_rmsnorm(p, p, p, 4, 64, 32, 64, 1e-5, 1, None) == -1       # stride < hidden
     assert lib.mi355_rmsnorm(p, p, p, 4, 64, 64, 64, 1e-5, 9, None) == -2       # unknown dtype
-    assert lib.mi355_decode_attention(p, p, p, p, p, 0, p, p, None, 8, None, None, None, 1, 2, 8, 3, 64, 64,
+    assert lib.mi355_decode_attention(p, p, p, p, p, 0, p, p, None, 8, None, None, None, None, 1, 2, 8, 3, 64, 64,
                                       512, 16, 0.1, 0.0, 1, None) == -1        # 8 % 3 != 0
-    assert lib.mi355_decode_attention(p, p, p, p, p, 0, p, p, None, 8, None, None, None, 4, 2, 8, 2, 64, 64,
+    assert lib.mi355_decode_attention(p, p, p, p, p, 0, p, p, None, 8, None, None, None, None, 4, 2, 8, 2, 64, 64,
                                       512, 16, 0.1, 0.0, 1, None) == -1        # splits need scratch
     assert lib.mi355_linear(p, p, p, None, 4, 64, 64, 32, None, 0, 1, 1, None) == -1   # x_stride < k
     assert lib.mi355_extend_attention(p, p, p, p, p, p, p, p, p, None, None, 1, 1, 1, 8, 130, 1, 64, 64,

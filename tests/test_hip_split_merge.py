@@ -253,3 +253,68 @@ def test_undersized_split_scratch_is_refused_before_any_launch(ops):
     ops.decode_attention_paged(q, kc, vc, o, r2t, pool, lt, full_o, full_l, splits, D ** -0.5)
     torch.cuda.synchronize()
     assert not bool((o == 7.0).all())
+
+
+@pytest.mark.parametrize("in_kernel_merge", [False, True])
+def test_per_sequence_split_plan_on_a_ragged_batch(ops, in_kernel_merge):
+    """kv_chunk_keys: one int32 on the device = the batch's keys per split; sequence b runs
+    ceil(len(b) / chunk) splits instead of num_kv_splits (the reference's per-sequence num_kv_splits,
+    triton_backend.py:875-924).  A ragged batch of 64 sequences (16 .. 4096 keys) under one 8-split launch:
+    every sequence's output is bit for bit what that sequence gets alone from a launch with as many splits as
+    the plan gave it; the chunk is read when the kernel runs (changing the device value changes the plan of a
+    replayed graph); a chunk too small to cover a sequence falls back to the even cut."""
+    dt, D, Hq, Hkv, S = torch.bfloat16, 128, 8, 2, 8
+    g = torch.Generator().manual_seed(77)
+    lens = [16, 4096, 17, 700] + torch.randint(16, 4097, (60,), generator=g).tolist()
+    B = len(lens)
+    q, kc, vc, r2t, pool, lt = (x.to(DEV) for x in _paged(950, dt, B, Hq, Hkv, D, lens))
+    al = torch.empty((B, Hq, S, D), dtype=torch.float32, device=DEV)
+    ll = torch.empty((B, Hq, S), dtype=torch.float32, device=DEV)
+    tickets = torch.zeros(B * Hq, dtype=torch.int32, device=DEV) if in_kernel_merge else None
+    chunk = (max(lens) + S - 1) // S
+    ck = torch.tensor([chunk], dtype=torch.int32, device=DEV)
+    got = torch.full((B, Hq, D), float("nan"), dtype=dt, device=DEV)
+    ops.decode_attention_paged(q, kc, vc, got, r2t, pool, lt, al, ll, S, D ** -0.5, tickets=tickets, kv_chunk_keys=ck)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got.float()).any()
+    # the partials of the splits a sequence does not use are empty (-inf log-sum-exp)
+    for b in (0, 2, 3):
+        used = (lens[b] + chunk - 1) // chunk
+        assert torch.isinf(ll[b, :, used:]).all() and torch.isfinite(ll[b, :, :used]).all(), b
+    # per request, alone, with the split count the plan gave it and an even cut of ITS length when that equals the chunk cut
+    one_al = torch.empty((1, Hq, S, D), dtype=torch.float32, device=DEV)
+    one_ll = torch.empty((1, Hq, S), dtype=torch.float32, device=DEV)
+    for b in range(B):
+        alone = torch.full((1, Hq, D), float("nan"), dtype=dt, device=DEV)
+        ops.decode_attention_paged(q[b: b + 1], kc, vc, alone, r2t, pool[b: b + 1], lt[b: b + 1], one_al, one_ll, S, D ** -0.5,
+                                   kv_chunk_keys=ck)
+        torch.cuda.synchronize()
+        assert torch.equal(_bits(alone[0]), _bits(got[b])), (b, lens[b])
+    # single-split sequences equal the unsplit kernel bit for bit only up to the merge's rounding: check against the oracle instead
+    cpu = [x.cpu() for x in (q, kc, vc, r2t, pool)]
+    ref = ops_ref.decode_attention(*cpu, torch.tensor(lens, dtype=torch.int64), D ** -0.5, True)
+    assert (got.cpu().double() - ref.double()).abs().max().item() <= 1.6e-2
+    # the value is read at run time: a graph captured with one chunk follows the device value on replay
+    out = torch.full_like(got, float("nan"))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.decode_attention_paged(q, kc, vc, out, r2t, pool, lt, al, ll, S, D ** -0.5, tickets=tickets, kv_chunk_keys=ck)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            ops.decode_attention_paged(q, kc, vc, out, r2t, pool, lt, al, ll, S, D ** -0.5, tickets=tickets, kv_chunk_keys=ck)
+    torch.cuda.current_stream().wait_stream(s)
+    ck.fill_(1)          # too small for any sequence: every sequence falls back to the even 8-way cut
+    gr.replay()
+    torch.cuda.synchronize()
+    even = torch.full_like(got, float("nan"))
+    ops.decode_attention_paged(q, kc, vc, even, r2t, pool, lt, al, ll, S, D ** -0.5, tickets=tickets)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(out), _bits(even))
+    ck.fill_(chunk)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(out), _bits(got))
+    if tickets is not None:
+        assert int(tickets.abs().sum()) == 0

@@ -28,7 +28,7 @@ def _call(lib, static, q, kc, vc, r2t, pool, lens, splits, scratch=None):
         al, ll = scratch
         rc = lib.mi355_decode_attention(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), o.data_ptr(), r2t.data_ptr(), 0,
                                         pool.data_ptr(), lens.data_ptr(), None, r2t.stride(0), al.data_ptr(), ll.data_ptr(),
-                                        None, splits, *common_tail)
+                                        None, None, splits, *common_tail)
     assert rc == 0, lib.mi355_last_error()
     torch.cuda.synchronize()
     return o
