@@ -293,6 +293,30 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
                                int kv_lora_rank, int rope_dim, int64_t q_stride, int64_t num_slots,
                                float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* MLA decode with RoPE and the cache write inside the launch: q's rope part (features rank .. rank + rope of
+ * every head) and k_pe [B, rope] arrive UNROTATED, k_nope [B, rank] is the normed latent; the launch rotates
+ * both at positions[b] (cos_sin_cache [max_pos, rope]: cos | sin, fp32 or the tensor dtype; interleaved
+ * pairs, or neox pairs when is_neox), writes the new row [k_nope | rope(k_pe)] to kv_buffer[out_cache_loc[b]]
+ * and attends over the sequence INCLUDING that row (page_table must already name out_cache_loc[b] as the
+ * last key; padded rows of a captured batch point out_cache_loc at the sink slot 0).  Bit for bit
+ * mi355_rope_inplace on (q rope part, k_pe) + mi355_set_kv_buffer + mi355_decode_attention_mla, in one launch
+ * instead of three.  Needs rank 512 + rope 64, a 16-bit dtype and cache (..._supported returns 1); everything
+ * else as mi355_decode_attention_mla.
+ * replaces: decode_attention_fwd_grouped_rope (layers/attention/triton_ops/rocm_mla_decode_rope.py:402-439),
+ *           called from DeepseekV2AttentionMLA.forward_absorb_fused_mla_rope_{prepare,core}
+ *           (python/sglang/srt/models/deepseek_v2.py:1337-1449, 1502-1536; dispatched at :973-980). */
+int mi355_decode_attention_mla_fused_rope_supported(int kv_lora_rank, int rope_dim, int dtype, int cache_is_fp8);
+int mi355_decode_attention_mla_fused_rope(const void* q, const void* k_nope, int64_t k_nope_stride, const void* k_pe,
+                                          int64_t k_pe_stride, const int64_t* positions, const int64_t* out_cache_loc,
+                                          const void* cos_sin_cache, int cache_dtype, int is_neox, void* kv_buffer,
+                                          void* o, const int32_t* page_table, int mode,
+                                          const int64_t* req_pool_indices, const int64_t* seq_lens,
+                                          const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
+                                          float* attn_lse, uint32_t* split_tickets, const int32_t* kv_chunk_keys,
+                                          int num_splits, int64_t bs, int hq, int kv_lora_rank, int rope_dim,
+                                          int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap,
+                                          int dtype, void* stream);
+
 /* The same attention for an EXTEND batch over cached rows: request b's new tokens are rows
  * qo_indptr[b] .. qo_indptr[b + 1] - 1 of q [T, hq, rank + rope] / o [T, hq, rank]; token i of the request
  * attends to the first (seq_lens[b] - n_new_b) + i + 1 rows of the request's req_to_token row (causal; the

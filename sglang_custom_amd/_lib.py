@@ -40,6 +40,9 @@ _SIGNATURES = {
     "mi355_packed_weight_elems": (L, [L, L]),
     "mi355_pack_weight": (I, [P, P, L, L, I, P]),
     "mi355_decode_attention_static": (I, [P, P, P, P, P, I, P, P, P, L, I, L, I, I, I, I, L, L, F, F, I, P]),
+    "mi355_decode_attention_mla_fused_rope_supported": (I, [I, I, I, I]),
+    "mi355_decode_attention_mla_fused_rope": (I, [P, P, L, P, L, P, P, P, I, I, P, P, P, I, P, P, P, L, P, P, P, P, I, L, I, I, I,
+                                                  L, L, F, F, I, P]),
     "mi355_decode_attention_mla": (I, [P, P, P, P, I, P, P, P, L, P, P, P, P, I, L, I, I, I, L, L, F, F, I, P]),
     "mi355_extend_attention_mla_supported": (I, [I, I, I, I]),
     "mi355_extend_attention_mla": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, L, L, F, F, I, P]),

@@ -1453,9 +1453,40 @@ __device__ __forceinline__ void load_to_lds_16_s(uint64_t base, unsigned lane_of
         : "memory");
 }
 
-template <typename T, bool CAP, int NSB>
+// Inputs of the decode launch that also applies RoPE and writes the new token's latent row: q's rope part
+// and k_pe arrive UNROTATED, the new row [k_nope | rope(k_pe)] is not in the cache yet.
+struct MlaRope {
+  const void* k_nope;         // [B] rows of 512 features (the normed latent), row stride below (elements)
+  const void* k_pe;           // [B] rows of 64 features, not rotated
+  int64_t k_nope_stride, k_pe_stride;
+  const int64_t* positions;   // [B]
+  const int64_t* out_loc;     // [B] cache slot of the new token (padded rows of a captured batch name the sink slot)
+  const void* cos_sin;        // [max_pos][64]: cos (32) | sin (32), fp32 or the tensor dtype
+  int cache_f32, is_neox;
+};
+
+// One rotation pair with the rounding points of rope_kernel (cos, sin -> T; every product and the sum /
+// difference round to T on their own).
+template <typename T>
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float sn, T& o1, T& o2) {
+#pragma clang fp contract(off)
+  c = round_to<T>(c);
+  sn = round_to<T>(sn);
+  o1 = from_f32<T>(round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * sn)));
+  o2 = from_f32<T>(round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * sn)));
+}
+template <typename T> __device__ __forceinline__ float mla_cs_t(const MlaRope& rp, int64_t pos, int idx) {
+  return rp.cache_f32 ? static_cast<const float*>(rp.cos_sin)[pos * MLA_ROPE + idx]
+                      : to_f32(static_cast<const T*>(rp.cos_sin)[pos * MLA_ROPE + idx]);
+}
+
+// ROPE: the launch rotates the query's rope part (in registers) and the new token's k_pe, writes the new
+// latent row to the cache (one workgroup per sequence) and -- in every workgroup whose key range ends at the
+// new token -- puts that row into the LDS tile over whatever the load unit fetched from the not yet written
+// slot.  Same bits as mi355_rope_inplace + mi355_set_kv_buffer + this kernel without ROPE.
+template <typename T, bool CAP, int NSB, bool ROPE = false>
 __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
-    const T* __restrict__ q, const T* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p) {
+    const T* __restrict__ q, const T* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p, MlaRope rp) {
   constexpr int NS = MLA_D / 32;   // 18 score k-steps
   using frag = typename Mfma<T>::frag;
   using frag4 = typename Mfma16<T>::frag;
@@ -1475,6 +1506,50 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const int n_steps = k1 > k0 ? (int)((k1 - k0 + 31) / 32) : 0;   // 32 keys (two tiles) per step
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  // ROPE: threads 0..63 hold one 16-byte piece of the new row's latent part, threads 64..71 (interleaved
+  // pairs) or 64..67 (neox pairs: a piece and its partner 32 features on) its rotated rope part.
+  const bool has_new = ROPE && k1 == len && len > k0;   // this workgroup's range ends at the new token
+  Vec<T, 8> new_a, new_b;
+  int64_t rope_pos = 0;
+  if constexpr (ROPE) {
+    rope_pos = rp.positions[b];
+    if (has_new) {
+      const int tid = threadIdx.x;
+      if (tid < 64) {
+        new_a = ldvec<T, 8>(static_cast<const T*>(rp.k_nope) + (int64_t)b * rp.k_nope_stride + 8 * tid);
+      } else if (tid < 72) {
+        const T* kp = static_cast<const T*>(rp.k_pe) + (int64_t)b * rp.k_pe_stride;
+        const int c = tid - 64;
+        if (!rp.is_neox) {
+          const Vec<T, 8> x = ldvec<T, 8>(kp + 8 * c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * c + j;
+            rope_pair<T>(to_f32(x.v[2 * j]), to_f32(x.v[2 * j + 1]), mla_cs_t<T>(rp, rope_pos, i),
+                         mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + i), new_a.v[2 * j], new_a.v[2 * j + 1]);
+          }
+        } else if (c < 4) {
+          const Vec<T, 8> x1 = ldvec<T, 8>(kp + 8 * c), x2 = ldvec<T, 8>(kp + MLA_ROPE / 2 + 8 * c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = 8 * c + j;
+            rope_pair<T>(to_f32(x1.v[j]), to_f32(x2.v[j]), mla_cs_t<T>(rp, rope_pos, i),
+                         mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + i), new_a.v[j], new_b.v[j]);
+          }
+        }
+      }
+      if (blockIdx.x == 0) {   // one workgroup per sequence writes the row to the cache
+        T* dst = const_cast<T*>(kvbuf) + rp.out_loc[b] * p.k_slot_stride;
+        if (tid < 64) stvec<T, 8>(dst + 8 * tid, new_a);
+        else if (tid < 72 && !rp.is_neox) stvec<T, 8>(dst + MLA_RANK + 8 * (tid - 64), new_a);
+        else if (tid < 68) {
+          stvec<T, 8>(dst + MLA_RANK + 8 * (tid - 64), new_a);
+          stvec<T, 8>(dst + MLA_RANK + MLA_ROPE / 2 + 8 * (tid - 64), new_b);
+        }
+      }
+    }
+  }
 
   // page-table reads through the scalar unit (wave-uniform index, read-only data)
   const int32_t __attribute__((address_space(4)))* pt =
@@ -1542,6 +1617,29 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
     const T* qp = q + (int64_t)b * p.q_stride + (int64_t)hq_c * MLA_D + 8 * c4;
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 32 * s);
+    if constexpr (ROPE) {
+      // rope part = k-steps 16 and 17: the lane holds features 8 c4 .. + 7 and 32 + 8 c4 .. + 7 of its head
+      Vec<T, 8> a = __builtin_bit_cast(Vec<T, 8>, qf[16]), b2 = __builtin_bit_cast(Vec<T, 8>, qf[17]);
+      if (!rp.is_neox) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ia = 4 * c4 + j, ib = 16 + 4 * c4 + j;
+          rope_pair<T>(to_f32(a.v[2 * j]), to_f32(a.v[2 * j + 1]), mla_cs_t<T>(rp, rope_pos, ia),
+                       mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + ia), a.v[2 * j], a.v[2 * j + 1]);
+          rope_pair<T>(to_f32(b2.v[2 * j]), to_f32(b2.v[2 * j + 1]), mla_cs_t<T>(rp, rope_pos, ib),
+                       mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + ib), b2.v[2 * j], b2.v[2 * j + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = 8 * c4 + j;
+          rope_pair<T>(to_f32(a.v[j]), to_f32(b2.v[j]), mla_cs_t<T>(rp, rope_pos, i),
+                       mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + i), a.v[j], b2.v[j]);
+        }
+      }
+      qf[16] = __builtin_bit_cast(frag, a);
+      qf[17] = __builtin_bit_cast(frag, b2);
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(qf[s]));
   }
@@ -1636,6 +1734,25 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
       __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's tiles are free
       if (t + P < n_steps) issue_step(t + P, s_nxt);
       s_nxt = slots_of(t + P + 1);
+      if constexpr (ROPE) {
+        if (has_new && t == n_steps - 1) {
+          // the new token is the last key of the last step: its row goes into the tile over what was fetched
+          // from the slot (every wave's loads of this step have landed: the barrier above)
+          const int kl = (int)(len - 1 - k0) - 32 * t;           // 0 .. 31 inside the step
+          char* row_tile = sm_raw + (2 * (t % NSB) + (kl >> 4)) * MLR_TILE;
+          const int r = kl & 15, tid = threadIdx.x;
+          if (tid < 64) {
+            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_ROWB * r + 16 * tid) = new_a;
+          } else if (tid < 72 && !rp.is_neox) {
+            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 64) ^ ((r >> 1) & 7))) = new_a;
+          } else if (tid < 68) {
+            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 64) ^ ((r >> 1) & 7))) = new_a;
+            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 60) ^ ((r >> 1) & 7))) = new_b;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
       step_compute(t, sm_raw + 2 * (t % NSB) * MLR_TILE);
     }
   }
@@ -2277,7 +2394,7 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
   return MI355_OK;
 }
 
-int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
+static int decode_attention_mla_impl(const MlaRope* rope, const void* q, const void* kv_buffer, void* o,
                                const int32_t* page_table, int mode,
                                const int64_t* req_pool_indices, const int64_t* seq_lens,
                                const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
@@ -2320,6 +2437,14 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   p.k_slot_stride = D;   // one latent row per slot; the value is its first kv_lora_rank features
   p.v_slot_stride = D;
   hipStream_t st = (hipStream_t)stream;
+  if (rope) {
+    // rotation + cache write inside the launch: only the LDS-ring kernel has it
+    MI355_REQUIRE(!kv8 && kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
+                      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && aligned16(attn_logits) &&
+                      g_decode_variant == 0,
+                  MI355_ERR_UNSUPPORTED,
+                  "decode_attention_mla_fused_rope: needs rank 512 + rope 64, a 16-bit dtype and cache, 16-byte aligned pointers");
+  }
   if (kv8) {
     // e4m3fn latent rows: the register kernel, widening on use (the LDS-ring kernel lands raw 16-bit rows)
     MI355_REQUIRE(kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
@@ -2351,10 +2476,12 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
       if (num_splits > 1 && num_splits <= MERGE_MAX_SPLITS && aligned16(o)) p.tickets = split_tickets;   // this kernel merges the splits itself
 #define MLR_LAUNCH(T_, CAP_)                                                                                   \
   do {                                                                                                         \
-    auto kern = deep ? decode_attn_mla_ring_kernel<T_, CAP_, 4> : decode_attn_mla_ring_kernel<T_, CAP_, NSB_>; \
-    const int lds_ = deep ? mlr_lds_bytes(4) : mlr_lds_bytes(NSB_);                                            \
+    auto kern = rope ? decode_attn_mla_ring_kernel<T_, CAP_, NSB_, true>                                       \
+                     : deep ? decode_attn_mla_ring_kernel<T_, CAP_, 4> : decode_attn_mla_ring_kernel<T_, CAP_, NSB_>; \
+    const int lds_ = deep && !rope ? mlr_lds_bytes(4) : mlr_lds_bytes(NSB_);                                   \
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p);        \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p,         \
+                       rope ? *rope : MlaRope{});                                                              \
     if (num_splits > 1 && !p.tickets)                                                                          \
       hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
                          p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
@@ -2390,6 +2517,55 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
   });
   MI355_CHECK_LAUNCH("decode_attention_mla");
   return MI355_OK;
+}
+
+int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
+                               const int32_t* page_table, int mode,
+                               const int64_t* req_pool_indices, const int64_t* seq_lens,
+                               const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
+                               float* attn_lse, uint32_t* split_tickets, const int32_t* kv_chunk_keys,
+                               int num_splits, int64_t bs, int hq, int kv_lora_rank, int rope_dim, int64_t q_stride,
+                               int64_t num_slots, float sm_scale, float logit_cap, int dtype, void* stream) {
+  return decode_attention_mla_impl(nullptr, q, kv_buffer, o, page_table, mode, req_pool_indices, seq_lens, kv_indptr,
+                                   table_stride, attn_logits, attn_lse, split_tickets, kv_chunk_keys, num_splits, bs, hq,
+                                   kv_lora_rank, rope_dim, q_stride, num_slots, sm_scale, logit_cap, dtype, stream);
+}
+
+int mi355_decode_attention_mla_fused_rope_supported(int kv_lora_rank, int rope_dim, int dtype, int cache_is_fp8) {
+  return kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
+         !cache_is_fp8 && g_decode_variant == 0;
+}
+
+int mi355_decode_attention_mla_fused_rope(const void* q, const void* k_nope, int64_t k_nope_stride, const void* k_pe,
+                                          int64_t k_pe_stride, const int64_t* positions, const int64_t* out_cache_loc,
+                                          const void* cos_sin_cache, int cache_dtype, int is_neox, void* kv_buffer,
+                                          void* o, const int32_t* page_table, int mode,
+                                          const int64_t* req_pool_indices, const int64_t* seq_lens,
+                                          const int32_t* kv_indptr, int64_t table_stride, float* attn_logits,
+                                          float* attn_lse, uint32_t* split_tickets, const int32_t* kv_chunk_keys,
+                                          int num_splits, int64_t bs, int hq, int kv_lora_rank, int rope_dim,
+                                          int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap,
+                                          int dtype, void* stream) {
+  MI355_REQUIRE(k_nope && k_pe && positions && out_cache_loc && cos_sin_cache, MI355_ERR_INVALID,
+                "decode_attention_mla_fused_rope: null pointer");
+  MI355_REQUIRE(k_nope_stride >= kv_lora_rank && k_nope_stride % 8 == 0 && k_pe_stride >= rope_dim && k_pe_stride % 8 == 0 &&
+                    aligned16(k_nope) && aligned16(k_pe),
+                MI355_ERR_INVALID, "decode_attention_mla_fused_rope: k_nope / k_pe rows must be 16-byte aligned");
+  MI355_REQUIRE(cache_dtype == MI355_F32 || cache_dtype == (dtype & 0xff), MI355_ERR_UNSUPPORTED,
+                "decode_attention_mla_fused_rope: cos_sin_cache must be fp32 or the tensor dtype");
+  MlaRope rp;
+  rp.k_nope = k_nope;
+  rp.k_pe = k_pe;
+  rp.k_nope_stride = k_nope_stride;
+  rp.k_pe_stride = k_pe_stride;
+  rp.positions = positions;
+  rp.out_loc = out_cache_loc;
+  rp.cos_sin = cos_sin_cache;
+  rp.cache_f32 = cache_dtype == MI355_F32;
+  rp.is_neox = is_neox != 0;
+  return decode_attention_mla_impl(&rp, q, kv_buffer, o, page_table, mode, req_pool_indices, seq_lens, kv_indptr,
+                                   table_stride, attn_logits, attn_lse, split_tickets, kv_chunk_keys, num_splits, bs, hq,
+                                   kv_lora_rank, rope_dim, q_stride, num_slots, sm_scale, logit_cap, dtype, stream);
 }
 
 int mi355_extend_attention_mla_supported(int hq, int kv_lora_rank, int rope_dim, int dtype) {

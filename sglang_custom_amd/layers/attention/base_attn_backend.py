@@ -60,3 +60,11 @@ class AttentionBackend(ABC):
                                  part_x_scale=None, part_w_scale=None, out_dtype=None):
         raise NotImplementedError()
 
+    def supports_mla_fused_rope(self, layer, rotary_emb, forward_batch, dtype) -> bool:
+        """Whether forward_decode_mla_fused_rope (MLA decode that rotates q / k_pe and writes the new latent
+        row inside the attention launch) serves this step; the default declines."""
+        return False
+
+    def forward_decode_mla_fused_rope(self, q, k_nope, k_pe, positions, rotary_emb, layer, forward_batch):
+        raise NotImplementedError()
+

@@ -29,6 +29,9 @@ MAX_KV_SPLITS = 64
 # workgroups, so batches too small to fill the chip with it stay on the per-token pass.
 MLA_EXTEND_TILED = os.environ.get("MI355_MLA_EXTEND", "tiled") == "tiled"
 MLA_EXTEND_TILED_MIN_WGS = 256
+# MLA decode with RoPE and the latent-row write inside the attention launch ("on"), or rope / cache write /
+# attention as separate launches ("off"); the reference's switch is SGLANG_ROCM_FUSED_DECODE_MLA.
+MLA_FUSED_ROPE = os.environ.get("MI355_MLA_FUSED_ROPE", "on") == "on"
 
 
 @dataclasses.dataclass
@@ -289,6 +292,31 @@ class Mi355AttnBackend(AttentionBackend):
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
             forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits, layer.scaling,
             part_x_scale=part_x_scale, part_w_scale=part_w_scale, tickets=md.tickets, kv_chunk_keys=md.kv_chunk_keys)
+        return o
+
+    def supports_mla_fused_rope(self, layer, rotary_emb, forward_batch, dtype) -> bool:
+        """Whether forward_decode_mla_fused_rope serves this decode step (MLA_FUSED_ROPE of the reference,
+        deepseek_v2.py:973-980: ROCm, decode only)."""
+        pool = forward_batch.token_to_kv_pool
+        return (MLA_FUSED_ROPE and forward_batch.forward_mode.is_decode() and hasattr(pool, "kv_lora_rank")
+                and rotary_emb.rotary_dim == pool.qk_rope_head_dim
+                and rotary_emb.cos_sin_cache.dtype in (torch.float32, dtype) and pool.dtype == dtype
+                and get_ops().decode_attention_mla_fused_rope_supported(pool.kv_lora_rank, pool.qk_rope_head_dim, dtype,
+                                                                         pool.dtype))
+
+    def forward_decode_mla_fused_rope(self, q, k_nope, k_pe, positions, rotary_emb, layer, forward_batch):
+        """Absorbed MLA decode from the UNROTATED q rope part / k_pe: RoPE, the write of the new latent row
+        and the attention in one launch.  Same result as rotary_emb + set_kv_buffer + forward_decode."""
+        pool = forward_batch.token_to_kv_pool
+        md = self.forward_metadata
+        q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+        o = q.new_empty((q3.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        get_ops().decode_attention_mla_fused_rope(
+            q3, k_nope, k_pe, positions.flatten(), forward_batch.out_cache_loc, rotary_emb.cos_sin_cache,
+            rotary_emb.is_neox_style, pool.get_key_buffer(layer.layer_id), o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens,
+            md.attn_logits, md.attn_lse, md.num_kv_splits, pool.kv_lora_rank, layer.scaling, layer.logit_cap,
+            tickets=md.tickets, kv_chunk_keys=md.kv_chunk_keys)
         return o
 
     @staticmethod

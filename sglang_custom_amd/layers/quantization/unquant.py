@@ -2,13 +2,14 @@
 (python/sglang/srt/layers/quantization/unquant.py:110-122).
 
 Decode-sized inputs (M <= 64 rows) and every fp32 input go to the hand-written kernels behind
-mi355_linear (weight-streaming MFMA / exact-fp32 tiled).  Large-M bf16/f16 GEMMs (prefill) have two
-implementations: the library GEMM (torch.nn.functional.linear -> hipBLASLt) and the hand-written
-256 x 256-tile matrix-core kernel behind mi355_linear_tiled, which can apply SiLU-and-mul in its
-epilogue.  PREFILL_GEMM (env MI355_PREFILL_GEMM) picks: "auto" (default) = the hand-written kernel
-where it is the faster choice on MI355X -- gate_up with the fused activation, 1.02x the library GEMM +
-activation pair -- and the library for the plain projections (where it is 4-6 % faster); "tiled" =
-the hand-written kernel for every shape it serves; "library" = never."""
+mi355_linear (weight-streaming MFMA / exact-fp32 tiled).  Large-M bf16/f16 GEMMs (prefill) run on the
+hand-written 256 x 256-tile matrix-core kernel behind mi355_linear_tiled, which can apply SiLU-and-mul in
+its epilogue.  PREFILL_GEMM (env MI355_PREFILL_GEMM) picks: "tiled" (default) = that kernel for every
+shape it serves (at least TILED_MIN_TILES output tiles; smaller problems and shapes it does not take
+fall back to the library GEMM, torch.nn.functional.linear -> hipBLASLt); "auto" = the faster of the two
+per projection as measured on MI355X (the hand-written kernel for gate_up with the fused activation,
+1.02x the library pair; the library for the plain projections, where it is 4-6 % faster); "library" =
+hipBLASLt everywhere."""
 import os
 from typing import Optional
 
@@ -21,8 +22,8 @@ SKINNY_MAX_M = 64
 # Deferred split-K reduction / fused decode step (bit-identical to the unfused kernels; the switch
 # exists so that tests and profiles can run both).
 DECODE_FUSION = True
-# "auto" | "tiled" | "library" for 16-bit GEMMs with more than SKINNY_MAX_M rows (see the module docstring)
-PREFILL_GEMM = os.environ.get("MI355_PREFILL_GEMM", "auto")
+# "tiled" | "auto" | "library" for 16-bit GEMMs with more than SKINNY_MAX_M rows (see the module docstring)
+PREFILL_GEMM = os.environ.get("MI355_PREFILL_GEMM", "tiled")
 # below this many 256 x 256 output tiles the one-tile-per-workgroup kernel leaves most CUs idle
 TILED_MIN_TILES = 192
 

@@ -167,6 +167,19 @@ class DeepseekV2AttentionMLA(nn.Module):
         assert self.w_kc is not None, "call post_load_weights() after loading kv_b_proj"
         q, latent = self._q_and_latent(hidden_states)
         k_nope = self.kv_a_layernorm(latent[..., : self.kv_lora_rank].contiguous()).unsqueeze(1)
+        backend = forward_batch.attn_backend
+        if backend.supports_mla_fused_rope(self.attn_mqa, self.rotary_emb, forward_batch, q.dtype):
+            # MLA_FUSED_ROPE (deepseek_v2.py:973-980, 1337-1536): q's rope part and k_pe go in unrotated; the
+            # decode launch rotates them, writes the new latent row and attends
+            q_nope, q_pe = q.split([self.qk_nope_head_dim, self.qk_rope_head_dim], dim=-1)
+            q_nope_out = torch.bmm(q_nope.transpose(0, 1), self.w_kc).transpose(0, 1)
+            qa = torch.cat([q_nope_out, q_pe], dim=-1)
+            attn_output = backend.forward_decode_mla_fused_rope(
+                qa, k_nope.squeeze(1), latent[..., self.kv_lora_rank:], positions, self.rotary_emb, self.attn_mqa,
+                forward_batch)
+            attn_output = attn_output.view(-1, self.num_local_heads, self.kv_lora_rank)
+            out = torch.bmm(attn_output.transpose(0, 1), self.w_vc).transpose(0, 1).flatten(1, 2)
+            return self.o_proj(out.contiguous())[0]
         k_pe = self._rope(positions, q, latent)
         q_nope, q_pe = q.split([self.qk_nope_head_dim, self.qk_rope_head_dim], dim=-1)
         q_nope_out = torch.bmm(q_nope.transpose(0, 1), self.w_kc).transpose(0, 1)       # [T, H, rank]

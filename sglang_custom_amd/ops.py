@@ -442,6 +442,42 @@ def decode_attention_mla(q, kv_buffer, o, req_to_token, req_pool_indices, seq_le
         "decode_attention_mla")
 
 
+def decode_attention_mla_fused_rope_supported(kv_lora_rank: int, rope_dim: int, dtype: torch.dtype, cache_dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib_().mi355_decode_attention_mla_fused_rope_supported(
+        kv_lora_rank, rope_dim, _DT[dtype], 1 if cache_dtype == torch.float8_e4m3fn else 0))
+
+
+def decode_attention_mla_fused_rope(q, k_nope, k_pe, positions, out_cache_loc, cos_sin_cache, is_neox: bool, kv_buffer, o,
+                                    req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse, num_kv_splits: int,
+                                    kv_lora_rank: int, sm_scale: float, logit_cap: float = 0.0, tickets=None,
+                                    kv_chunk_keys=None) -> None:
+    """decode_attention_mla with RoPE and the cache write inside the launch (the reference's ROCm kernel
+    decode_attention_fwd_grouped_rope, rocm_mla_decode_rope.py:402-439): q [B, H, rank + rope] with its rope part
+    NOT rotated, k_nope [B, rank] (row-strided view allowed), k_pe [B, rope] not rotated (row-strided view allowed);
+    rotates both at positions, writes the row [k_nope | rope(k_pe)] to kv_buffer[out_cache_loc] and attends."""
+    _gpu(q, k_nope, k_pe, positions, out_cache_loc, cos_sin_cache, kv_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    B, Hq, D = q.shape
+    rope = D - kv_lora_rank
+    assert kv_buffer.is_contiguous() and kv_buffer.shape[1] == 1 and kv_buffer.shape[2] == D and kv_buffer.dtype == q.dtype
+    assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous() and o.shape == (B, Hq, kv_lora_rank)
+    k_nope2, k_pe2 = k_nope.view(B, -1), k_pe.view(B, -1)
+    assert k_nope2.shape[1] == kv_lora_rank and k_pe2.shape[1] == rope and k_nope2.stride(1) == 1 and k_pe2.stride(1) == 1
+    assert k_nope2.dtype == q.dtype and k_pe2.dtype == q.dtype
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == B
+    assert out_cache_loc.dtype == torch.int64 and out_cache_loc.is_contiguous() and out_cache_loc.numel() == B
+    assert cos_sin_cache.is_contiguous() and cos_sin_cache.shape[1] == rope
+    assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
+    assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    _split_scratch(attn_logits, attn_lse, B * Hq, kv_lora_rank, num_kv_splits)
+    check(_lib_().mi355_decode_attention_mla_fused_rope(
+        q.data_ptr(), k_nope2.data_ptr(), k_nope2.stride(0), k_pe2.data_ptr(), k_pe2.stride(0), positions.data_ptr(),
+        out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(), _dt(cos_sin_cache), 1 if is_neox else 0, kv_buffer.data_ptr(),
+        o.data_ptr(), req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
+        req_to_token.stride(0), _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys),
+        num_kv_splits, B, Hq, kv_lora_rank, rope, q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap),
+        _dt(q), _stream(q)), "decode_attention_mla_fused_rope")
+
+
 def extend_attention_mla_supported(hq: int, kv_lora_rank: int, rope_dim: int, dtype: torch.dtype) -> bool:
     """Whether extend_attention_mla serves the shape (latent row of 512 + 64 features, 16-bit)."""
     return dtype in (torch.bfloat16, torch.float16) and bool(

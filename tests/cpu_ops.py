@@ -162,3 +162,8 @@ def qkv_proj_rope_tiled_supported(m, k, num_heads, num_kv_heads, head_dim, rotar
     model takes the unfused sequence, which is what the oracle restates."""
     return False
 
+
+def decode_attention_mla_fused_rope_supported(kv_lora_rank, rope_dim, dtype, cache_dtype):
+    """RoPE + latent-row write inside the MLA decode launch is a GPU kernel only: the double declines and the
+    model takes rotary_emb + set_kv_buffer + decode_attention_mla, which is what the oracle restates."""
+    return False

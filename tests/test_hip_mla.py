@@ -485,3 +485,71 @@ def test_fp8_latent_cache_refuses_other_shapes():
     with pytest.raises(Mi355Error):
         ops.decode_attention_mla(q, cache, o, r2t, torch.zeros(1, dtype=torch.int64, device=DEV),
                                  torch.ones(1, dtype=torch.int64, device=DEV), None, None, 1, 128, 0.1)
+
+
+@pytest.mark.parametrize("H,splits,in_kernel_merge", [(16, 1, False), (16, 4, True), (20, 3, False), (128, 2, True), (5, 8, True)])
+@pytest.mark.parametrize("dt,cs_dt,neox,cap", [(torch.bfloat16, torch.bfloat16, False, 0.0), (torch.float16, torch.float32, False, 0.0),
+                                               (torch.bfloat16, torch.float32, True, 30.0)])
+def test_mla_decode_with_rope_and_cache_write_inside_the_launch(H, splits, in_kernel_merge, dt, cs_dt, neox, cap):
+    """mi355_decode_attention_mla_fused_rope (the reference's ROCm decode_attention_fwd_grouped_rope,
+    rocm_mla_decode_rope.py:402-439, selected at deepseek_v2.py:973-980): q's rope part and k_pe unrotated in,
+    one launch rotates them, writes the new latent row and attends.  Bit for bit the three-launch sequence
+    rope_inplace -> set_kv_buffer -> decode_attention_mla: the outputs AND the cache rows; lengths that put the
+    new token first / last in a tile and in either tile of a step, empty splits, head counts around the
+    16-head tile, interleaved and neox pairing, fp32 and 16-bit tables."""
+    from sglang_custom_amd import ops
+
+    rank, rope = 512, 64
+    D = rank + rope
+    lens = [1, 16, 17, 32, 33, 300, 1029, 48]
+    B, total = len(lens), sum(lens)
+    cache0 = _CASES.randn((total + 1, 1, D), 41, dt).to(DEV)
+    r2t = torch.zeros((B, max(lens)), dtype=torch.int32)
+    perm = torch.randperm(total, generator=torch.Generator().manual_seed(5)) + 1
+    pos = 0
+    for b, n in enumerate(lens):
+        r2t[b, :n] = perm[pos: pos + n].int()
+        pos += n
+    r2t = r2t.to(DEV)
+    rpi = torch.arange(B, dtype=torch.int64, device=DEV)
+    lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    loc = torch.stack([r2t[b, n - 1] for b, n in enumerate(lens)]).to(torch.int64)
+    positions = (lt - 1).clone()
+    positions[3] = 4000          # the position need not be len - 1 (a cached prefix was dropped, or a test)
+    q = _CASES.randn((B, H, D), 42, dt).to(DEV)
+    lat = _CASES.randn((B, 192 + D), 43, dt).to(DEV)        # [q_a | kv_a | k_pe] as the fused projection leaves it
+    k_nope = _CASES.randn((B, rank), 44, dt).to(DEV)          # the normed latent
+    k_pe_view = lat[:, 192 + rank:]
+    g = torch.Generator().manual_seed(6)
+    cs = torch.cat([torch.randn(4096 + 8, rope // 2, generator=g).cos(), torch.randn(4096 + 8, rope // 2, generator=g).sin()],
+                   dim=1).to(cs_dt).to(DEV).contiguous()
+    scale = D ** -0.5
+    n = B * H * max(splits, 1)
+    lg = torch.empty(n * rank, dtype=torch.float32, device=DEV)
+    ls = torch.empty(n, dtype=torch.float32, device=DEV)
+    tickets = torch.zeros(B * H, dtype=torch.int32, device=DEV) if in_kernel_merge else None
+    # three launches
+    q_ref = q.clone()
+    q_pe = q_ref[..., rank:].contiguous().view(B, -1)
+    k_pe = k_pe_view.contiguous()
+    ops.rope_inplace(positions, q_pe, k_pe, rope, cs, neox)
+    q_ref[..., rank:] = q_pe.view(B, H, rope)
+    cache_ref = cache0.clone()
+    row = torch.cat([k_nope, k_pe], dim=-1).view(B, 1, D)
+    ops.set_kv_buffer(cache_ref, cache_ref, loc, row, row)
+    want = torch.full((B, H, rank), float("nan"), dtype=dt, device=DEV)
+    ops.decode_attention_mla(q_ref, cache_ref, want, r2t, rpi, lt, lg, ls, splits, rank, scale, cap, tickets=tickets)
+    torch.cuda.synchronize()
+    # one launch
+    for rep in range(2):
+        cache = cache0.clone()
+        got = torch.full_like(want, float("nan"))
+        ops.decode_attention_mla_fused_rope(q, k_nope, k_pe_view, positions, loc, cs, neox, cache, got, r2t, rpi, lt, lg, ls,
+                                            splits, rank, scale, cap, tickets=tickets)
+        torch.cuda.synchronize()
+        assert not torch.isnan(got.float()).any()
+        assert torch.equal(cache.view(torch.int16), cache_ref.view(torch.int16)), "cache rows differ"
+        bad = (got.view(torch.int16) != want.view(torch.int16)).any(-1).any(-1).nonzero().flatten().tolist()
+        assert not bad, (bad, (got.float() - want.float()).abs().max().item())
+        if tickets is not None:
+            assert int(tickets.abs().sum()) == 0

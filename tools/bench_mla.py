@@ -60,3 +60,26 @@ for ns in SPLIT_LIST:
     err = (o[:nb].float() - ref8).abs().max().item()
     t = timeit(lambda i: ops.decode_attention_mla(q, kv8[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5))
     print(f"fp8 latent cache splits={ns}: {t:7.1f} us  {nbytes / 2 / t / 1e6:5.2f} TB/s of fp8 rows  err={err:.4f}", flush=True)
+# RoPE + latent-row write inside the launch against the three launches it replaces (rope, cache write, attention)
+lib.mi355_debug_set(6, 0)
+pos_t = sl - 1
+loc = r2t[rpi, (sl - 1)].to(torch.int64)
+cs = torch.cat([torch.randn(ctx + 8, rope // 2, device='cuda').cos(), torch.randn(ctx + 8, rope // 2, device='cuda').sin()], 1).contiguous()
+k_nope = torch.randn(bs, rank, device='cuda').bfloat16()
+lat = torch.randn(bs, 1536 + D, device='cuda').bfloat16()
+k_pe_v = lat[:, 1536 + rank:]
+for ns in SPLIT_LIST:
+    if ns not in (4, 8): continue
+    def three(i):
+        q_pe = q[..., rank:].contiguous().view(bs, -1)
+        k_pe = k_pe_v.contiguous()
+        ops.rope_inplace(pos_t, q_pe, k_pe, rope, cs, False)
+        q[..., rank:] = q_pe.view(bs, H, rope)
+        row = torch.cat([k_nope, k_pe], -1).view(bs, 1, D)
+        ops.set_kv_buffer(kv[i % NL], kv[i % NL], loc, row, row)
+        ops.decode_attention_mla(q, kv[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5, tickets=tk)
+    def one(i):
+        ops.decode_attention_mla_fused_rope(q, k_nope, k_pe_v, pos_t, loc, cs, False, kv[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank,
+                                            D ** -0.5, tickets=tk)
+    t3, t1 = timeit(three), timeit(one)
+    print(f"splits={ns}: rope + cache write + attention as the model issues them {t3:7.1f} us; one launch {t1:7.1f} us", flush=True)
