@@ -24,6 +24,11 @@ class LogitsProcessorOutput:
     next_token_logprobs: Optional[torch.Tensor] = None
     next_token_top_logprobs_val: Optional[list] = None
     next_token_top_logprobs_idx: Optional[list] = None
+    # prefill with return_logprob: log-probability of every kept prompt token given its prefix, and the
+    # top-k rows per request (logits_processor.py:64-77)
+    input_token_logprobs: Optional[torch.Tensor] = None
+    input_top_logprobs_val: Optional[list] = None
+    input_top_logprobs_idx: Optional[list] = None
 
 
 class LogitsProcessor(nn.Module):
@@ -37,6 +42,11 @@ class LogitsProcessor(nn.Module):
 
     def forward(self, input_ids, hidden_states, lm_head, forward_batch) -> LogitsProcessorOutput:
         ops = get_ops()
+        if (forward_batch.forward_mode.is_extend() and getattr(forward_batch, "return_logprob", False)
+                and forward_batch.extend_logprob_start_lens_cpu is not None
+                and any(n - s > 0 for n, s in zip(forward_batch.extend_seq_lens_cpu,
+                                                  forward_batch.extend_logprob_start_lens_cpu))):
+            return self._forward_with_input_logprobs(hidden_states, lm_head, forward_batch)
         if forward_batch.forward_mode.is_decode_or_idle():
             pruned = hidden_states
         else:
@@ -49,6 +59,52 @@ class LogitsProcessor(nn.Module):
                 logits = logits.contiguous()
             ops.softcap_inplace(logits, self.final_logit_softcapping)
         return LogitsProcessorOutput(next_token_logits=logits)
+
+    def _forward_with_input_logprobs(self, hidden_states, lm_head, fb) -> LogitsProcessorOutput:
+        """The extend_return_logprob branch (logits_processor.py:274-420): logits of every prompt row from
+        extend_logprob_start_len on (at least the last row, which samples), log-softmax over the rows that
+        report a prompt token, the given next token's value per row, and per-request top-k."""
+        sample_pt, in_pt = -1, 0
+        sample_indices, input_indices, pruned_rows, pruned_lens = [], [], [], []
+        pt = 0
+        for start, n in zip(fb.extend_logprob_start_lens_cpu, fb.extend_seq_lens_cpu):
+            s0 = start - 1 if n == start else start      # a chunk that reports nothing still samples one token
+            assert n > s0
+            pruned_rows.append(torch.arange(pt + s0, pt + n, dtype=torch.int64))
+            pt += n
+            sample_pt += n - s0
+            sample_indices.append(sample_pt)
+            input_indices.extend(in_pt + i for i in range(n - start))
+            in_pt += n - s0
+            pruned_lens.append(n - start)
+        dev = hidden_states.device
+        rows = torch.cat(pruned_rows).to(dev)
+        pruned = get_ops().embedding(rows, hidden_states.contiguous())     # row gather
+        logits = self._get_logits(pruned, lm_head)
+        if self.final_logit_softcapping:
+            if not logits.is_contiguous():
+                logits = logits.contiguous()
+            get_ops().softcap_inplace(logits, self.final_logit_softcapping)
+        sampled = logits[torch.tensor(sample_indices, dtype=torch.int64, device=dev)]
+        input_logits = logits[torch.tensor(input_indices, dtype=torch.int64, device=dev)]
+        logprobs = torch.nn.functional.log_softmax(input_logits, dim=-1)
+        out = LogitsProcessorOutput(next_token_logits=sampled)
+        ids = fb.extend_input_logprob_token_ids_gpu
+        out.input_token_logprobs = logprobs[torch.arange(logprobs.shape[0], device=dev), ids]
+        nums = fb.top_logprobs_nums or []
+        if any(k > 0 for k in nums):
+            top = logprobs.topk(max(nums), dim=1)
+            vals, idxs = top.values.tolist(), top.indices.tolist()
+            out.input_top_logprobs_val, out.input_top_logprobs_idx, p0 = [], [], 0
+            for k, plen in zip(nums, pruned_lens):
+                if plen <= 0:
+                    out.input_top_logprobs_val.append([])
+                    out.input_top_logprobs_idx.append([])
+                    continue
+                out.input_top_logprobs_val.append([vals[p0 + j][:k] for j in range(plen)])
+                out.input_top_logprobs_idx.append([idxs[p0 + j][:k] for j in range(plen)])
+                p0 += plen
+        return out
 
     def _get_logits(self, hidden_states: torch.Tensor, lm_head) -> torch.Tensor:
         w = lm_head.weight

@@ -23,8 +23,15 @@ class Req:
     """The request fields the hot path reads (schedule_batch.py Req)."""
 
     def __init__(self, rid, origin_input_ids: List[int], sampling_params: Optional[SamplingParams] = None,
-                 origin_input_text: str = ""):
+                 origin_input_text: str = "", return_logprob: bool = False, top_logprobs_num: int = 0,
+                 logprob_start_len: Optional[int] = None):
         self.rid = rid
+        # log-probabilities (schedule_batch.py Req :473-510): of the prompt tokens from position
+        # logprob_start_len on (default: none of them, only the sampled tokens), with the top-k of each row
+        self.return_logprob = return_logprob
+        self.top_logprobs_num = top_logprobs_num
+        self.logprob_start_len = len(origin_input_ids) - 1 if logprob_start_len is None else logprob_start_len
+        self.extend_logprob_start_len = 0
         self.origin_input_text = origin_input_text
         self.origin_input_ids = list(origin_input_ids)
         self.output_ids: List[int] = []
@@ -78,6 +85,10 @@ class ModelWorkerBatch:
     extend_prefix_lens: Optional[List[int]]
     sampling_info: SamplingBatchInfo
     positions: Optional[torch.Tensor] = None  # decode: produced by the prepare kernel
+    # input-token log-probabilities of an extend batch (schedule_batch.py ModelWorkerBatch :1862-1866)
+    top_logprobs_nums: Optional[List[int]] = None
+    extend_logprob_start_lens: Optional[List[int]] = None
+    extend_input_logprob_token_ids: Optional[torch.Tensor] = None
 
 
 class ScheduleBatch:
@@ -88,7 +99,10 @@ class ScheduleBatch:
         self.model_config = model_config
         self.device = device
         self.forward_mode: Optional[ForwardMode] = None
-        self.return_logprob = False
+        self.return_logprob = any(getattr(r, "return_logprob", False) for r in reqs)   # schedule_batch.py:919
+        self.top_logprobs_nums: Optional[List[int]] = None
+        self.extend_logprob_start_lens: Optional[List[int]] = None
+        self.extend_input_logprob_token_ids: Optional[torch.Tensor] = None
         self.input_ids = None
         self.req_pool_indices = None
         self.seq_lens = None
@@ -158,6 +172,24 @@ class ScheduleBatch:
                                              pre.to(device=dev, dtype=torch.int32))
             req.cached_tokens += pre_len - req.already_computed
             req.already_computed = seq_len
+            # the request's logprob_start_len relative to this batch's new tokens (schedule_batch.py:1175-1183)
+            if req.logprob_start_len >= pre_len:
+                req.extend_logprob_start_len = min(req.logprob_start_len - pre_len, req.extend_input_len, req.seqlen - 1)
+            else:
+                req.extend_logprob_start_len = 0
+        self.top_logprobs_nums = [r.top_logprobs_num for r in reqs]
+        self.extend_logprob_start_lens = [r.extend_logprob_start_len for r in reqs]
+        self.extend_input_logprob_token_ids = None
+        if self.return_logprob:
+            # the token whose log-probability each kept row reports = the NEXT prompt token; rows past the
+            # prompt's end (the row that samples) are padded with 0 (schedule_batch.py:1185-1226)
+            ids = []
+            for req in reqs:
+                start = max(len(req.prefix_indices), req.logprob_start_len)
+                toks = req.origin_input_ids[start + 1: len(req.fill_ids) + 1]
+                ids.extend(toks)
+                ids.extend([0] * (req.extend_input_len - req.extend_logprob_start_len - len(toks)))
+            self.extend_input_logprob_token_ids = torch.tensor(ids, dtype=torch.int64)
 
         if self.token_to_kv_pool_allocator.page_size == 1:
             self.out_cache_loc = self.alloc_token_slots(extend_num_tokens)
@@ -225,6 +257,11 @@ class ScheduleBatch:
         self.extend_lens = list(self.extend_lens) + [1] * running_bs
         self.extend_num_tokens += running_bs
         self.positions = None
+        # the riders report no prompt log-probabilities (schedule_batch.py:1338)
+        if self.extend_logprob_start_lens is not None:
+            self.extend_logprob_start_lens = list(self.extend_logprob_start_lens) + [0] * running_bs
+        if self.top_logprobs_nums is not None:
+            self.top_logprobs_nums = list(self.top_logprobs_nums) + [0] * running_bs
 
     def get_model_worker_batch(self) -> ModelWorkerBatch:
         if self.forward_mode.is_decode_or_idle():
@@ -245,6 +282,9 @@ class ScheduleBatch:
             extend_prefix_lens=extend_prefix_lens,
             sampling_info=self.sampling_info,
             positions=self.positions if self.forward_mode.is_decode() else None,
+            top_logprobs_nums=self.top_logprobs_nums,
+            extend_logprob_start_lens=None if self.forward_mode.is_decode_or_idle() else self.extend_logprob_start_lens,
+            extend_input_logprob_token_ids=self.extend_input_logprob_token_ids,
         )
 
     def is_empty(self) -> bool:

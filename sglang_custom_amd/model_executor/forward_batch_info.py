@@ -70,6 +70,10 @@ class ForwardBatch:
     extend_prefix_lens_cpu: Optional[List[int]] = None
     extend_seq_lens_cpu: Optional[List[int]] = None
     sampling_info: object = None
+    # input-token log-probabilities (forward_batch_info.py:183-190)
+    top_logprobs_nums: Optional[List[int]] = None
+    extend_logprob_start_lens_cpu: Optional[List[int]] = None
+    extend_input_logprob_token_ids_gpu: Optional[torch.Tensor] = None
     req_to_token_pool: object = None
     token_to_kv_pool: object = None
     attn_backend: object = None
@@ -106,4 +110,9 @@ class ForwardBatch:
                 ret.extend_prefix_lens, ret.extend_seq_lens, ret.extend_num_tokens)
             ret.extend_prefix_lens_cpu = batch.extend_prefix_lens
             ret.extend_seq_lens_cpu = batch.extend_seq_lens
+            ret.top_logprobs_nums = getattr(batch, "top_logprobs_nums", None)
+            ret.extend_logprob_start_lens_cpu = getattr(batch, "extend_logprob_start_lens", None)
+            ids = getattr(batch, "extend_input_logprob_token_ids", None)
+            if ids is not None:
+                ret.extend_input_logprob_token_ids_gpu = ids.to(device, non_blocking=True)
         return ret

@@ -190,3 +190,77 @@ def mla_hidden_states(lens, extra, seed, dt):
 def mla_slots(total, seed):
     """A scrambled assignment of KV slots 1..total (slot 0 is the padding sink)."""
     return torch.randperm(total, generator=_g(seed)) + 1
+
+
+# ---- input-token log-probabilities of a prefill (tests/golden/logprob.json, gen_logprob_golden.py) ----
+def run_logprob_scenarios(mr, golden):
+    """Runs the two scenarios of logprob.json (plain prefill; extend over a cached prefix) on ModelRunner
+    `mr` of this package and returns records shaped like the golden's."""
+    import torch
+
+    from sglang_custom_amd import bench_one_batch as bob
+    from sglang_custom_amd.managers.schedule_batch import Req, ScheduleBatch
+    from sglang_custom_amd.model_executor.forward_batch_info import ForwardBatch
+
+    prompts = e2e_prompts(mr.model_config.vocab_size, golden["lens"])
+
+    def run(reqs):
+        batch = ScheduleBatch.init_new(reqs=reqs, req_to_token_pool=mr.req_to_token_pool,
+                                       token_to_kv_pool_allocator=mr.token_to_kv_pool_allocator, tree_cache=None,
+                                       model_config=mr.model_config)
+        batch.prepare_for_extend()
+        fb = ForwardBatch.init_new(batch.get_model_worker_batch(), mr)
+        with torch.no_grad():
+            lo, _ = mr.forward(fb)
+        return lo, batch
+
+    def record(lo, batch):
+        return dict(extend_logprob_start_lens=list(batch.extend_logprob_start_lens),
+                    extend_input_logprob_token_ids=batch.extend_input_logprob_token_ids.tolist(),
+                    next_token_logits_top1=lo.next_token_logits.argmax(-1).tolist(),
+                    next_token_logits_max=lo.next_token_logits.max(-1).values.tolist(),
+                    input_token_logprobs=lo.input_token_logprobs.tolist(),
+                    input_top_logprobs_val=lo.input_top_logprobs_val, input_top_logprobs_idx=lo.input_top_logprobs_idx)
+
+    out = {}
+    g = golden["prefill"]
+    bob.clear_pools(mr)
+    lo, batch = run([Req(i, p, return_logprob=True, top_logprobs_num=g["top_logprobs_nums"][i],
+                         logprob_start_len=g["logprob_start_lens"][i]) for i, p in enumerate(prompts)])
+    out["prefill"] = record(lo, batch)
+    g = golden["prefix_extend"]
+    cut = g["cut"]
+    bob.clear_pools(mr)
+    reqs = [Req(i, p[:cut]) for i, p in enumerate(prompts)]
+    run(reqs)
+    for i, r in enumerate(reqs):
+        r.fill_ids = r.fill_ids + prompts[i][cut:]
+        r.origin_input_ids = list(r.fill_ids)
+        r.prefix_indices = mr.req_to_token_pool.req_to_token[i, :cut].clone()
+        r.extend_input_len = len(r.fill_ids) - cut
+        r.return_logprob, r.logprob_start_len, r.top_logprobs_num = True, g["logprob_start_lens"][i], g["top_logprobs_nums"][i]
+    mr.req_to_token_pool.clear()
+    lo, batch = run(reqs)
+    out["prefix_extend"] = record(lo, batch)
+    return out
+
+
+def check_logprob_records(got, golden, tol):
+    for name in ("prefill", "prefix_extend"):
+        a, b = got[name], golden[name]
+        assert a["extend_logprob_start_lens"] == b["extend_logprob_start_lens"], name
+        assert a["extend_input_logprob_token_ids"] == b["extend_input_logprob_token_ids"], name
+        assert a["next_token_logits_top1"] == b["next_token_logits_top1"], name
+        assert max(abs(x - y) for x, y in zip(a["next_token_logits_max"], b["next_token_logits_max"])) < tol, name
+        assert len(a["input_token_logprobs"]) == len(b["input_token_logprobs"]), name
+        assert max(abs(x - y) for x, y in zip(a["input_token_logprobs"], b["input_token_logprobs"])) < tol, name
+        assert len(a["input_top_logprobs_val"]) == len(b["input_top_logprobs_val"]), name
+        for ra, rb, ia, ib in zip(a["input_top_logprobs_val"], b["input_top_logprobs_val"],
+                                  a["input_top_logprobs_idx"], b["input_top_logprobs_idx"]):
+            assert len(ra) == len(rb), name
+            for va, vb, xa, xb in zip(ra, rb, ia, ib):
+                assert len(va) == len(vb) and max((abs(x - y) for x, y in zip(va, vb)), default=0.0) < tol, name
+                # ids agree wherever the reference's neighbouring values are further apart than the tolerance
+                for j, (x, y) in enumerate(zip(xa, xb)):
+                    tie = any(abs(vb[j] - vb[k]) < 2 * tol for k in range(len(vb)) if k != j)
+                    assert x == y or tie, (name, xa, xb)

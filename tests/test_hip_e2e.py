@@ -414,6 +414,18 @@ def test_fp8_kv_cache_end_to_end_close_to_16bit_cache():
 
 
 
+def test_input_token_logprobs_match_reference_vectors_on_the_gpu():
+    """The extend_return_logprob branch of LogitsProcessor (logits_processor.py:274-420) through the HIP
+    path: same scenarios and vectors as the CPU test (tests/golden/logprob.json, recorded from the
+    reference), fp32, log-probabilities within 1e-3."""
+    import json
+    import os
+
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "logprob.json")))
+    mr, cfg, _ = make_runner(golden["preset"], golden["dtype"], False)
+    cases.check_logprob_records(cases.run_logprob_scenarios(mr, golden), golden, 1e-3)
+
+
 def _real_shape_runner(preset, dtn, graphs):
     from sglang_custom_amd.configs.model_config import ModelConfig
     from sglang_custom_amd.model_executor.model_runner import ModelRunner

@@ -693,3 +693,18 @@ def test_deepseek_dense_stack_host_wiring_matches_oracle(preset):
             ModelRunner(ModelConfig(moe, dtype="float32"), sa, weights=w)
     finally:
         ops_backend.set_ops_backend(None)
+
+
+def test_input_token_logprobs_match_reference_vectors():
+    """Prefill with return_logprob: ScheduleBatch.prepare_for_extend's bookkeeping (extend_logprob_start_lens,
+    the next-token ids of every kept row, zero padding) and LogitsProcessor's extend_return_logprob branch
+    (row selection, log-softmax, per-request top-k) against vectors recorded from the reference's own
+    classes on CPU (tests/golden/logprob.json): plain prefill and an extend over a cached prefix, with
+    logprob_start_len before / inside / past the new tokens."""
+    import json
+
+    import cases
+
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "logprob.json")))
+    cfg, w, dt, mr = _build(golden["preset"], "float32")
+    cases.check_logprob_records(cases.run_logprob_scenarios(mr, golden), golden, 1e-4)
