@@ -479,6 +479,18 @@ int mi355_qkv_proj_rope_tiled(void* qkv, const void* x, const void* w, const flo
 int mi355_argmax(int64_t* ids, const float* logits, int64_t rows, int64_t vocab,
                  int64_t row_stride, void* stream);
 
+/* The same arg-max for a handful of rows (a decode batch): each row is cut into chunks handled by separate
+ * workgroups (one workgroup per row reads at what one CU can draw), the chunks' (maximum, first index)
+ * pairs meet in a 64-bit cell per row through an order-independent atomic max, and the last chunk to
+ * arrive writes ids[row].  Same indices as mi355_argmax, same tie rule, deterministic.
+ * workspace: mi355_argmax_workspace_bytes(rows) bytes, 8-byte aligned, ZERO when first used (the launch
+ * hands it back zeroed); calls that may overlap on one GPU need workspaces of their own.  NULL, or enough
+ * rows to fill the chip, runs mi355_argmax's kernel.
+ * replaces: torch.argmax(logits, -1) in Sampler.forward (python/sglang/srt/layers/sampler.py:74). */
+int64_t mi355_argmax_workspace_bytes(int64_t rows);
+int mi355_argmax_chunked(int64_t* ids, const float* logits, int64_t rows, int64_t vocab, int64_t row_stride,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
 /* In place: logits[b,:] = softmax(logits[b,:] / temperature[b])
  * replaces: Sampler.forward lines 79-81 (layers/sampler.py). */
 int mi355_softmax_temperature(float* logits, const float* temperatures, int64_t rows,

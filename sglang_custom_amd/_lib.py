@@ -88,6 +88,8 @@ _SIGNATURES = {
     "mi355_fp8_workspace_bytes": (L, [L, L, L]),
     "mi355_fp8_scaled_mm": (I, [P, P, P, P, P, P, L, L, L, P, L, I, P]),
     "mi355_argmax": (I, [P, P, L, L, L, P]),
+    "mi355_argmax_workspace_bytes": (L, [L]),
+    "mi355_argmax_chunked": (I, [P, P, L, L, L, P, L, P]),
     "mi355_softmax_temperature": (I, [P, P, L, L, L, P]),
     "mi355_top_k_top_p_min_p_sample": (I, [P, P, P, P, P, P, L, L, L, P]),
 }

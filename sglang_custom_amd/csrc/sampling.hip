@@ -4,23 +4,23 @@
 // from L2 / Infinity Cache.
 #include "common.cuh"
 #include <math.h>
+#include <algorithm>
 
 namespace mi355 {
 
 constexpr int SAMP_THREADS = 1024;
 
 // ---- argmax: first index of the maximum (torch.argmax tie rule) --------------------------
-__global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restrict__ ids,
-                                                             const float* __restrict__ logits,
-                                                             int64_t vocab, int64_t row_stride) {
+// (maximum, first index) of elements [4 v0, 4 v1) of `row` -- plus the row's tail past the last whole
+// float4 when `with_tail` -- reduced over the workgroup; valid in thread 0.  vec = the 16-byte path.
+__device__ __forceinline__ void argmax_scan(const float* __restrict__ row, int64_t vocab, bool vec, int64_t v0, int64_t v1,
+                                            bool with_tail, float& best_out, int& bidx_out) {
   __shared__ float sv[SAMP_THREADS / 64];
   __shared__ int si[SAMP_THREADS / 64];
-  const float* row = logits + (int64_t)blockIdx.x * row_stride;
   float best = -INFINITY;
   int bidx = 0x7fffffff;
-  const bool vec = (row_stride % 4 == 0) && aligned16(logits);
   if (vec) {
-    const int64_t nv = vocab / 4;
+    const int64_t nv = v1;
     auto take = [&](const float4& v, int64_t i) {
       const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restric
     // a row is read at the latency of its load rounds (two for a 128k vocabulary), not at bandwidth
     constexpr int U = 16;
     auto scan = [&](auto&& pick) {
-      for (int64_t i = threadIdx.x; i < nv; i += U * SAMP_THREADS) {
+      for (int64_t i = v0 + threadIdx.x; i < nv; i += U * SAMP_THREADS) {
         float4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -59,13 +59,14 @@ __global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restric
     };
     scan(take_gt);
     if (bidx == 0x7fffffff) scan(take);
-    for (int64_t i = nv * 4 + threadIdx.x; i < vocab; i += SAMP_THREADS)
-      if (row[i] > best || (row[i] == best && (int)i < bidx)) {
-        best = row[i];
-        bidx = (int)i;
-      }
+    if (with_tail)
+      for (int64_t i = (vocab / 4) * 4 + threadIdx.x; i < vocab; i += SAMP_THREADS)
+        if (row[i] > best || (row[i] == best && (int)i < bidx)) {
+          best = row[i];
+          bidx = (int)i;
+        }
   } else {
-    for (int64_t i = threadIdx.x; i < vocab; i += SAMP_THREADS)
+    for (int64_t i = 4 * v0 + threadIdx.x; i < (with_tail ? vocab : 4 * v1); i += SAMP_THREADS)
       if (row[i] > best || (row[i] == best && (int)i < bidx)) {
         best = row[i];
         bidx = (int)i;
@@ -91,9 +92,59 @@ __global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restric
         best = sv[w];
         bidx = si[w];
       }
-    // a row without any finite-or-greater element (all NaN / -inf): index 0 like torch on -inf
-    ids[blockIdx.x] = bidx == 0x7fffffff ? 0 : bidx;
+    best_out = best;
+    bidx_out = bidx;
   }
+}
+
+__global__ __launch_bounds__(SAMP_THREADS) void argmax_kernel(int64_t* __restrict__ ids,
+                                                             const float* __restrict__ logits,
+                                                             int64_t vocab, int64_t row_stride) {
+  const float* row = logits + (int64_t)blockIdx.x * row_stride;
+  const bool vec = (row_stride % 4 == 0) && aligned16(logits);
+  float best;
+  int bidx;
+  argmax_scan(row, vocab, vec, 0, vocab / 4, true, best, bidx);
+  // a row without any finite-or-greater element (all NaN / -inf): index 0 like torch on -inf
+  if (threadIdx.x == 0) ids[blockIdx.x] = bidx == 0x7fffffff ? 0 : bidx;
+}
+
+// A few rows (a decode batch) are a few workgroups: one workgroup reads its 0.5-MB row at what ONE CU can
+// draw.  Here a row is cut into gridDim.y chunks; every chunk's (maximum, first index) is folded into the
+// row's 64-bit cell with an atomic max -- key = (order-preserving image of the float) << 32 | ~index, so a
+// larger key is a larger value or, among equal values, a smaller index: the same winner in any arrival
+// order -- and the chunk that draws the row's last ticket decodes the cell into ids[row] and hands cell and
+// ticket counter back zeroed.  All traffic on cells and counters is returning agent-scope atomics (each is
+// complete before the next is issued), so nothing depends on cache write-back.
+// grid (rows, chunks); cells: rows x uint64, tickets: rows x uint32, both zero between launches.
+__global__ __launch_bounds__(SAMP_THREADS) void argmax_chunk_kernel(int64_t* __restrict__ ids,
+                                                                   const float* __restrict__ logits, int64_t vocab,
+                                                                   int64_t row_stride,
+                                                                   unsigned long long* __restrict__ cells,
+                                                                   unsigned* __restrict__ tickets) {
+  const int r = blockIdx.x, c = blockIdx.y, chunks = gridDim.y;
+  const float* row = logits + (int64_t)r * row_stride;
+  const bool vec = (row_stride % 4 == 0) && aligned16(logits);
+  const int64_t nv = vocab / 4, per = (nv + chunks - 1) / chunks;
+  const int64_t v0 = c * per < nv ? c * per : nv, v1 = v0 + per < nv ? v0 + per : nv;
+  float best;
+  int bidx;
+  argmax_scan(row, vocab, vec, v0, v1, c == chunks - 1, best, bidx);
+  if (threadIdx.x != 0) return;
+  unsigned u = __builtin_bit_cast(unsigned, best + 0.f);   // (-0 + 0 = +0: the two zeros are one value, as in a float compare)
+  u = (u >> 31) ? ~u : (u | 0x80000000u);
+  const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned)bidx);
+  (void)__hip_atomic_fetch_max(&cells[r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the maximum is in before the ticket is drawn
+  const unsigned t = __hip_atomic_fetch_add(&tickets[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != (unsigned)(chunks - 1)) return;
+  // every chunk's maximum is in (each was complete before its ticket was drawn): read the cell at the
+  // point the atomics work at, then put cell and counter back to zero (nothing waits for those stores)
+  const unsigned long long win = __hip_atomic_load(&cells[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&cells[r], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&tickets[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned idx = 0xffffffffu - (unsigned)(win & 0xffffffffu);
+  ids[r] = idx == 0x7fffffffu ? 0 : (int64_t)idx;
 }
 
 // ---- softmax(logits / temperature), in place ----------------------------------------------
@@ -273,6 +324,34 @@ int mi355_argmax(int64_t* ids, const float* logits, int64_t rows, int64_t vocab,
   hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)rows), dim3(SAMP_THREADS), 0,
                      (hipStream_t)stream, ids, logits, vocab, row_stride);
   MI355_CHECK_LAUNCH("argmax");
+  return MI355_OK;
+}
+
+int64_t mi355_argmax_workspace_bytes(int64_t rows) { return rows > 0 ? rows * 16 : 0; }
+
+int mi355_argmax_chunked(int64_t* ids, const float* logits, int64_t rows, int64_t vocab, int64_t row_stride,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+  MI355_REQUIRE(ids && logits, MI355_ERR_INVALID, "argmax_chunked: null pointer");
+  MI355_REQUIRE(rows >= 0 && rows <= 65535 && vocab > 0 && vocab < (1LL << 31) - 1 && row_stride >= vocab, MI355_ERR_INVALID,
+                "argmax_chunked: bad shape");
+  if (rows == 0) return MI355_OK;
+  // enough workgroups for every CU; a chunk keeps at least 16 K elements
+  int64_t chunks = (256 + rows - 1) / rows;
+  chunks = std::min<int64_t>(chunks, std::max<int64_t>(1, vocab / 16384));
+  chunks = std::min<int64_t>(chunks, 16);
+  if (chunks <= 1 || !workspace) {
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)rows), dim3(SAMP_THREADS), 0, (hipStream_t)stream, ids, logits, vocab,
+                       row_stride);
+  } else {
+    MI355_REQUIRE(workspace_bytes >= mi355_argmax_workspace_bytes(rows) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                  MI355_ERR_INVALID, "argmax_chunked: workspace of %lld bytes (8-byte aligned, zeroed) required",
+                  (long long)mi355_argmax_workspace_bytes(rows));
+    unsigned long long* cells = static_cast<unsigned long long*>(workspace);
+    unsigned* tickets = reinterpret_cast<unsigned*>(cells + rows);
+    hipLaunchKernelGGL(argmax_chunk_kernel, dim3((unsigned)rows, (unsigned)chunks), dim3(SAMP_THREADS), 0,
+                       (hipStream_t)stream, ids, logits, vocab, row_stride, cells, tickets);
+  }
+  MI355_CHECK_LAUNCH("argmax_chunked");
   return MI355_OK;
 }
 

@@ -904,6 +904,15 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     _gpu(logits)
     assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
     ids = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    rows = logits.shape[0]
+    if 0 < rows < 256:
+        # few rows: several workgroups per row (mi355_argmax_chunked); its cells live in a persistent zeroed workspace
+        lib = _lib_()
+        need = lib.mi355_argmax_workspace_bytes(rows)
+        ws = _workspace(logits.device, need, tag="argmax")
+        check(lib.mi355_argmax_chunked(ids.data_ptr(), logits.data_ptr(), rows, logits.shape[1], logits.stride(0),
+                                       ws.data_ptr(), ws.numel(), _stream(logits)), "argmax_chunked")
+        return ids
     check(_lib_().mi355_argmax(ids.data_ptr(), logits.data_ptr(), logits.shape[0], logits.shape[1],
                                logits.stride(0), _stream(logits)), "argmax")
     return ids

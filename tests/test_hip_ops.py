@@ -964,6 +964,53 @@ def test_argmax_rows_of_minus_infinity_and_nan(ops):
         assert torch.equal(got, want), (V, got.tolist(), want.tolist())
 
 
+def test_argmax_over_several_workgroups_per_row(ops):
+    """mi355_argmax_chunked (few rows: a row is cut into chunks that meet in a 64-bit cell through an atomic
+    max): the indices of the one-workgroup-per-row kernel for 1 .. 200 rows, ties across chunk boundaries
+    (first index wins), negative maxima, the two zeros as one value, a row of -inf; the workspace comes back
+    zeroed, back-to-back calls and a replayed graph share it."""
+    from sglang_custom_amd import _lib
+
+    lib = _lib.load()
+    V = 128256
+    g = torch.Generator().manual_seed(3)
+    for rows in (1, 3, 64, 200):
+        x = (2.0 * torch.randn((rows, V), generator=g)).bfloat16().float()
+        x[0] = -torch.rand(V, generator=g) - 1.0                      # every value negative
+        x[0, 70000] = x[0, 20000] = -0.5                                # a tie across chunks
+        if rows > 2:
+            x[1] = float("-inf")
+            x[2] = -1.0; x[2, 100000] = 0.0; x[2, 5] = -0.0           # -0.0 at 5 and +0.0 at 100000 are equal: index 5
+        xd = x.to(DEV)
+        want = torch.empty(rows, dtype=torch.int64, device=DEV)
+        assert lib.mi355_argmax(want.data_ptr(), xd.data_ptr(), rows, V, V, torch.cuda.current_stream().cuda_stream) == 0
+        ws = torch.zeros(lib.mi355_argmax_workspace_bytes(rows), dtype=torch.uint8, device=DEV)
+        for rep in range(2):
+            got = torch.full((rows,), -7, dtype=torch.int64, device=DEV)
+            assert lib.mi355_argmax_chunked(got.data_ptr(), xd.data_ptr(), rows, V, V, ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream().cuda_stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (rows, rep)
+            assert int(ws.sum()) == 0, "workspace not handed back zeroed"
+        assert torch.equal(want.cpu(), torch.argmax(x, -1))
+        assert want[0].item() == 20000 and (rows < 3 or (want[1].item() == 0 and want[2].item() == 5))
+    # through the wrapper, inside a replayed graph, on changing logits
+    x = torch.randn((64, V), generator=g).to(DEV)
+    ops.argmax(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            out = ops.argmax(x)
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(3):
+        x.copy_(torch.randn((64, V), generator=g))
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.argmax(x, -1))
+
+
 def test_argmax_and_sampler_at_llama3_vocab(ops):
     """vocab 128256 (sgl-kernel/tests/test_sampling.py runs its cases at 111 / 32000 / 128256): arg-max
     with the first-index tie rule, softmax with temperature, and the joint top-k / top-p / min-p
