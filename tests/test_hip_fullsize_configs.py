@@ -235,3 +235,127 @@ def test_chunked_prefill_2048_plus_2048_equals_one_pass(ops, hq, hkv):
     rows = [C, C + 1, C + 63, C + 64, 3000, S - 1]
     ref = _ref_rows(q, k, v, rows, hq, hkv)
     assert (second[[r - C for r in rows]].double() - ref).abs().max().item() <= 1.6e-2
+
+
+# ---- DeepSeek-V3 MLA attention, one tensor-parallel rank of 8 (16 of 128 heads), batch 64, context ~4096 ----
+def _mla_world(bs, ctx_lo, ctx_hi, seed, dt=torch.bfloat16):
+    rank, rope = 512, 64
+    D_ = rank + rope
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    lens = torch.randint(ctx_lo, ctx_hi + 1, (bs,), device=DEV, generator=g, dtype=torch.int64)
+    lens[0], lens[-1] = ctx_hi, ctx_lo
+    total = int(lens.sum())
+    cache = torch.randn(total + 1, 1, D_, device=DEV, generator=g).to(dt)
+    perm = (torch.randperm(total, device=DEV, generator=g) + 1).to(torch.int32)
+    r2t = torch.zeros(bs, ctx_hi, dtype=torch.int32, device=DEV)
+    off = 0
+    for b in range(bs):
+        n = int(lens[b])
+        r2t[b, :n] = perm[off: off + n]
+        off += n
+    rpi = torch.arange(bs, dtype=torch.int64, device=DEV)
+    q = torch.randn(bs, 16, D_, device=DEV, generator=g).to(dt)
+    return rank, rope, D_, lens, cache, r2t, rpi, q, g
+
+
+@pytest.mark.parametrize("bs,splits", [(64, 8), (16, 16)])
+def test_deepseek_shard_mla_decode_fused_rope_is_bit_identical(ops, bs, splits):
+    """MLA decode at the DeepSeek-V3 TP=8 shard shape (16 heads, 512 + 64 latent row, contexts 3900 .. 4160):
+    the launch that rotates q / k_pe and writes the latent row == rope + cache write + decode, bit for bit,
+    outputs and cache; sampled (sequence, head) pairs against float64 attention computed on the GPU."""
+    rank, rope, D_, lens, cache0, r2t, rpi, q, g = _mla_world(bs, 3900, 4160, 11)
+    loc = torch.stack([r2t[b, int(lens[b]) - 1] for b in range(bs)]).to(torch.int64)
+    positions = lens - 1
+    k_nope = torch.randn(bs, rank, device=DEV, generator=g).bfloat16()
+    lat = torch.randn(bs, 1536 + D_, device=DEV, generator=g).bfloat16()
+    k_pe_view = lat[:, 1536 + rank:]
+    cs = torch.cat([torch.randn(4200, rope // 2, device=DEV, generator=g).cos(),
+                    torch.randn(4200, rope // 2, device=DEV, generator=g).sin()], 1).contiguous()
+    scale = D_ ** -0.5
+    lg = torch.empty(bs * 16 * splits * rank, dtype=torch.float32, device=DEV)
+    ls = torch.empty(bs * 16 * splits, dtype=torch.float32, device=DEV)
+    tickets = torch.zeros(bs * 16, dtype=torch.int32, device=DEV)
+    q_ref = q.clone()
+    q_pe = q_ref[..., rank:].contiguous().view(bs, -1)
+    k_pe = k_pe_view.contiguous()
+    ops.rope_inplace(positions, q_pe, k_pe, rope, cs, False)
+    q_ref[..., rank:] = q_pe.view(bs, 16, rope)
+    cache_ref = cache0.clone()
+    row = torch.cat([k_nope, k_pe], -1).view(bs, 1, D_)
+    ops.set_kv_buffer(cache_ref, cache_ref, loc, row, row)
+    want = torch.full((bs, 16, rank), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_mla(q_ref, cache_ref, want, r2t, rpi, lens, lg, ls, splits, rank, scale, tickets=tickets)
+    cache = cache0.clone()
+    got = torch.full_like(want, float("nan"))
+    ops.decode_attention_mla_fused_rope(q, k_nope, k_pe_view, positions, loc, cs, False, cache, got, r2t, rpi, lens, lg, ls,
+                                        splits, rank, scale, tickets=tickets)
+    torch.cuda.synchronize()
+    assert torch.equal(cache.view(torch.int16), cache_ref.view(torch.int16))
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert int(tickets.abs().sum()) == 0
+    for b in (0, bs // 2, bs - 1):
+        kv = cache_ref[r2t[b, : int(lens[b])].long(), 0].double()
+        ref = torch.softmax((q_ref[b].double() @ kv.t()) * scale, -1) @ kv[:, :rank]
+        assert (got[b].double() - ref).abs().max().item() <= 2e-2 * max(ref.abs().max().item(), 1.0), b
+
+
+def test_deepseek_shard_mla_decode_over_fp8_latent_cache(ops):
+    """The same shape over an e4m3fn latent cache: bit for bit the same kernel over a 16-bit cache holding the
+    widened rows, and sampled sequences against float64 attention over the widened rows."""
+    bs, splits = 64, 4
+    rank, rope, D_, lens, cache16, r2t, rpi, q, g = _mla_world(bs, 3900, 4160, 12)
+    cache8 = torch.zeros(cache16.shape, dtype=torch.float8_e4m3fn, device=DEV)
+    loc = torch.arange(cache16.shape[0], dtype=torch.int64, device=DEV)
+    ops.set_kv_buffer(cache8, cache8, loc, cache16, cache16)
+    wide = cache8.to(torch.bfloat16)
+    scale = D_ ** -0.5
+    lg = torch.empty(bs * 16 * splits * rank + 1, dtype=torch.float32, device=DEV)
+    ls = torch.empty(bs * 16 * splits, dtype=torch.float32, device=DEV)
+    got = torch.full((bs, 16, rank), float("nan"), dtype=torch.bfloat16, device=DEV)
+    same = torch.full_like(got, float("nan"))
+    ops.decode_attention_mla(q, cache8, got, r2t, rpi, lens, lg, ls, splits, rank, scale)
+    ops.decode_attention_mla(q, wide, same, r2t, rpi, lens, lg[1:], ls, splits, rank, scale)   # misaligned scratch: the register kernel
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), same.view(torch.int16))
+    for b in (0, 31, 63):
+        kv = wide[r2t[b, : int(lens[b])].long(), 0].double()
+        ref = torch.softmax((q[b].double() @ kv.t()) * scale, -1) @ kv[:, :rank]
+        assert (got[b].double() - ref).abs().max().item() <= 2e-2 * max(ref.abs().max().item(), 1.0), b
+
+
+def test_ragged_batch_of_64_under_the_per_sequence_split_plan(ops):
+    """Llama-3-70B shard attention (8 query heads on one kv head), 64 sequences of 16 .. 4160 keys under one
+    8-split launch with kv_chunk_keys: every sequence bit for bit what it gets alone under the same chunk."""
+    bs, S = 64, 8
+    g = torch.Generator(device=DEV).manual_seed(21)
+    lens = torch.randint(16, 4161, (bs,), device=DEV, generator=g, dtype=torch.int64)
+    lens[0], lens[1] = 4160, 16
+    total = int(lens.sum())
+    kc = torch.randn(total + 1, 1, D, device=DEV, generator=g).bfloat16()
+    vc = torch.randn(total + 1, 1, D, device=DEV, generator=g).bfloat16()
+    perm = (torch.randperm(total, device=DEV, generator=g) + 1).to(torch.int32)
+    r2t = torch.zeros(bs, 4160, dtype=torch.int32, device=DEV)
+    off = 0
+    for b in range(bs):
+        n = int(lens[b])
+        r2t[b, :n] = perm[off: off + n]
+        off += n
+    rpi = torch.arange(bs, dtype=torch.int64, device=DEV)
+    q = torch.randn(bs, 8, D, device=DEV, generator=g).bfloat16()
+    al = torch.empty(bs * 8 * S * D, dtype=torch.float32, device=DEV)
+    ll = torch.empty(bs * 8 * S, dtype=torch.float32, device=DEV)
+    tickets = torch.zeros(bs * 8, dtype=torch.int32, device=DEV)
+    ck = torch.tensor([(4160 + S - 1) // S], dtype=torch.int32, device=DEV)
+    got = torch.full((bs, 8, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_paged(q, kc, vc, got, r2t, rpi, lens, al, ll, S, D ** -0.5, tickets=tickets, kv_chunk_keys=ck)
+    torch.cuda.synchronize()
+    for b in range(0, bs, 7):
+        alone = torch.full((1, 8, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.decode_attention_paged(q[b: b + 1], kc, vc, alone, r2t, rpi[b: b + 1], lens[b: b + 1], al, ll, S, D ** -0.5,
+                                   tickets=tickets, kv_chunk_keys=ck)
+        torch.cuda.synchronize()
+        assert torch.equal(alone[0].view(torch.int16), got[b].view(torch.int16)), b
+        kk = kc[r2t[b, : int(lens[b])].long(), 0].double()
+        vv = vc[r2t[b, : int(lens[b])].long(), 0].double()
+        ref = torch.softmax((q[b].double() @ kk.t()) * D ** -0.5, -1) @ vv
+        assert (got[b].double() - ref).abs().max().item() <= 1.6e-2, b
