@@ -43,8 +43,20 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, backend: st
     _TP_GROUP = dist.group.WORLD
     _CA_STATE = "off"
     if _CPU_GROUP is None:
-        _CPU_GROUP = _TP_GROUP if backend == "gloo" else dist.new_group(backend="gloo")
-    if use_custom_all_reduce:
+        if backend == "gloo":
+            _CPU_GROUP = _TP_GROUP
+        else:
+            try:
+                _CPU_GROUP = dist.new_group(backend="gloo")
+            except Exception as e:  # noqa: BLE001 -- e.g. no usable network interface for gloo on this machine
+                import sys
+
+                print(f"[parallel_state] no CPU side group ({type(e).__name__}: {e}); host-side agreement goes through "
+                      "the device group, the one-launch collectives stay off", file=sys.stderr, flush=True)
+                _CPU_GROUP = None
+    if use_custom_all_reduce and _CPU_GROUP is None:
+        _CA_STATE = "off (no CPU side group for the handle exchange)"
+    elif use_custom_all_reduce:
         from sglang_custom_amd.distributed.device_communicators.custom_all_reduce import CustomAllreduce
 
         side = _CPU_GROUP
@@ -98,18 +110,25 @@ def tp_barrier() -> None:
     phases whose first device collective must not find the ranks seconds apart -- the warm-up runs
     of graph capture above all: the custom collectives give up after a bounded wait, and a timeout
     raises their status word for good (there is no reset; the communicator has to be dropped)."""
-    if _TP_SIZE == 1 or _SIMULATED or _CPU_GROUP is None:
+    if _TP_SIZE == 1 or _SIMULATED or _TP_GROUP is None:
         return
-    dist.barrier(group=_CPU_GROUP)      # the CPU side group: no device work queued
+    if _CPU_GROUP is not None:
+        dist.barrier(group=_CPU_GROUP)      # the CPU side group: no device work queued
+    else:
+        dist.barrier(group=_TP_GROUP, device_ids=[torch.cuda.current_device()])
 
 
 def tp_any(flag: bool) -> bool:
     """True on every rank when `flag` is true on at least one (host-side, over the gloo group): how the
     ranks agree on a decision that one of them may have been forced into (a failed graph capture)."""
-    if _TP_SIZE == 1 or _SIMULATED or _CPU_GROUP is None:
+    if _TP_SIZE == 1 or _SIMULATED or _TP_GROUP is None:
         return bool(flag)
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CPU_GROUP)
+    if _CPU_GROUP is not None:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CPU_GROUP)
+    else:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_TP_GROUP)
     return bool(t.item())
 
 
