@@ -87,7 +87,7 @@ def main():
     ref_toks, ref_logits = run_once()                     # the reference's own torch-native backend
     ops_backend.set_ops_backend(cpu_ops)
     backend = Mi355AttnBackend(mr)                        # constructed from the reference's model runner
-    mr.attn_backend = backend                             # the registration INTEGRATION.md describes
+    mr.attn_backend = backend                             # the registration a maintainer adds in _get_attention_backend_from_str (model_runner.py:1313-1391)
     toks, logits = run_once()
     err = max((a - b).abs().max().item() for a, b in zip(logits, ref_logits))
     # graph hooks: the reference's CudaGraphRunner calls them positionally with these arguments

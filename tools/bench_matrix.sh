@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box: the bench lines that DESIGN.md quotes beside the headline one, each saved as
+# Runs on the GPU box: the bench lines quoted beside the headline one (other batch sizes, fp8 modes, simulated TP shards), each saved as
 # its own record.  Usage: tools/bench_matrix.sh <tag>     -> gpurun_out/matrix_<tag>/*.json
 set -o pipefail
 tag=${1:-r02}

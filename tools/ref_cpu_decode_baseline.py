@@ -1,6 +1,6 @@
 """Build container only (the reference tree must be importable): time the REFERENCE's own CPU decode
 step -- its ModelRunner, LlamaForCausalLM, torch-native attention backend, sampler -- at the headline
-configuration's batch and context, for BASELINE.md.
+configuration's batch and context (the reference's own number beside this build's CPU port).
 
     python tools/ref_cpu_decode_baseline.py [--model llama-3-8b] [--bs 64] [--ctx 1040] [--steps 5]
 
