@@ -335,6 +335,35 @@ int mi355_extend_attention_mla(const void* q, const void* kv_buffer, void* o, co
                                int64_t q_stride, int64_t num_slots, float sm_scale, float logit_cap,
                                int dtype, void* stream);
 
+/* ---- the small steps of an MLA decode layer between its projections, one launch each ------------------
+ * mi355_mla_latent_norms: a row of fused_qkv_a_proj_with_mqa's output is [q_a (q_rank) | c_kv (kv_rank) | k_pe
+ * (rope_dim)].  Given x [rows, >= width] (16-bit, row stride x_row_stride) OR that GEMM's split-K partials
+ * part [nsplit, rows, width] fp32 (with part_x_scale [rows] / part_w_scale [width] when the GEMM was fp8 W8A8),
+ * writes q_out [rows, q_rank] = RMSNorm(q_a) * q_weight, kv_out [rows, kv_rank] = RMSNorm(c_kv) * kv_weight and
+ * pe_out [rows, rope_dim] = k_pe, all dense.  q_rank == 0 (a model without q_lora: x is kv_a_proj_with_mqa's
+ * output) skips the q part (q_out, q_weight NULL).  Same bits as split + contiguous + mi355_rmsnorm per part.
+ * Needs a 16-bit dtype, q_rank <= 2048, kv_rank + rope_dim <= 2048, all three % 8 == 0.
+ * replaces: q_a_layernorm / kv_a_layernorm around the split of fused_qkv_a_proj_with_mqa in
+ *           DeepseekV2AttentionMLA.forward_absorb_prepare (python/sglang/srt/models/deepseek_v2.py:1193-1232). */
+int mi355_mla_latent_norms(void* q_out, void* kv_out, void* pe_out, const void* x, int64_t x_row_stride,
+                           const float* part, int nsplit, const float* part_x_scale, const float* part_w_scale,
+                           const void* q_weight, const void* kv_weight, int64_t rows, int q_rank, int kv_rank,
+                           int rope_dim, float eps, int dtype, void* stream);
+
+/* mi355_mla_absorb: out[m, h, 0..n) = sum_k a[m, h, k] * w_t[h, j, k] for m < M <= 64 rows and every head, fp32
+ * accumulation, rounded once to the 16-bit dtype; a[m, h, k .. k + tail) is copied to out[m, h, n .. n + tail).
+ * a / out: element (m, h, f) at m * row_stride + h * head_stride + f; w_t [heads, n, k] contiguous (each head's
+ * matrix TRANSPOSED, the reduction dimension contiguous).  Serves both absorbed products of MLA decode:
+ * q_nope . w_kc with q's rope part carried along (n = kv_lora_rank, k = qk_nope_head_dim, tail = rope) and
+ * attn . w_vc written straight into o_proj's input layout (n = v_head_dim, k = kv_lora_rank, tail = 0,
+ * out_head_stride = v_head_dim).  Needs n % 16 == 0, k % 32 == 0, tail % 8 == 0, strides % 8 == 0.
+ * replaces: torch.bmm(q_nope.transpose(0, 1), w_kc) + the concatenation with q_pe, and
+ *           torch.bmm(attn_output.transpose(0, 1), w_vc) + the transpose back
+ *           (python/sglang/srt/models/deepseek_v2.py:1234-1262, 1296-1333). */
+int mi355_mla_absorb(void* out, const void* a, const void* w_t, int64_t m, int heads, int n, int k, int tail,
+                     int64_t a_row_stride, int64_t a_head_stride, int64_t out_row_stride, int64_t out_head_stride,
+                     int dtype, void* stream);
+
 /* ---- K12/K13 dense projection y = x @ W^T ------------------------------------------------------
  * x [M, K] (row stride x_stride), W [N, K] contiguous (nn.Linear layout), y [M, N] contiguous.
  * M <= 64 uses the weight-streaming MFMA kernel (bf16/f16); fp32 uses an exact-fp32 tiled kernel

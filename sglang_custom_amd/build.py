@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libmi355_hotpath.so")
 # variables set through mi355_debug_set) plus the bandwidth probes; used by tools/, never by the package
 LIB_DEV = os.path.join(HERE, "libmi355_hotpath_dev.so")
 SOURCES = ["elementwise.hip", "index_ops.hip", "attn_decode.hip", "attn_extend.hip", "gemm.hip",
-           "gemm_tiled.hip", "sampling.hip", "quant_fp8.hip", "allreduce.hip"]
+           "gemm_tiled.hip", "sampling.hip", "quant_fp8.hip", "allreduce.hip", "mla_proj.hip"]
 DEV_SOURCES = ["debug_bw.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"),
            os.path.join(os.path.dirname(HERE), "include", "mi355_hotpath.h"),

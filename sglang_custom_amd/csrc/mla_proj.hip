@@ -1,0 +1,219 @@
+// The small steps between the projections of a multi-head-latent-attention decode layer, each as ONE launch:
+//   mla_latent_norms  the output row of fused_qkv_a_proj_with_mqa [q_a | c_kv | k_pe] (or its split-K partials)
+//                     -> q_a_layernorm(q_a), kv_a_layernorm(c_kv) and k_pe as three dense tensors;
+//   mla_absorb        the per-head products that fold kv_b_proj into the query (q_nope . w_kc, with the rope part
+//                     of q copied behind the result) and into the output (attn . w_vc, written in o_proj's row layout).
+// Both are latency-bound at decode sizes (<= 64 rows, a few MB of L2-resident operands): what they buy is launches.
+#include "common.cuh"
+
+namespace mi355 {
+
+// ------------------------------------------------------------------------------------------
+// grid (rows, segments).  Segment 0 normalises columns [0, q_rank) with wq; segment 1 normalises
+// [q_rank, q_rank + kv_rank) with wkv and copies the rope_dim columns behind them.  One 8-element vector
+// per lane, the row held in registers: the arithmetic and its order are those of the one-chunk RMSNorm
+// kernel, so the results are the bits of split + contiguous + rmsnorm.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mla_latent_norms_kernel(
+    T* __restrict__ q_out, T* __restrict__ kv_out, T* __restrict__ pe_out, const T* __restrict__ x, int64_t x_stride,
+    const float* __restrict__ part, int nsplit, int64_t split_stride, const float* __restrict__ part_xs,
+    const float* __restrict__ part_ws, const T* __restrict__ wq, const T* __restrict__ wkv, int q_rank, int kv_rank,
+    int rope, float eps) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const int seg = (int)blockIdx.y + (q_rank ? 0 : 1);
+  const int width = q_rank + kv_rank + rope;
+  const int col0 = seg ? q_rank : 0;
+  const int hidden = seg ? kv_rank : q_rank;
+  const int nvec = hidden / 8;
+  const int ncopy = seg ? rope / 8 : 0;
+  const T* w = seg ? wkv : wq;
+  T* orow = (seg ? kv_out : q_out) + row * hidden;
+  const int t = threadIdx.x;
+  const bool live = t < nvec + ncopy;
+  const int col = col0 + 8 * (live ? t : 0);
+  Vec<T, 8> wv = ldvec<T, 8>(w + 8 * (t < nvec ? t : 0));
+  Vec<T, 8> a;
+  if (part) {
+    // split-K partials [split][rows][width] fp32: summed in split order and rounded once, as the GEMM's own combine
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+    const float* pr = part + row * width + col;
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) {
+#pragma unroll
+      for (int j4 = 0; j4 < 8; j4 += 4) {
+        const float4 f = *reinterpret_cast<const float4*>(pr + sp * split_stride + j4);
+        sum[j4] += f.x; sum[j4 + 1] += f.y; sum[j4 + 2] += f.z; sum[j4 + 3] += f.w;
+      }
+    }
+    if (part_xs) {   // partials of an fp8 GEMM: (acc * x_scale[m]) * w_scale[n]
+      const float xs = part_xs[row];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a.v[j] = from_f32<T>((sum[j] * xs) * part_ws[col + j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a.v[j] = from_f32<T>(sum[j] + 0.f);
+    }
+  } else {
+    a = ldvec<T, 8>(x + row * x_stride + col);
+  }
+  if (t >= nvec && live) stvec<T, 8>(pe_out + row * rope + 8 * (t - nvec), a);
+  float vals[8];
+  float ss = 0.f;
+  if (t < nvec) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vals[j] = to_f32(a.v[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += vals[j] * vals[j];
+  }
+  ss = block_sum(ss, red);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  if (t < nvec) {
+    Vec<T, 8> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = from_f32<T>((vals[j] * inv) * to_f32(wv.v[j]));
+    stvec<T, 8>(orow + 8 * t, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[m, h, n] = sum_k a[m, h, k] * w_t[h, n, k]   (m < M <= 16 MT, k < K, n < N), 16-bit in, fp32 accumulate.
+// One wave per (16 output features, head): the weight rows are the MFMA's A operand and the activations its
+// B operand, so a lane ends with four consecutive features of one row -- one 8-byte store.  Operands come
+// straight from L2 (16-byte fragments); no LDS, no barrier.  Workgroup x == N / 16 (present when tail > 0)
+// copies a[m, h, K .. K + tail) behind the N outputs of each (m, h).
+// ------------------------------------------------------------------------------------------
+template <typename T, int MT>
+__global__ __launch_bounds__(64) void mla_absorb_kernel(T* __restrict__ out, const T* __restrict__ a,
+                                                        const T* __restrict__ w_t, int M, int N, int K, int tail,
+                                                        int64_t a_row_stride, int64_t a_head_stride,
+                                                        int64_t out_row_stride, int64_t out_head_stride) {
+  using frag = typename Mfma<T>::frag;
+  const int h = blockIdx.y, nt = blockIdx.x, l = threadIdx.x;
+  const T* ah = a + (int64_t)h * a_head_stride;
+  T* oh = out + (int64_t)h * out_head_stride;
+  if (nt * 16 >= N) {
+    const int per = tail / 8;
+    for (int idx = l; idx < M * per; idx += 64) {
+      const int m = idx / per, c = idx - m * per;
+      stvec<T, 8>(oh + m * out_row_stride + N + 8 * c, ldvec<T, 8>(ah + m * a_row_stride + K + 8 * c));
+    }
+    return;
+  }
+  const int i = l & 15, g = l >> 4;
+  const T* wrow = w_t + ((int64_t)h * N + nt * 16 + i) * K + 8 * g;
+  const T* arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + i;
+    arow[mt] = ah + (int64_t)(m < M ? m : M - 1) * a_row_stride + 8 * g;   // rows past M: computed, never stored
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const frag wf = *reinterpret_cast<const frag*>(wrow + k0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      acc[mt] = Mfma<T>::run(wf, *reinterpret_cast<const frag*>(arow[mt] + k0), acc[mt]);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + i;
+    if (m < M) {
+      Vec<T, 4> o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o.v[r] = from_f32<T>(acc[mt][r]);
+      stvec<T, 4>(oh + m * out_row_stride + nt * 16 + 4 * g, o);
+    }
+  }
+}
+
+template <typename T>
+static void launch_absorb(void* out, const void* a, const void* w_t, int m, int heads, int n, int k, int tail,
+                          int64_t ars, int64_t ahs, int64_t ors, int64_t ohs, hipStream_t st) {
+  const dim3 grid((unsigned)(n / 16 + (tail ? 1 : 0)), (unsigned)heads), block(64);
+#define LAUNCH(MT_)                                                                                               \
+  hipLaunchKernelGGL((mla_absorb_kernel<T, MT_>), grid, block, 0, st, (T*)out, (const T*)a, (const T*)w_t, m, n, k, \
+                     tail, ars, ahs, ors, ohs)
+  if (m <= 16) LAUNCH(1);
+  else if (m <= 32) LAUNCH(2);
+  else if (m <= 48) LAUNCH(3);
+  else LAUNCH(4);
+#undef LAUNCH
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+int mi355_mla_latent_norms(void* q_out, void* kv_out, void* pe_out, const void* x, int64_t x_row_stride,
+                           const float* part, int nsplit, const float* part_x_scale, const float* part_w_scale,
+                           const void* q_weight, const void* kv_weight, int64_t rows, int q_rank, int kv_rank,
+                           int rope_dim, float eps, int dtype, void* stream) {
+  MI355_REQUIRE(kv_out && pe_out && kv_weight && (x || part) && !(x && part), MI355_ERR_INVALID,
+                "mla_latent_norms: null pointer (exactly one of x and part is given)");
+  MI355_REQUIRE((q_rank == 0) == (q_out == nullptr) && (q_rank == 0) == (q_weight == nullptr), MI355_ERR_INVALID,
+                "mla_latent_norms: q_out and q_weight go with q_rank > 0");
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "mla_latent_norms: only 16-bit dtypes");
+  MI355_REQUIRE(rows >= 0 && q_rank >= 0 && kv_rank > 0 && rope_dim > 0 && q_rank % 8 == 0 && kv_rank % 8 == 0 &&
+                    rope_dim % 8 == 0 && q_rank <= 2048 && kv_rank + rope_dim <= 2048,
+                MI355_ERR_UNSUPPORTED,
+                "mla_latent_norms: needs q_rank, kv_rank, rope_dim %% 8 == 0, q_rank <= 2048, kv_rank + rope_dim <= 2048 "
+                "(q_rank=%d kv_rank=%d rope_dim=%d)", q_rank, kv_rank, rope_dim);
+  const int64_t width = (int64_t)q_rank + kv_rank + rope_dim;
+  MI355_REQUIRE(part || (x_row_stride >= width && x_row_stride % 8 == 0 && aligned16(x)), MI355_ERR_INVALID,
+                "mla_latent_norms: x needs a 16-byte aligned base and a row stride %% 8 == 0 of at least %lld",
+                (long long)width);
+  MI355_REQUIRE(!part || (nsplit >= 1 && nsplit <= 64 && aligned16(part)), MI355_ERR_INVALID,
+                "mla_latent_norms: bad partials (nsplit=%d)", nsplit);
+  MI355_REQUIRE((part_x_scale == nullptr) == (part_w_scale == nullptr) && (!part_x_scale || part), MI355_ERR_INVALID,
+                "mla_latent_norms: scales come in pairs and only with partials");
+  MI355_REQUIRE(aligned16(kv_out) && aligned16(pe_out) && aligned16(kv_weight) && (!q_out || (aligned16(q_out) && aligned16(q_weight))),
+                MI355_ERR_INVALID, "mla_latent_norms: misaligned pointer");
+  if (rows == 0) return MI355_OK;
+  const dim3 grid((unsigned)rows, q_rank ? 2 : 1), block(256);
+#define LAUNCH(T)                                                                                                   \
+  hipLaunchKernelGGL((mla_latent_norms_kernel<T>), grid, block, 0, (hipStream_t)stream, (T*)q_out, (T*)kv_out,      \
+                     (T*)pe_out, (const T*)x, x_row_stride, part, nsplit, rows * width, part_x_scale, part_w_scale, \
+                     (const T*)q_weight, (const T*)kv_weight, q_rank, kv_rank, rope_dim, eps)
+  if (dtype == MI355_BF16) LAUNCH(bf16_t);
+  else LAUNCH(f16_t);
+#undef LAUNCH
+  MI355_CHECK_LAUNCH("mla_latent_norms");
+  return MI355_OK;
+}
+
+int mi355_mla_absorb(void* out, const void* a, const void* w_t, int64_t m, int heads, int n, int k, int tail,
+                     int64_t a_row_stride, int64_t a_head_stride, int64_t out_row_stride, int64_t out_head_stride,
+                     int dtype, void* stream) {
+  MI355_REQUIRE(out && a && w_t, MI355_ERR_INVALID, "mla_absorb: null pointer");
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "mla_absorb: only 16-bit dtypes");
+  MI355_REQUIRE(m >= 0 && m <= 64 && heads >= 1 && heads <= 65535 && n >= 16 && n % 16 == 0 && k >= 32 && k % 32 == 0 &&
+                    tail >= 0 && tail % 8 == 0,
+                MI355_ERR_UNSUPPORTED,
+                "mla_absorb: needs m <= 64, n %% 16 == 0, k %% 32 == 0, tail %% 8 == 0 (m=%lld n=%d k=%d tail=%d)",
+                (long long)m, n, k, tail);
+  MI355_REQUIRE(a_head_stride >= k + tail && out_head_stride >= n + tail && a_row_stride >= a_head_stride &&
+                    out_row_stride >= out_head_stride && a_row_stride % 8 == 0 && a_head_stride % 8 == 0 &&
+                    out_row_stride % 8 == 0 && out_head_stride % 8 == 0,
+                MI355_ERR_INVALID, "mla_absorb: strides must be multiples of 8 elements and cover a head's features");
+  MI355_REQUIRE(aligned16(out) && aligned16(a) && aligned16(w_t), MI355_ERR_INVALID, "mla_absorb: misaligned pointer");
+  if (m == 0) return MI355_OK;
+  if (dtype == MI355_BF16)
+    launch_absorb<bf16_t>(out, a, w_t, (int)m, heads, n, k, tail, a_row_stride, a_head_stride, out_row_stride,
+                          out_head_stride, (hipStream_t)stream);
+  else
+    launch_absorb<f16_t>(out, a, w_t, (int)m, heads, n, k, tail, a_row_stride, a_head_stride, out_row_stride,
+                         out_head_stride, (hipStream_t)stream);
+  MI355_CHECK_LAUNCH("mla_absorb");
+  return MI355_OK;
+}
+
+}  // extern "C"

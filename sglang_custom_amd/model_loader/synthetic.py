@@ -63,6 +63,13 @@ DEEPSEEK_PRESETS = {
         hidden_size=512, num_hidden_layers=2, num_attention_heads=16, q_lora_rank=None, kv_lora_rank=512,
         qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=1024, vocab_size=2048,
         rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=4096, rope_scaling=None),
+    # DeepSeek-V3's own attention / dense-MLP geometry (hidden 7168, 128 heads, q_lora 1536, latent 512 + 64,
+    # dense intermediate 18432 as in its first three layers, vocabulary 129280) with FOUR dense layers: the
+    # per-layer decode cost of the dense part at the real shapes (the 58 mixture-of-experts layers are not built)
+    "deepseek-v3-dense4": dict(
+        hidden_size=7168, num_hidden_layers=4, num_attention_heads=128, q_lora_rank=1536, kv_lora_rank=512,
+        qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=18432, vocab_size=129280,
+        rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192, rope_scaling=_YARN_V3),
     "tiny-deepseek-yarn": dict(
         hidden_size=512, num_hidden_layers=2, num_attention_heads=16, q_lora_rank=192, kv_lora_rank=512,
         qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=1024, vocab_size=2048,

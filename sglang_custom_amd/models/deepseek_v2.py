@@ -29,9 +29,12 @@ from ..layers.layernorm import RMSNorm
 from ..distributed.parallel_state import get_tensor_model_parallel_world_size
 from ..layers.linear import MergedColumnParallelLinear, ReplicatedLinear, RowParallelLinear
 from ..layers.logits_processor import LogitsProcessor
+from ..layers.quantization.unquant import UnquantizedLinearMethod, decode_linear_deferred, pack_gate_up_for_decode
 from ..layers.radix_attention import RadixAttention
+from ..ops_backend import get_ops
 from ..layers.rotary_embedding import get_rope, yarn_get_mscale
 from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
+from .llama import LlamaMLP, wants_fp8_input
 
 
 class DeepseekV2AttentionMLA(nn.Module):
@@ -80,6 +83,7 @@ class DeepseekV2AttentionMLA(nn.Module):
         self.attn_mha = RadixAttention(self.num_local_heads, self.qk_head_dim, self.scaling, num_kv_heads=self.num_local_heads,
                                        layer_id=layer_id, v_head_dim=v_head_dim)
         self.w_kc = self.w_vc = None
+        self.w_kc_t = self.w_vc_t = None    # the same per-head matrices transposed, for the one-launch decode products
         for m in self.modules():
             if isinstance(m, RMSNorm):
                 m.weight.data = m.weight.data.to(dtype=dtype, device=device)
@@ -126,6 +130,11 @@ class DeepseekV2AttentionMLA(nn.Module):
             w_vc = w_vc.to(torch.bfloat16) * self.w_scale
         self.w_kc = w_kc.contiguous().to(self.dtype)
         self.w_vc = w_vc.transpose(1, 2).contiguous().to(self.dtype)
+        if self.w_kc.is_cuda and self.dtype in (torch.bfloat16, torch.float16):
+            # [H, n, k] with the reduction dimension contiguous: what ops.mla_absorb streams (2 x 2 MB per layer at
+            # DeepSeek-V3's TP=8 shard shape)
+            self.w_kc_t = self.w_kc.transpose(1, 2).contiguous()
+            self.w_vc_t = self.w_vc.transpose(1, 2).contiguous()
 
     # ---- shared front end ----
     def _q_and_latent(self, hidden_states):
@@ -163,32 +172,82 @@ class DeepseekV2AttentionMLA(nn.Module):
         return self.o_proj(attn_output.reshape(-1, self.num_local_heads * self.v_head_dim))[0]
 
     # ---- decode ----
-    def forward_absorb(self, positions, hidden_states, forward_batch):
-        assert self.w_kc is not None, "call post_load_weights() after loading kv_b_proj"
-        q, latent = self._q_and_latent(hidden_states)
-        k_nope = self.kv_a_layernorm(latent[..., : self.kv_lora_rank].contiguous()).unsqueeze(1)
-        backend = forward_batch.attn_backend
-        if backend.supports_mla_fused_rope(self.attn_mqa, self.rotary_emb, forward_batch, q.dtype):
-            # MLA_FUSED_ROPE (deepseek_v2.py:973-980, 1337-1536): q's rope part and k_pe go in unrotated; the
-            # decode launch rotates them, writes the new latent row and attends
-            q_nope, q_pe = q.split([self.qk_nope_head_dim, self.qk_rope_head_dim], dim=-1)
-            q_nope_out = torch.bmm(q_nope.transpose(0, 1), self.w_kc).transpose(0, 1)
-            qa = torch.cat([q_nope_out, q_pe], dim=-1)
-            attn_output = backend.forward_decode_mla_fused_rope(
-                qa, k_nope.squeeze(1), latent[..., self.kv_lora_rank:], positions, self.rotary_emb, self.attn_mqa,
-                forward_batch)
-            attn_output = attn_output.view(-1, self.num_local_heads, self.kv_lora_rank)
-            out = torch.bmm(attn_output.transpose(0, 1), self.w_vc).transpose(0, 1).flatten(1, 2)
-            return self.o_proj(out.contiguous())[0]
-        k_pe = self._rope(positions, q, latent)
+    def _decode_front(self, hidden_states):
+        """Decode-sized batches: the "a" projection's split-K partials (or its output) go through ONE launch that
+        sums them and applies q_a_layernorm and kv_a_layernorm (ops.mla_latent_norms) instead of a split, two
+        copies and two norms.  Returns (q [T, H, nope + rope], normed c_kv [T, rank], k_pe [T, rope] unrotated),
+        or None when the shape or the ops backend does not serve it."""
+        ops = get_ops()
+        x = hidden_states
+        rank, rope = self.kv_lora_rank, self.qk_rope_head_dim
+        q_rank = self.q_lora_rank or 0
+        if (x.dim() != 2 or not x.is_cuda or x.shape[0] > 64
+                or not ops.mla_latent_norms_supported(q_rank, rank, rope, x.dtype)):
+            return None
+        proj = self.fused_qkv_a_proj_with_mqa if q_rank else self.kv_a_proj_with_mqa
+        qw = self.q_a_layernorm.weight.data if q_rank else None
+        kvw, eps = self.kv_a_layernorm.weight.data, self.kv_a_layernorm.variance_epsilon
+        part = decode_linear_deferred(proj, x, needs_all_reduce=False)
+        if part is not None:
+            q, c_kv, k_pe = ops.mla_latent_norms(qw, kvw, q_rank, rank, rope, eps, part=part.part,
+                                                 part_x_scale=part.x_scale, part_w_scale=part.w_scale)
+        else:
+            q, c_kv, k_pe = ops.mla_latent_norms(qw, kvw, q_rank, rank, rope, eps, x=proj(x)[0])
+        q = self.q_b_proj(q)[0] if q_rank else self.q_proj(x)[0]
+        return q.view(-1, self.num_local_heads, self.qk_head_dim), c_kv, k_pe
+
+    def _absorb_q(self, q):
+        """[T, H, nope + rope] -> [T, H, rank + rope]: q_nope . w_kc per head with q's rope part carried behind it
+        (deepseek_v2.py:1234-1262)."""
+        ops = get_ops()
+        if (self.w_kc_t is not None and q.is_cuda
+                and ops.mla_absorb_supported(q.shape[0], self.kv_lora_rank, self.qk_nope_head_dim, self.qk_rope_head_dim, q.dtype)):
+            return ops.mla_absorb(q, self.w_kc_t, tail=self.qk_rope_head_dim)
         q_nope, q_pe = q.split([self.qk_nope_head_dim, self.qk_rope_head_dim], dim=-1)
         q_nope_out = torch.bmm(q_nope.transpose(0, 1), self.w_kc).transpose(0, 1)       # [T, H, rank]
-        qa = torch.cat([q_nope_out, q_pe], dim=-1)
-        ka = torch.cat([k_nope, k_pe], dim=-1)
-        attn_output = self.attn_mqa(qa, ka, k_nope, forward_batch)
-        attn_output = attn_output.view(-1, self.num_local_heads, self.kv_lora_rank)
-        out = torch.bmm(attn_output.transpose(0, 1), self.w_vc).transpose(0, 1).flatten(1, 2)
-        return self.o_proj(out.contiguous())[0]
+        return torch.cat([q_nope_out, q_pe], dim=-1)
+
+    def _absorb_out(self, attn_output):
+        """[T, H * rank] -> [T, H * v]: attn . w_vc per head, in o_proj's input layout (deepseek_v2.py:1296-1333)."""
+        ops = get_ops()
+        a = attn_output.view(-1, self.num_local_heads, self.kv_lora_rank)
+        if (self.w_vc_t is not None and a.is_cuda
+                and ops.mla_absorb_supported(a.shape[0], self.v_head_dim, self.kv_lora_rank, 0, a.dtype)):
+            return ops.mla_absorb(a, self.w_vc_t).flatten(1, 2)
+        return torch.bmm(a.transpose(0, 1), self.w_vc).transpose(0, 1).flatten(1, 2).contiguous()
+
+    def _o_proj(self, x):
+        """o_proj with its split-K sum (tensor-parallel: its sum over the ranks) left to the norm that follows."""
+        deferred = decode_linear_deferred(self.o_proj, x)
+        if deferred is not None:
+            return deferred
+        return self.o_proj(x, defer_all_reduce=True)[0]
+
+    def forward_absorb(self, positions, hidden_states, forward_batch):
+        assert self.w_kc is not None, "call post_load_weights() after loading kv_b_proj"
+        backend = forward_batch.attn_backend
+        fused_rope = backend.supports_mla_fused_rope(self.attn_mqa, self.rotary_emb, forward_batch, hidden_states.dtype)
+        front = self._decode_front(hidden_states) if forward_batch.forward_mode.is_decode() else None
+        if front is not None:
+            q, c_kv, k_pe = front
+        else:
+            q, latent = self._q_and_latent(hidden_states)
+            c_kv = self.kv_a_layernorm(latent[..., : self.kv_lora_rank].contiguous())
+            k_pe = latent[..., self.kv_lora_rank:]
+        if fused_rope:
+            # MLA_FUSED_ROPE (deepseek_v2.py:973-980, 1337-1536): q's rope part and k_pe go in unrotated; the
+            # decode launch rotates them, writes the new latent row and attends
+            attn_output = backend.forward_decode_mla_fused_rope(
+                self._absorb_q(q), c_kv, k_pe, positions, self.rotary_emb, self.attn_mqa, forward_batch)
+            return self._o_proj(self._absorb_out(attn_output))
+        T = q.shape[0]
+        q_pe = q[..., self.qk_nope_head_dim:].contiguous()
+        q_pe, k_pe = self.rotary_emb(positions, q_pe.view(T, -1), k_pe.contiguous().view(T, -1))
+        q[..., self.qk_nope_head_dim:] = q_pe.view(T, self.num_local_heads, self.qk_rope_head_dim)
+        k_nope = c_kv.unsqueeze(1)
+        ka = torch.cat([k_nope, k_pe.view(T, 1, self.qk_rope_head_dim)], dim=-1)
+        attn_output = self.attn_mqa(self._absorb_q(q), ka, k_nope, forward_batch)
+        return self._o_proj(self._absorb_out(attn_output))
 
     def forward(self, positions, hidden_states, forward_batch):
         # dispatch_attn_forward_method (:969-1039) for the Triton backend: multi-head form for a
@@ -199,18 +258,10 @@ class DeepseekV2AttentionMLA(nn.Module):
 
 
 # =============================== the decoder stack (dense layers) ===================================
-class DeepseekV2MLP(nn.Module):
-    """gate_up -> SiLU-and-mul -> down (:167-219); column- / row-parallel over the ranks (:182-198)."""
-
-    def __init__(self, hidden_size: int, intermediate_size: int, dtype, device, quant_method_factory=None):
-        super().__init__()
-        qm = quant_method_factory or (lambda: None)
-        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size, intermediate_size], dtype, device, qm())
-        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, dtype, device, qm())
-        self.act_fn = SiluAndMul()
-
-    def forward(self, x):
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)[0]))[0]
+class DeepseekV2MLP(LlamaMLP):
+    """gate_up -> SiLU-and-mul -> down (:167-219); column- / row-parallel over the ranks (:182-198).  The same
+    module as LlamaMLP, decode fusions included: SiLU-and-mul in the gate_up GEMM's epilogue, and down_proj's
+    split-K sum (tensor-parallel: its sum over the ranks) left to the next layer's norm."""
 
 
 class DeepseekV2DecoderLayer(nn.Module):
@@ -235,7 +286,10 @@ class DeepseekV2DecoderLayer(nn.Module):
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions, hidden_states, forward_batch)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        if wants_fp8_input(self.mlp.gate_up_proj, hidden_states.shape[0]):   # the norm also quantises for the fp8 GEMM
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual, quant_fp8=True)
+        else:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         return self.mlp(hidden_states), residual
 
 
@@ -321,6 +375,9 @@ class DeepseekV2ForCausalLM(nn.Module):
         for layer in self.model.layers:
             for lin in layer.self_attn.linears() + [layer.mlp.gate_up_proj, layer.mlp.down_proj]:
                 lin.quant_method.process_weights_after_loading(lin)
+            gu = layer.mlp.gate_up_proj
+            if isinstance(gu.quant_method, UnquantizedLinearMethod):
+                pack_gate_up_for_decode(gu)     # gate and up rows interleaved: SiLU-and-mul in the decode GEMM's epilogue
             layer.self_attn.post_load_weights()
 
     @torch.no_grad()

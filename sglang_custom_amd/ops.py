@@ -478,6 +478,68 @@ def decode_attention_mla_fused_rope(q, k_nope, k_pe, positions, out_cache_loc, c
         _dt(q), _stream(q)), "decode_attention_mla_fused_rope")
 
 
+def mla_latent_norms_supported(q_rank: int, kv_rank: int, rope_dim: int, dtype: torch.dtype) -> bool:
+    """Whether mla_latent_norms serves the shape (16-bit; the widths multiples of 8, at most 2048 per part)."""
+    return (dtype in (torch.bfloat16, torch.float16) and q_rank % 8 == 0 and kv_rank % 8 == 0 and rope_dim % 8 == 0
+            and 0 <= q_rank <= 2048 and 0 < kv_rank and 0 < rope_dim and kv_rank + rope_dim <= 2048)
+
+
+def mla_latent_norms(q_weight: Optional[torch.Tensor], kv_weight: torch.Tensor, q_rank: int, kv_rank: int, rope_dim: int,
+                     eps: float, x: Optional[torch.Tensor] = None, part: Optional[torch.Tensor] = None,
+                     part_x_scale: Optional[torch.Tensor] = None, part_w_scale: Optional[torch.Tensor] = None):
+    """q_a_layernorm and kv_a_layernorm over the two parts of fused_qkv_a_proj_with_mqa's output row
+    [q_a | c_kv | k_pe] in one launch (deepseek_v2.py:1193-1232): from x [M, width] (row-strided view allowed) or
+    from that GEMM's split-K partials [splits, M, width] (with the fp8 GEMM's scales when it was one).  Returns
+    (q_a normed [M, q_rank] or None when q_rank == 0, c_kv normed [M, kv_rank], k_pe [M, rope_dim]), all dense."""
+    src = part if part is not None else x
+    _gpu(src, q_weight, kv_weight)
+    dt = kv_weight.dtype
+    width = q_rank + kv_rank + rope_dim
+    if part is not None:
+        assert part.dim() == 3 and part.is_contiguous() and part.dtype == torch.float32 and part.shape[2] == width
+        rows = part.shape[1]
+    else:
+        assert x.dim() == 2 and x.shape[1] == width and x.stride(1) == 1 and x.dtype == dt
+        rows = x.shape[0]
+    assert kv_weight.is_contiguous() and kv_weight.numel() == kv_rank
+    assert (q_weight is None) == (q_rank == 0)
+    q_out = None
+    if q_rank:
+        assert q_weight.is_contiguous() and q_weight.numel() == q_rank and q_weight.dtype == dt
+        q_out = torch.empty((rows, q_rank), dtype=dt, device=kv_weight.device)
+    kv_out = torch.empty((rows, kv_rank), dtype=dt, device=kv_weight.device)
+    pe_out = torch.empty((rows, rope_dim), dtype=dt, device=kv_weight.device)
+    if rows:
+        check(_lib_().mi355_mla_latent_norms(
+            _p(q_out), kv_out.data_ptr(), pe_out.data_ptr(), _p(x), x.stride(0) if x is not None else 0, _p(part),
+            part.shape[0] if part is not None else 0, _p(part_x_scale), _p(part_w_scale), _p(q_weight),
+            kv_weight.data_ptr(), rows, q_rank, kv_rank, rope_dim, float(eps), _dt(kv_weight), _stream(kv_weight)),
+            "mla_latent_norms")
+    return q_out, kv_out, pe_out
+
+
+def mla_absorb_supported(m: int, n: int, k: int, tail: int, dtype: torch.dtype) -> bool:
+    """Whether mla_absorb serves the shape (decode-sized batch, 16-bit, MFMA-tileable)."""
+    return (dtype in (torch.bfloat16, torch.float16) and 0 <= m <= 64 and n >= 16 and n % 16 == 0 and k >= 32
+            and k % 32 == 0 and tail % 8 == 0)
+
+
+def mla_absorb(a: torch.Tensor, w_t: torch.Tensor, tail: int = 0) -> torch.Tensor:
+    """The absorbed products of MLA decode as one launch each (deepseek_v2.py:1234-1262, 1296-1333):
+    a [M, H, k + tail] (row- and head-strided view allowed, features contiguous), w_t [H, n, k] (each head's
+    matrix with the reduction dimension contiguous) -> out [M, H, n + tail] with out[..., :n] = a[..., :k] @ w_t[h].T
+    per head and out[..., n:] = a[..., k:].  M <= 64."""
+    _gpu(a, w_t)
+    m, heads, feat = a.shape
+    hw, n, k = w_t.shape
+    assert hw == heads and feat == k + tail and a.stride(2) == 1 and w_t.is_contiguous() and a.dtype == w_t.dtype
+    out = torch.empty((m, heads, n + tail), dtype=a.dtype, device=a.device)
+    if m:
+        check(_lib_().mi355_mla_absorb(out.data_ptr(), a.data_ptr(), w_t.data_ptr(), m, heads, n, k, tail, a.stride(0),
+                                       a.stride(1), out.stride(0), out.stride(1), _dt(a), _stream(a)), "mla_absorb")
+    return out
+
+
 def extend_attention_mla_supported(hq: int, kv_lora_rank: int, rope_dim: int, dtype: torch.dtype) -> bool:
     """Whether extend_attention_mla serves the shape (latent row of 512 + 64 features, 16-bit)."""
     return dtype in (torch.bfloat16, torch.float16) and bool(

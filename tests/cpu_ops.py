@@ -167,3 +167,15 @@ def decode_attention_mla_fused_rope_supported(kv_lora_rank, rope_dim, dtype, cac
     """RoPE + latent-row write inside the MLA decode launch is a GPU kernel only: the double declines and the
     model takes rotary_emb + set_kv_buffer + decode_attention_mla, which is what the oracle restates."""
     return False
+
+
+def mla_latent_norms_supported(q_rank, kv_rank, rope_dim, dtype):
+    """The one-launch q_a / kv_a norms are a GPU kernel only: the double declines and the model takes
+    split + contiguous + rmsnorm, which is what the oracle restates."""
+    return False
+
+
+def mla_absorb_supported(m, n, k, tail, dtype):
+    """The one-launch absorbed products are a GPU kernel only: the double declines and the model takes
+    torch.bmm + cat / transpose, which is what the oracle restates."""
+    return False

@@ -553,3 +553,98 @@ def test_mla_decode_with_rope_and_cache_write_inside_the_launch(H, splits, in_ke
         assert not bad, (bad, (got.float() - want.float()).abs().max().item())
         if tickets is not None:
             assert int(tickets.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,q_rank,kv_rank,rope", [(64, 1536, 512, 64), (1, 1536, 512, 64), (7, 0, 512, 64), (33, 2048, 1984, 64),
+                                                      (5, 8, 8, 8)])
+def test_mla_latent_norms_is_split_plus_two_rmsnorms_bit_for_bit(dt, rows, q_rank, kv_rank, rope):
+    """One launch over the [q_a | c_kv | k_pe] row == split + contiguous + rmsnorm per part (and == the oracle's
+    RMSNorm), from a dense row, from a row-strided view, and from fp32 split-K partials (bf16 and fp8-scaled)."""
+    from oracle import ops_ref
+    from sglang_custom_amd import ops
+
+    g = torch.Generator().manual_seed(rows * 131 + q_rank + kv_rank)
+    width = q_rank + kv_rank + rope
+    wide = torch.randn(rows, width + 24, generator=g).to(dt).to(DEV)
+    x = wide[:, 8: 8 + width]                       # row-strided, 16-byte aligned view
+    qw = (1 + 0.1 * torch.randn(q_rank, generator=g)).to(dt).to(DEV) if q_rank else None
+    kvw = (1 + 0.1 * torch.randn(kv_rank, generator=g)).to(dt).to(DEV)
+    eps = 1e-6
+
+    def unfused(row):
+        q = ops.rmsnorm(row[:, :q_rank].contiguous(), qw, eps) if q_rank else None
+        kv = ops.rmsnorm(row[:, q_rank: q_rank + kv_rank].contiguous(), kvw, eps)
+        return q, kv, row[:, q_rank + kv_rank:].contiguous()
+
+    def same(got, want):
+        for a, b in zip(got, want):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert a.is_contiguous() and torch.equal(a, b)
+
+    want = unfused(x)
+    same(ops.mla_latent_norms(qw, kvw, q_rank, kv_rank, rope, eps, x=x), want)
+    same(ops.mla_latent_norms(qw, kvw, q_rank, kv_rank, rope, eps, x=x.contiguous()), want)
+    ref_kv = ops_ref.rmsnorm(x[:, q_rank: q_rank + kv_rank].cpu(), kvw.cpu(), eps)
+    torch.testing.assert_close(want[1].float().cpu(), ref_kv.float(), atol=2e-2, rtol=2e-2)
+
+    # split-K partials: summed in split order, rounded once, then normalised
+    part = torch.randn(3, rows, width, generator=g).to(DEV)
+    summed = ((part[0] + part[1]) + part[2]).to(dt)
+    same(ops.mla_latent_norms(qw, kvw, q_rank, kv_rank, rope, eps, part=part), unfused(summed))
+    xs = (0.5 + torch.rand(rows, 1, generator=g)).to(DEV)
+    ws = (0.5 + torch.rand(width, 1, generator=g)).to(DEV)
+    scaled = ((((part[0] + part[1]) + part[2]) * xs) * ws.view(1, -1)).to(dt)
+    same(ops.mla_latent_norms(qw, kvw, q_rank, kv_rank, rope, eps, part=part, part_x_scale=xs, part_w_scale=ws), unfused(scaled))
+
+
+def test_mla_latent_norms_refuses_what_it_does_not_serve():
+    from sglang_custom_amd import _lib, ops
+
+    kvw = torch.ones(512, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.Mi355Error, match="mla_latent_norms"):
+        ops.mla_latent_norms(None, kvw[:508].contiguous(), 0, 508, 64, 1e-6, x=torch.zeros(2, 572, dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(_lib.Mi355Error, match="mla_latent_norms"):
+        ops.mla_latent_norms(torch.ones(4096, dtype=torch.bfloat16, device=DEV), kvw, 4096, 512, 64, 1e-6,
+                             x=torch.zeros(2, 4096 + 576, dtype=torch.bfloat16, device=DEV))
+    assert not ops.mla_latent_norms_supported(1536, 512, 64, torch.float32)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,heads,n,k,tail", [(64, 16, 512, 128, 64), (1, 16, 512, 128, 64), (17, 5, 512, 128, 64), (64, 16, 128, 512, 0),
+                                              (33, 128, 128, 512, 0), (48, 3, 16, 32, 8)])
+def test_mla_absorb_matches_float64_per_head_products(dt, m, heads, n, k, tail):
+    """Both absorbed products of MLA decode (q_nope . w_kc with the rope part carried along; attn . w_vc in
+    o_proj's layout) against a float64 product of the same rounded operands, rounded once; the copied tail is
+    exact; row- and head-strided inputs."""
+    from sglang_custom_amd import ops
+
+    g = torch.Generator().manual_seed(m * 7 + heads * 3 + n + k)
+    wide = torch.randn(m, heads, k + tail + 8, generator=g).to(dt).to(DEV)
+    a = wide[..., : k + tail]
+    w_t = (torch.randn(heads, n, k, generator=g) * k ** -0.5).to(dt).to(DEV)
+    out = ops.mla_absorb(a, w_t, tail=tail)
+    assert out.shape == (m, heads, n + tail) and out.is_contiguous()
+    want = torch.einsum("mhk,hnk->mhn", a[..., :k].double().cpu(), w_t.double().cpu())
+    # one rounding of an fp32 accumulation: within half a unit in the last place of the 16-bit type plus fp32 noise
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10    # spacing relative to the value, at most
+    err = (out[..., :n].double().cpu() - want).abs()
+    assert (err <= want.abs() * ulp * 0.51 + 1e-5).all(), err.max().item()
+    if tail:
+        assert torch.equal(out[..., n:], a[..., k:])
+    torch.testing.assert_close(out[..., :n].float(), torch.bmm(a[..., :k].transpose(0, 1), w_t.transpose(1, 2)).transpose(0, 1).float(),
+                               atol=4 * ulp, rtol=4 * ulp)
+
+
+def test_mla_absorb_refuses_what_it_does_not_serve():
+    from sglang_custom_amd import _lib, ops
+
+    a = torch.zeros(65, 2, 128, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(2, 512, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.Mi355Error, match="mla_absorb"):
+        ops.mla_absorb(a, w)
+    with pytest.raises(_lib.Mi355Error, match="mla_absorb"):
+        ops.mla_absorb(a[:4, :, :120], torch.zeros(2, 512, 120, dtype=torch.bfloat16, device=DEV))
+    assert not ops.mla_absorb_supported(65, 512, 128, 64, torch.bfloat16)
+    assert not ops.mla_absorb_supported(8, 512, 128, 64, torch.float32)
