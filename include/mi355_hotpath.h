@@ -342,13 +342,15 @@ int mi355_extend_attention_mla(const void* q, const void* kv_buffer, void* o, co
  * writes q_out [rows, q_rank] = RMSNorm(q_a) * q_weight, kv_out [rows, kv_rank] = RMSNorm(c_kv) * kv_weight and
  * pe_out [rows, rope_dim] = k_pe, all dense.  q_rank == 0 (a model without q_lora: x is kv_a_proj_with_mqa's
  * output) skips the q part (q_out, q_weight NULL).  Same bits as split + contiguous + mi355_rmsnorm per part.
+ * q_fp8_out [rows, q_rank] e4m3fn + q_fp8_scale [rows] (both or neither): also the per-token fp8 quantisation
+ * of q_out's rows (= mi355_per_token_quant_fp8 on them), for an fp8 W8A8 q_b_proj.
  * Needs a 16-bit dtype, q_rank <= 2048, kv_rank + rope_dim <= 2048, all three % 8 == 0.
  * replaces: q_a_layernorm / kv_a_layernorm around the split of fused_qkv_a_proj_with_mqa in
  *           DeepseekV2AttentionMLA.forward_absorb_prepare (python/sglang/srt/models/deepseek_v2.py:1193-1232). */
 int mi355_mla_latent_norms(void* q_out, void* kv_out, void* pe_out, const void* x, int64_t x_row_stride,
                            const float* part, int nsplit, const float* part_x_scale, const float* part_w_scale,
-                           const void* q_weight, const void* kv_weight, int64_t rows, int q_rank, int kv_rank,
-                           int rope_dim, float eps, int dtype, void* stream);
+                           const void* q_weight, const void* kv_weight, uint8_t* q_fp8_out, float* q_fp8_scale,
+                           int64_t rows, int q_rank, int kv_rank, int rope_dim, float eps, int dtype, void* stream);
 
 /* mi355_mla_absorb: out[m, h, 0..n) = sum_k a[m, h, k] * w_t[h, j, k] for m < M <= 64 rows and every head, fp32
  * accumulation, rounded once to the 16-bit dtype; a[m, h, k .. k + tail) is copied to out[m, h, n .. n + tail).
@@ -410,7 +412,7 @@ int mi355_linear_packed(void* y, const void* x, const void* w_packed, const void
  * `out`, and optionally their per-token fp8 quantisation (q_out [rows, hidden] e4m3fn + q_scale
  * [rows]; identical to mi355_per_token_quant_fp8 applied to `out`) for the fp8 GEMM that follows.
  * mi355_silu_and_mul_quant_fp8 = mi355_silu_and_mul followed by mi355_per_token_quant_fp8 in one
- * launch (the 16-bit activation is never written).
+ * launch (the 16-bit activation is never written); q_stride as in mi355_per_token_quant_fp8.
  * replaces: apply_fp8_linear's quantise-then-GEMM pairs (layers/quantization/fp8_utils.py:676-749)
  *           around RMSNorm / SiluAndMul on the decode path; no fused counterpart in the reference. */
 int mi355_fp8_packed_splits(int64_t m, int64_t n, int64_t k);
@@ -420,7 +422,7 @@ int mi355_rmsnorm_ex(void* out, const void* x, void* residual, const void* weigh
                      int nsplit, const float* part_x_scale, const float* part_w_scale, uint8_t* q_out,
                      float* q_scale, int64_t rows, int64_t hidden, float eps, int dtype, void* stream);
 int mi355_silu_and_mul_quant_fp8(uint8_t* q_out, float* q_scale, const void* x, int64_t rows, int64_t d,
-                                 int dtype, void* stream);
+                                 int64_t q_stride, int dtype, void* stream);
 int mi355_linear_packed_splits(int64_t m, int64_t n, int64_t k);
 int mi355_linear_packed_partials(float* part, const void* x, const void* w_packed, int64_t m, int64_t n,
                                  int64_t k, int64_t x_stride, int dtype, void* stream);
@@ -453,11 +455,13 @@ int mi355_linear_tiled(void* y, const void* x, const void* w, const void* bias, 
 
 /* ---- K14 fp8 W8A8 ------------------------------------------------------------------------------
  * Per-token dynamic quantisation to OCP e4m3fn (max 448): s[r] = max(absmax(x[r,:]), 1e-10)/448,
- * q = clamp(x/s, +-448) -> fp8.
+ * q = clamp(x/s, +-448) -> fp8.  Row r of xq starts at byte r * q_stride (q_stride >= k); bytes k .. q_stride of
+ * every row are set to zero, so that a reduction length the packed GEMM does not stream (K % 512 != 0) can be
+ * rounded up with zero weights and zero activations behind it.
  * replaces: per_token_group_quant_fp8 with group = K (layers/quantization/fp8_kernel.py:115-155,
  *           fp8_utils.py:676-678), sgl_per_token_quant_fp8 (sgl-kernel/csrc/gemm/per_token_quant_fp8.cu). */
 int mi355_per_token_quant_fp8(uint8_t* xq, float* scales, const void* x, int64_t rows, int64_t k,
-                              int64_t x_stride, int dtype, void* stream);
+                              int64_t x_stride, int64_t q_stride, int dtype, void* stream);
 
 /* y[m,n] = T( (sum_k fp8(xq[m,k]) * fp8(wq[n,k])) * x_scale[m] * w_scale[n] (+ bias[n]) ),
  * wq is [N, K] e4m3fn (row per output channel), fp32 accumulation on the fp8 MFMA; bias (may be

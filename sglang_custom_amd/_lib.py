@@ -46,7 +46,7 @@ _SIGNATURES = {
     "mi355_decode_attention_mla": (I, [P, P, P, P, I, P, P, P, L, P, P, P, P, I, L, I, I, I, L, L, F, F, I, P]),
     "mi355_extend_attention_mla_supported": (I, [I, I, I, I]),
     "mi355_extend_attention_mla": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, L, L, F, F, I, P]),
-    "mi355_mla_latent_norms": (I, [P, P, P, P, L, P, I, P, P, P, P, L, I, I, I, F, I, P]),
+    "mi355_mla_latent_norms": (I, [P, P, P, P, L, P, I, P, P, P, P, P, P, L, I, I, I, F, I, P]),
     "mi355_mla_absorb": (I, [P, P, P, L, I, I, I, I, L, L, L, L, I, P]),
     "mi355_linear_packed": (I, [P, P, P, P, L, L, L, L, P, L, I, I, P]),
     "mi355_linear_packed_silu_mul": (I, [P, P, P, L, L, L, L, P, L, I, P]),
@@ -66,7 +66,7 @@ _SIGNATURES = {
     "mi355_fp8_packed_splits": (I, [L, L, L]),
     "mi355_fp8_packed_partials": (I, [P, P, P, L, L, L, P]),
     "mi355_rmsnorm_ex": (I, [P, P, P, P, P, I, P, P, P, P, L, L, F, I, P]),
-    "mi355_silu_and_mul_quant_fp8": (I, [P, P, P, L, L, I, P]),
+    "mi355_silu_and_mul_quant_fp8": (I, [P, P, P, L, L, L, I, P]),
     "mi355_linear_packed_splits": (I, [L, L, L]),
     "mi355_linear_packed_partials": (I, [P, P, P, L, L, L, L, I, P]),
     "mi355_ar_region_bytes": (L, [L]),
@@ -86,7 +86,7 @@ _SIGNATURES = {
     "mi355_ar_fused_add_rmsnorm": (I, [P, P, P, P, L, L, F, I, P]),
     "mi355_ar_status": (I, [P, P]),
     "mi355_fused_add_rmsnorm_partials": (I, [P, P, P, P, I, L, L, F, I, P]),
-    "mi355_per_token_quant_fp8": (I, [P, P, P, L, L, L, I, P]),
+    "mi355_per_token_quant_fp8": (I, [P, P, P, L, L, L, L, I, P]),
     "mi355_fp8_workspace_bytes": (L, [L, L, L]),
     "mi355_fp8_scaled_mm": (I, [P, P, P, P, P, P, L, L, L, P, L, I, P]),
     "mi355_argmax": (I, [P, P, L, L, L, P]),

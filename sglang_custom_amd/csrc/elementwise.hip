@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void softcap_kernel(float* __restrict__ x, int
 template <typename T>
 __global__ __launch_bounds__(1024) void silu_mul_quant_fp8_kernel(uint8_t* __restrict__ q_out,
                                                                   float* __restrict__ q_scale,
-                                                                  const T* __restrict__ x, int64_t d) {
+                                                                  const T* __restrict__ x, int64_t d,
+                                                                  int64_t q_stride) {
   // 1024 threads per row: with one workgroup per token the launch is latency-bound, so the row is
   // spread over as many lanes as a workgroup has (two 16-byte pairs per thread at d = 14336).
   constexpr int MAXV = 2;
@@ -340,8 +341,11 @@ __global__ __launch_bounds__(1024) void silu_mul_quant_fp8_kernel(uint8_t* __res
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int idx = threadIdx.x + i * 1024;
-    if (idx < nvec) *reinterpret_cast<uint2*>(q_out + row * d + (int64_t)idx * 8) = quant8_fp8<T>(o[i], inv);
+    if (idx < nvec) *reinterpret_cast<uint2*>(q_out + row * q_stride + (int64_t)idx * 8) = quant8_fp8<T>(o[i], inv);
   }
+  // a row padded for the consumer (a reduction length rounded up to what its kernel streams): zeros behind d
+  for (int idx = nvec + threadIdx.x; idx < (int)(q_stride >> 3); idx += 1024)
+    *reinterpret_cast<uint2*>(q_out + row * q_stride + (int64_t)idx * 8) = uint2{0u, 0u};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,21 +639,23 @@ int mi355_rmsnorm_ex(void* out, const void* x, void* residual, const void* weigh
 }
 
 int mi355_silu_and_mul_quant_fp8(uint8_t* q_out, float* q_scale, const void* x, int64_t rows, int64_t d,
-                                 int dtype, void* stream) {
+                                 int64_t q_stride, int dtype, void* stream) {
   MI355_REQUIRE(q_out && q_scale && x, MI355_ERR_INVALID, "silu_and_mul_quant_fp8: null pointer");
   MI355_REQUIRE(rows >= 0 && d > 0 && d % 8 == 0 && d <= 16384, MI355_ERR_UNSUPPORTED,
                 "silu_and_mul_quant_fp8: needs d %% 8 == 0 and d <= 16384 (d=%lld)", (long long)d);
   MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED,
                 "silu_and_mul_quant_fp8: only 16-bit dtypes");
+  MI355_REQUIRE(q_stride >= d && q_stride % 8 == 0, MI355_ERR_INVALID,
+                "silu_and_mul_quant_fp8: q_stride must be a multiple of 8 and at least d (q_stride=%lld)", (long long)q_stride);
   MI355_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(q_out) & 7) == 0, MI355_ERR_INVALID,
                 "silu_and_mul_quant_fp8: misaligned pointer");
   if (rows == 0) return MI355_OK;
   if (dtype == MI355_BF16)
     hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<bf16_t>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
-                       q_out, q_scale, (const bf16_t*)x, d);
+                       q_out, q_scale, (const bf16_t*)x, d, q_stride);
   else
     hipLaunchKernelGGL((silu_mul_quant_fp8_kernel<f16_t>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
-                       q_out, q_scale, (const f16_t*)x, d);
+                       q_out, q_scale, (const f16_t*)x, d, q_stride);
   MI355_CHECK_LAUNCH("silu_and_mul_quant_fp8");
   return MI355_OK;
 }

@@ -623,6 +623,13 @@ static constexpr int g_force_waves = 0;
 // side per workgroup share one activation tile, K is split `splits` ways.  Aim: one or two
 // workgroups per CU (256 CUs) with equal work, >= 2 chunks each; splitting K costs fp32 partial
 // traffic (splits * M * N * 8 bytes written + read), so wide outputs are never split.
+// Most splits a reduction of k elements (kchunks chunks of SK_BK) is cut into: two chunks per split, except
+// that a short reduction (under four chunks: the low-rank projections of MLA) may go down to one -- there the
+// launch is a latency chain and the extra workgroups are what shortens it.
+static int64_t max_splits_for(int64_t k, int64_t kchunks) {
+  return k < 4 * SK_BK ? std::max<int64_t>(1, kchunks) : std::min<int64_t>(16, k / 512);
+}
+
 static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k, bool ring) {
   SkinnyPlan p;
   // Very wide outputs (lm_head): two tiles per wave and, on the ring kernel, eight waves -- 256
@@ -641,7 +648,7 @@ static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k, bool ring) {
     for (int w : {4, 6, 7, 8}) {
       if (g_force_waves > 0 && w != g_force_waves) continue;
       const int64_t nb = (tiles + w - 1) / w;
-      const int64_t smax = std::min<int64_t>(16, std::max<int64_t>(1, k / 512));
+      const int64_t smax = max_splits_for(k, kchunks);
       for (int64_t s = 1; s <= smax; ++s) {
         if (s > 1 && nb > SK_COUNTER_BYTES / 4) break;
         const int64_t chunks = (kchunks + s - 1) / s;
@@ -659,7 +666,7 @@ static SkinnyPlan plan_skinny(int64_t m, int64_t n, int64_t k, bool ring) {
     splits = (320 + p.nblocks - 1) / p.nblocks;
     if (k / splits > 2048) splits = std::min<int64_t>((k + 1791) / 1792, 16);
   }
-  const int64_t max_splits = std::max<int64_t>(1, k / 512);
+  const int64_t max_splits = max_splits_for(k, kchunks);
   splits = std::min(splits, max_splits);
   splits = std::max<int64_t>(splits, 1);
   if (g_force_splits > 0) splits = std::min<int64_t>(g_force_splits, max_splits);

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void mla_latent_norms_kernel(
     T* __restrict__ q_out, T* __restrict__ kv_out, T* __restrict__ pe_out, const T* __restrict__ x, int64_t x_stride,
     const float* __restrict__ part, int nsplit, int64_t split_stride, const float* __restrict__ part_xs,
     const float* __restrict__ part_ws, const T* __restrict__ wq, const T* __restrict__ wkv, int q_rank, int kv_rank,
-    int rope, float eps) {
+    int rope, float eps, uint8_t* __restrict__ q8_out, float* __restrict__ q8_scale) {
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
   const int seg = (int)blockIdx.y + (q_rank ? 0 : 1);
@@ -71,64 +71,100 @@ __global__ __launch_bounds__(256) void mla_latent_norms_kernel(
   }
   ss = block_sum(ss, red);
   const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  Vec<T, 8> o;
+  float amax = 0.f;
   if (t < nvec) {
-    Vec<T, 8> o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] = from_f32<T>((vals[j] * inv) * to_f32(wv.v[j]));
+    for (int j = 0; j < 8; ++j) {
+      o.v[j] = from_f32<T>((vals[j] * inv) * to_f32(wv.v[j]));
+      amax = fmaxf(amax, fabsf(to_f32(o.v[j])));
+    }
     stvec<T, 8>(orow + 8 * t, o);
+  }
+  if (q8_out && seg == 0) {
+    // per-token fp8 quantisation of the normalised q_a row, for an fp8 q_b_proj (the arithmetic of
+    // per_token_quant_fp8 on the stored 16-bit row)
+    amax = wave_max(amax);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = fmaxf(amax, 1e-10f) / 448.0f;
+    const float qinv = 1.0f / s;
+    if (t == 0) q8_scale[row] = s;
+    if (t < nvec) *reinterpret_cast<uint2*>(q8_out + row * hidden + 8 * t) = quant8_fp8<T>(o, qinv);
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // out[m, h, n] = sum_k a[m, h, k] * w_t[h, n, k]   (m < M <= 16 MT, k < K, n < N), 16-bit in, fp32 accumulate.
-// One wave per (16 output features, head): the weight rows are the MFMA's A operand and the activations its
-// B operand, so a lane ends with four consecutive features of one row -- one 8-byte store.  Operands come
-// straight from L2 (16-byte fragments); no LDS, no barrier.  Workgroup x == N / 16 (present when tail > 0)
-// copies a[m, h, K .. K + tail) behind the N outputs of each (m, h).
+// One workgroup per (16 output features, head): the weight rows are the MFMA's A operand and the activations
+// its B operand, so a lane ends with four consecutive features of one row -- one 8-byte store.  Operands come
+// straight from L2 (16-byte fragments).  A long reduction is cut over the KW waves of the workgroup (each wave
+// has all its loads in flight at once instead of walking K in dependent rounds); the partial tiles meet in
+// LDS and are summed in wave order, wave w finishing row tiles w, w + KW, ...  Workgroup x == N / 16
+// (present when tail > 0) copies a[m, h, K .. K + tail) behind the N outputs of each (m, h).
 // ------------------------------------------------------------------------------------------
-template <typename T, int MT>
-__global__ __launch_bounds__(64) void mla_absorb_kernel(T* __restrict__ out, const T* __restrict__ a,
-                                                        const T* __restrict__ w_t, int M, int N, int K, int tail,
-                                                        int64_t a_row_stride, int64_t a_head_stride,
-                                                        int64_t out_row_stride, int64_t out_head_stride) {
+template <typename T, int MT, int KW>
+__global__ __launch_bounds__(64 * KW) void mla_absorb_kernel(T* __restrict__ out, const T* __restrict__ a,
+                                                             const T* __restrict__ w_t, int M, int N, int K, int tail,
+                                                             int64_t a_row_stride, int64_t a_head_stride,
+                                                             int64_t out_row_stride, int64_t out_head_stride) {
   using frag = typename Mfma<T>::frag;
-  const int h = blockIdx.y, nt = blockIdx.x, l = threadIdx.x;
+  __shared__ f32x4 red[KW > 1 ? KW * MT * 64 : 1];
+  const int h = blockIdx.y, nt = blockIdx.x, l = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* ah = a + (int64_t)h * a_head_stride;
   T* oh = out + (int64_t)h * out_head_stride;
   if (nt * 16 >= N) {
     const int per = tail / 8;
-    for (int idx = l; idx < M * per; idx += 64) {
+    for (int idx = threadIdx.x; idx < M * per; idx += 64 * KW) {
       const int m = idx / per, c = idx - m * per;
       stvec<T, 8>(oh + m * out_row_stride + N + 8 * c, ldvec<T, 8>(ah + m * a_row_stride + K + 8 * c));
     }
     return;
   }
   const int i = l & 15, g = l >> 4;
-  const T* wrow = w_t + ((int64_t)h * N + nt * 16 + i) * K + 8 * g;
+  const int kw = K / KW, kbeg = wave * kw;
+  const T* wrow = w_t + ((int64_t)h * N + nt * 16 + i) * K + kbeg + 8 * g;
   const T* arow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mt * 16 + i;
-    arow[mt] = ah + (int64_t)(m < M ? m : M - 1) * a_row_stride + 8 * g;   // rows past M: computed, never stored
+    arow[mt] = ah + (int64_t)(m < M ? m : M - 1) * a_row_stride + kbeg + 8 * g;   // rows past M: computed, never stored
   }
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-  for (int k0 = 0; k0 < K; k0 += 32) {
+  for (int k0 = 0; k0 < kw; k0 += 32) {
     const frag wf = *reinterpret_cast<const frag*>(wrow + k0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       acc[mt] = Mfma<T>::run(wf, *reinterpret_cast<const frag*>(arow[mt] + k0), acc[mt]);
   }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  auto store_tile = [&](int mt, const f32x4& v) {
     const int m = mt * 16 + i;
     if (m < M) {
       Vec<T, 4> o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o.v[r] = from_f32<T>(acc[mt][r]);
+      for (int r = 0; r < 4; ++r) o.v[r] = from_f32<T>(v[r]);
       stvec<T, 4>(oh + m * out_row_stride + nt * 16 + 4 * g, o);
+    }
+  };
+  if constexpr (KW == 1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) store_tile(mt, acc[mt]);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + l] = acc[mt];
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (mt % KW != wave) continue;
+      f32x4 v = red[mt * 64 + l];
+#pragma unroll
+      for (int w = 1; w < KW; ++w) v += red[(w * MT + mt) * 64 + l];
+      store_tile(mt, v);
     }
   }
 }
@@ -136,14 +172,23 @@ __global__ __launch_bounds__(64) void mla_absorb_kernel(T* __restrict__ out, con
 template <typename T>
 static void launch_absorb(void* out, const void* a, const void* w_t, int m, int heads, int n, int k, int tail,
                           int64_t ars, int64_t ahs, int64_t ors, int64_t ohs, hipStream_t st) {
-  const dim3 grid((unsigned)(n / 16 + (tail ? 1 : 0)), (unsigned)heads), block(64);
-#define LAUNCH(MT_)                                                                                               \
-  hipLaunchKernelGGL((mla_absorb_kernel<T, MT_>), grid, block, 0, st, (T*)out, (const T*)a, (const T*)w_t, m, n, k, \
-                     tail, ars, ahs, ors, ohs)
-  if (m <= 16) LAUNCH(1);
-  else if (m <= 32) LAUNCH(2);
-  else if (m <= 48) LAUNCH(3);
-  else LAUNCH(4);
+  const dim3 grid((unsigned)(n / 16 + (tail ? 1 : 0)), (unsigned)heads);
+  // every wave of a workgroup reduces at least 128 features (four MFMA steps in flight together)
+  const int kw = k % 512 == 0 ? 4 : (k % 256 == 0 ? 2 : 1);
+#define LAUNCH(MT_, KW_)                                                                                        \
+  hipLaunchKernelGGL((mla_absorb_kernel<T, MT_, KW_>), grid, dim3(64 * KW_), 0, st, (T*)out, (const T*)a,       \
+                     (const T*)w_t, m, n, k, tail, ars, ahs, ors, ohs)
+#define LAUNCH_MT(KW_)             \
+  do {                             \
+    if (m <= 16) LAUNCH(1, KW_);   \
+    else if (m <= 32) LAUNCH(2, KW_); \
+    else if (m <= 48) LAUNCH(3, KW_); \
+    else LAUNCH(4, KW_);           \
+  } while (0)
+  if (kw == 4) LAUNCH_MT(4);
+  else if (kw == 2) LAUNCH_MT(2);
+  else LAUNCH_MT(1);
+#undef LAUNCH_MT
 #undef LAUNCH
 }
 
@@ -155,13 +200,16 @@ extern "C" {
 
 int mi355_mla_latent_norms(void* q_out, void* kv_out, void* pe_out, const void* x, int64_t x_row_stride,
                            const float* part, int nsplit, const float* part_x_scale, const float* part_w_scale,
-                           const void* q_weight, const void* kv_weight, int64_t rows, int q_rank, int kv_rank,
-                           int rope_dim, float eps, int dtype, void* stream) {
+                           const void* q_weight, const void* kv_weight, uint8_t* q_fp8_out, float* q_fp8_scale,
+                           int64_t rows, int q_rank, int kv_rank, int rope_dim, float eps, int dtype, void* stream) {
   MI355_REQUIRE(kv_out && pe_out && kv_weight && (x || part) && !(x && part), MI355_ERR_INVALID,
                 "mla_latent_norms: null pointer (exactly one of x and part is given)");
   MI355_REQUIRE((q_rank == 0) == (q_out == nullptr) && (q_rank == 0) == (q_weight == nullptr), MI355_ERR_INVALID,
                 "mla_latent_norms: q_out and q_weight go with q_rank > 0");
   MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "mla_latent_norms: only 16-bit dtypes");
+  MI355_REQUIRE((q_fp8_out == nullptr) == (q_fp8_scale == nullptr) && (!q_fp8_out || q_rank > 0) &&
+                    (reinterpret_cast<uintptr_t>(q_fp8_out) & 7) == 0,
+                MI355_ERR_INVALID, "mla_latent_norms: q_fp8_out and q_fp8_scale come together, 8-byte aligned, with q_rank > 0");
   MI355_REQUIRE(rows >= 0 && q_rank >= 0 && kv_rank > 0 && rope_dim > 0 && q_rank % 8 == 0 && kv_rank % 8 == 0 &&
                     rope_dim % 8 == 0 && q_rank <= 2048 && kv_rank + rope_dim <= 2048,
                 MI355_ERR_UNSUPPORTED,
@@ -182,7 +230,7 @@ int mi355_mla_latent_norms(void* q_out, void* kv_out, void* pe_out, const void* 
 #define LAUNCH(T)                                                                                                   \
   hipLaunchKernelGGL((mla_latent_norms_kernel<T>), grid, block, 0, (hipStream_t)stream, (T*)q_out, (T*)kv_out,      \
                      (T*)pe_out, (const T*)x, x_row_stride, part, nsplit, rows * width, part_x_scale, part_w_scale, \
-                     (const T*)q_weight, (const T*)kv_weight, q_rank, kv_rank, rope_dim, eps)
+                     (const T*)q_weight, (const T*)kv_weight, q_rank, kv_rank, rope_dim, eps, q_fp8_out, q_fp8_scale)
   if (dtype == MI355_BF16) LAUNCH(bf16_t);
   else LAUNCH(f16_t);
 #undef LAUNCH

@@ -21,11 +21,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(uint8_t* __restrict__ xq,
                                                                   float* __restrict__ scales,
                                                                   const T* __restrict__ x, int64_t k,
-                                                                  int64_t x_stride) {
+                                                                  int64_t x_stride, int64_t q_stride) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const T* xr = x + row * x_stride;
-  uint8_t* qr = xq + row * k;
+  uint8_t* qr = xq + row * q_stride;
+  for (int64_t i = k + threadIdx.x; i < q_stride; i += 256) qr[i] = 0;   // padding behind the row
   float amax = 0.f;
   for (int64_t i = threadIdx.x; i < k; i += 256) amax = fmaxf(amax, fabsf(to_f32(xr[i])));
   amax = wave_max(amax);
@@ -52,13 +53,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void per_token_quant_fp8_vec_kernel(uint8_t* __restrict__ xq,
                                                                       float* __restrict__ scales,
                                                                       const T* __restrict__ x, int64_t k,
-                                                                      int64_t x_stride) {
+                                                                      int64_t x_stride, int64_t q_stride) {
   constexpr int MAXV = 8;
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const T* xr = x + row * x_stride;
-  uint8_t* qr = xq + row * k;
+  uint8_t* qr = xq + row * q_stride;
   const int nvec = (int)(k >> 3);
+  for (int idx = nvec + threadIdx.x; idx < (int)(q_stride >> 3); idx += 256)   // padding behind the row
+    *reinterpret_cast<uint2*>(qr + (int64_t)idx * 8) = uint2{0u, 0u};
   Vec<T, 8> v[MAXV];
   float amax = 0.f;
 #pragma unroll
@@ -298,20 +301,20 @@ using namespace mi355;
 extern "C" {
 
 int mi355_per_token_quant_fp8(uint8_t* xq, float* scales, const void* x, int64_t rows, int64_t k,
-                              int64_t x_stride, int dtype, void* stream) {
+                              int64_t x_stride, int64_t q_stride, int dtype, void* stream) {
   MI355_REQUIRE(xq && scales && x, MI355_ERR_INVALID, "per_token_quant_fp8: null pointer");
-  MI355_REQUIRE(rows >= 0 && k > 0 && x_stride >= k, MI355_ERR_INVALID,
+  MI355_REQUIRE(rows >= 0 && k > 0 && x_stride >= k && q_stride >= k, MI355_ERR_INVALID,
                 "per_token_quant_fp8: bad shape");
   if (rows == 0) return MI355_OK;
-  const bool vec = dtype != MI355_F32 && k % 8 == 0 && k <= 16384 && x_stride % 8 == 0 && aligned16(x) &&
-                   (reinterpret_cast<uintptr_t>(xq) & 7) == 0;
+  const bool vec = dtype != MI355_F32 && k % 8 == 0 && k <= 16384 && x_stride % 8 == 0 && q_stride % 8 == 0 &&
+                   aligned16(x) && (reinterpret_cast<uintptr_t>(xq) & 7) == 0;
   MI355_DISPATCH_DTYPE(dtype, "per_token_quant_fp8", {
     if (vec)
       hipLaunchKernelGGL((per_token_quant_fp8_vec_kernel<T>), dim3((unsigned)rows), dim3(256), 0,
-                         (hipStream_t)stream, xq, scales, (const T*)x, k, x_stride);
+                         (hipStream_t)stream, xq, scales, (const T*)x, k, x_stride, q_stride);
     else
       hipLaunchKernelGGL((per_token_quant_fp8_kernel<T>), dim3((unsigned)rows), dim3(256), 0,
-                         (hipStream_t)stream, xq, scales, (const T*)x, k, x_stride);
+                         (hipStream_t)stream, xq, scales, (const T*)x, k, x_stride, q_stride);
   });
   MI355_CHECK_LAUNCH("per_token_quant_fp8");
   return MI355_OK;

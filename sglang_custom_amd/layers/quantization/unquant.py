@@ -146,7 +146,9 @@ def decode_linear_deferred(layer, x, needs_all_reduce: bool = True):
         if isinstance(x, QuantizedAct):
             xq, xs = x.xq, x.x_scale
         else:
-            xq, xs = ops.per_token_quant_fp8(x)
+            xq, xs = ops.per_token_quant_fp8(x, pad_to=layer.k_padded)
+        if xq.shape[1] != layer.k_padded:
+            return None
         part = ops.fp8_packed_partials(xq, wp, n)
         return None if part is None else SplitKPartials(part, xs, layer.weight_scale.data)
     if (isinstance(x, QuantizedAct) or not isinstance(layer.quant_method, UnquantizedLinearMethod)

@@ -87,10 +87,21 @@ class W8A8Fp8LinearMethod:
             layer.weight_scale = torch.nn.Parameter(s.contiguous(), requires_grad=False)
         # decode copy in the weight-streaming kernel's fragment order (the row-major one stays for
         # the large-M library GEMM)
+        # A reduction length the kernel does not stream (K % 512 != 0: DeepSeek-V3's down_proj shard, 18432 / 8 =
+        # 2304) is rounded up with zero weights; the activation quantisers write the matching zero tail
+        # (k_padded is the row length the packed GEMM expects of xq).
         w = layer.weight
         layer.weight_packed = None
-        if w.is_cuda and w.shape[1] % 512 == 0 and w.shape[0] < 65536:
+        n, k = w.shape
+        layer.k_padded = k
+        if w.is_cuda and k % 16 == 0 and n < 65536:
+            kp = -(-k // 512) * 512
+            if kp != k:
+                wp = torch.zeros((n, kp), dtype=torch.uint8, device=w.device)
+                wp[:, :k] = w.data.view(torch.uint8)
+                w = wp.view(FP8_DTYPE)
             layer.weight_packed = get_ops().pack_weight_fp8(w.data)
+            layer.k_padded = kp
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         from .unquant import QuantizedAct
@@ -100,10 +111,16 @@ class W8A8Fp8LinearMethod:
             xq, xs = x.xq, x.x_scale
             out_dtype = x.dtype
             wp = getattr(layer, "weight_packed", None)
-            if wp is not None and xq.shape[0] <= SKINNY_MAX_M:
+            if wp is not None and xq.shape[0] <= SKINNY_MAX_M and xq.shape[1] == layer.k_padded:
                 return ops.fp8_scaled_mm_packed(xq, wp, layer.weight.shape[0], xs, layer.weight_scale, out_dtype, bias)
+            assert xq.shape[1] == layer.weight.shape[1], "a padded activation is for the packed decode GEMM only"
             return ops.fp8_scaled_mm(xq, layer.weight, xs, layer.weight_scale, out_dtype, bias)
         x2 = x.view(-1, x.shape[-1])
+        wp = getattr(layer, "weight_packed", None)
+        if wp is not None and x2.shape[0] <= SKINNY_MAX_M and x2.is_cuda:   # decode: the packed kernel (K padded if need be)
+            xq, xs = ops.per_token_quant_fp8(x2, pad_to=layer.k_padded)
+            y = ops.fp8_scaled_mm_packed(xq, wp, layer.weight.shape[0], xs, layer.weight_scale, x.dtype, bias)
+            return y.view(*x.shape[:-1], y.shape[-1])
         xq, xs = ops.per_token_quant_fp8(x2)
         y = None
         if (PREFILL_GEMM != "library" and x2.shape[0] > SKINNY_MAX_M and x2.is_cuda
@@ -112,9 +129,6 @@ class W8A8Fp8LinearMethod:
         if (y is None and x2.shape[0] > SKINNY_MAX_M and x2.is_cuda and x2.shape[1] % 16 == 0
                 and layer.weight.shape[0] % 16 == 0):
             y = _library_scaled_mm(xq, layer.weight, xs, layer.weight_scale, x.dtype, bias)
-        wp = getattr(layer, "weight_packed", None)
-        if y is None and wp is not None and x2.shape[0] <= SKINNY_MAX_M:
-            y = ops.fp8_scaled_mm_packed(xq, wp, layer.weight.shape[0], xs, layer.weight_scale, x.dtype, bias)
         if y is None:
             y = ops.fp8_scaled_mm(xq, layer.weight, xs, layer.weight_scale, x.dtype, bias)
         return y.view(*x.shape[:-1], y.shape[-1])

@@ -29,12 +29,17 @@ from ..layers.layernorm import RMSNorm
 from ..distributed.parallel_state import get_tensor_model_parallel_world_size
 from ..layers.linear import MergedColumnParallelLinear, ReplicatedLinear, RowParallelLinear
 from ..layers.logits_processor import LogitsProcessor
-from ..layers.quantization.unquant import UnquantizedLinearMethod, decode_linear_deferred, pack_gate_up_for_decode
+from ..layers.quantization.unquant import (
+    QuantizedAct,
+    UnquantizedLinearMethod,
+    decode_linear_deferred,
+    pack_gate_up_for_decode,
+)
 from ..layers.radix_attention import RadixAttention
 from ..ops_backend import get_ops
 from ..layers.rotary_embedding import get_rope, yarn_get_mscale
 from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
-from .llama import LlamaMLP, wants_fp8_input
+from .llama import LlamaMLP, takes_fp8_rows_of_k
 
 
 class DeepseekV2AttentionMLA(nn.Module):
@@ -178,7 +183,7 @@ class DeepseekV2AttentionMLA(nn.Module):
         copies and two norms.  Returns (q [T, H, nope + rope], normed c_kv [T, rank], k_pe [T, rope] unrotated),
         or None when the shape or the ops backend does not serve it."""
         ops = get_ops()
-        x = hidden_states
+        x = hidden_states.dense if isinstance(hidden_states, QuantizedAct) else hidden_states   # (the norm's 16-bit rows)
         rank, rope = self.kv_lora_rank, self.qk_rope_head_dim
         q_rank = self.q_lora_rank or 0
         if (x.dim() != 2 or not x.is_cuda or x.shape[0] > 64
@@ -187,13 +192,15 @@ class DeepseekV2AttentionMLA(nn.Module):
         proj = self.fused_qkv_a_proj_with_mqa if q_rank else self.kv_a_proj_with_mqa
         qw = self.q_a_layernorm.weight.data if q_rank else None
         kvw, eps = self.kv_a_layernorm.weight.data, self.kv_a_layernorm.variance_epsilon
-        part = decode_linear_deferred(proj, x, needs_all_reduce=False)
-        if part is not None:
-            q, c_kv, k_pe = ops.mla_latent_norms(qw, kvw, q_rank, rank, rope, eps, part=part.part,
-                                                 part_x_scale=part.x_scale, part_w_scale=part.w_scale)
-        else:
-            q, c_kv, k_pe = ops.mla_latent_norms(qw, kvw, q_rank, rank, rope, eps, x=proj(x)[0])
-        q = self.q_b_proj(q)[0] if q_rank else self.q_proj(x)[0]
+        q8 = bool(q_rank) and takes_fp8_rows_of_k(self.q_b_proj, x.shape[0])   # the launch also quantises q_a for an fp8 q_b_proj
+        part = decode_linear_deferred(proj, hidden_states, needs_all_reduce=False)
+        src = (dict(part=part.part, part_x_scale=part.x_scale, part_w_scale=part.w_scale) if part is not None
+               else dict(x=proj(hidden_states)[0]))
+        out = ops.mla_latent_norms(qw, kvw, q_rank, rank, rope, eps, quant_q_fp8=q8, **src)
+        q, c_kv, k_pe = out[:3]
+        if q8:
+            q = QuantizedAct(out[3], out[4], q.dtype, q)
+        q = self.q_b_proj(q)[0] if q_rank else self.q_proj(hidden_states)[0]
         return q.view(-1, self.num_local_heads, self.qk_head_dim), c_kv, k_pe
 
     def _absorb_q(self, q):
@@ -280,13 +287,21 @@ class DeepseekV2DecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, positions, hidden_states, forward_batch, residual):
+        at = self.self_attn
+        proj_a = at.fused_qkv_a_proj_with_mqa if at.q_lora_rank is not None else None
+        # decode with an fp8 "a" projection: the norm also quantises its rows (a model without q_lora feeds the
+        # same rows to two projections and keeps the 16-bit tensor)
+        q_in = (proj_a is not None and forward_batch.forward_mode.is_decode()
+                and takes_fp8_rows_of_k(proj_a, hidden_states.shape[0]))
         if residual is None:
             residual = hidden_states
-            hidden_states = self.input_layernorm(hidden_states)
+            hidden_states = self.input_layernorm(hidden_states, quant_fp8=True) if q_in else self.input_layernorm(hidden_states)
+        elif q_in:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual, quant_fp8=True)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions, hidden_states, forward_batch)
-        if wants_fp8_input(self.mlp.gate_up_proj, hidden_states.shape[0]):   # the norm also quantises for the fp8 GEMM
+        if takes_fp8_rows_of_k(self.mlp.gate_up_proj, hidden_states.shape[0]):   # the norm also quantises for the fp8 GEMM
             hidden_states, residual = self.post_attention_layernorm(hidden_states, residual, quant_fp8=True)
         else:
             hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)

@@ -59,7 +59,7 @@ class LlamaMLP(nn.Module):
             gate_up, _ = self.gate_up_proj(x)
             if wants_fp8_input(self.down_proj, gate_up.shape[0]) and gate_up.dim() == 2:
                 # SiLU-mul and the down projection's per-token quantisation in one launch
-                xq, xs = get_ops().silu_and_mul_quant_fp8(gate_up)
+                xq, xs = get_ops().silu_and_mul_quant_fp8(gate_up, pad_to=self.down_proj.k_padded)
                 x = QuantizedAct(xq, xs, gate_up.dtype)
             else:
                 x = self.act_fn(gate_up)
@@ -76,6 +76,11 @@ def wants_fp8_input(layer, m: int) -> bool:
     from ..layers.quantization import unquant
     return (unquant.DECODE_FUSION and isinstance(layer.quant_method, W8A8Fp8LinearMethod)
             and 1 <= m <= SKINNY_MAX_M and getattr(layer, "weight_packed", None) is not None)
+
+
+def takes_fp8_rows_of_k(layer, m: int) -> bool:
+    """wants_fp8_input for a producer that cannot pad its rows (the norms): the packed GEMM must stream exactly K."""
+    return wants_fp8_input(layer, m) and layer.k_padded == layer.weight.shape[1]
 
 
 class LlamaAttention(nn.Module):
@@ -192,8 +197,8 @@ class LlamaDecoderLayer(nn.Module):
     def forward(self, positions, hidden_states, forward_batch,
                 residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
         m = hidden_states.shape[0]
-        q_in = wants_fp8_input(self.self_attn.qkv_proj, m)      # norm also quantises for the fp8 GEMM behind it
-        q_mlp = wants_fp8_input(self.mlp.gate_up_proj, m)
+        q_in = takes_fp8_rows_of_k(self.self_attn.qkv_proj, m)      # norm also quantises for the fp8 GEMM behind it
+        q_mlp = takes_fp8_rows_of_k(self.mlp.gate_up_proj, m)
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states, quant_fp8=True) if q_in else self.input_layernorm(hidden_states)

@@ -486,11 +486,13 @@ def mla_latent_norms_supported(q_rank: int, kv_rank: int, rope_dim: int, dtype: 
 
 def mla_latent_norms(q_weight: Optional[torch.Tensor], kv_weight: torch.Tensor, q_rank: int, kv_rank: int, rope_dim: int,
                      eps: float, x: Optional[torch.Tensor] = None, part: Optional[torch.Tensor] = None,
-                     part_x_scale: Optional[torch.Tensor] = None, part_w_scale: Optional[torch.Tensor] = None):
+                     part_x_scale: Optional[torch.Tensor] = None, part_w_scale: Optional[torch.Tensor] = None,
+                     quant_q_fp8: bool = False):
     """q_a_layernorm and kv_a_layernorm over the two parts of fused_qkv_a_proj_with_mqa's output row
     [q_a | c_kv | k_pe] in one launch (deepseek_v2.py:1193-1232): from x [M, width] (row-strided view allowed) or
     from that GEMM's split-K partials [splits, M, width] (with the fp8 GEMM's scales when it was one).  Returns
-    (q_a normed [M, q_rank] or None when q_rank == 0, c_kv normed [M, kv_rank], k_pe [M, rope_dim]), all dense."""
+    (q_a normed [M, q_rank] or None when q_rank == 0, c_kv normed [M, kv_rank], k_pe [M, rope_dim]), all dense;
+    with quant_q_fp8 additionally (e4m3fn [M, q_rank], scale [M, 1]) = per_token_quant_fp8 of the normed q_a."""
     src = part if part is not None else x
     _gpu(src, q_weight, kv_weight)
     dt = kv_weight.dtype
@@ -509,12 +511,19 @@ def mla_latent_norms(q_weight: Optional[torch.Tensor], kv_weight: torch.Tensor, 
         q_out = torch.empty((rows, q_rank), dtype=dt, device=kv_weight.device)
     kv_out = torch.empty((rows, kv_rank), dtype=dt, device=kv_weight.device)
     pe_out = torch.empty((rows, rope_dim), dtype=dt, device=kv_weight.device)
+    q8 = s8 = None
+    if quant_q_fp8:
+        assert q_rank > 0
+        q8 = torch.empty((rows, q_rank), dtype=torch.float8_e4m3fn, device=kv_weight.device)
+        s8 = torch.empty((rows, 1), dtype=torch.float32, device=kv_weight.device)
     if rows:
         check(_lib_().mi355_mla_latent_norms(
             _p(q_out), kv_out.data_ptr(), pe_out.data_ptr(), _p(x), x.stride(0) if x is not None else 0, _p(part),
             part.shape[0] if part is not None else 0, _p(part_x_scale), _p(part_w_scale), _p(q_weight),
-            kv_weight.data_ptr(), rows, q_rank, kv_rank, rope_dim, float(eps), _dt(kv_weight), _stream(kv_weight)),
-            "mla_latent_norms")
+            kv_weight.data_ptr(), _p(q8), _p(s8), rows, q_rank, kv_rank, rope_dim, float(eps), _dt(kv_weight),
+            _stream(kv_weight)), "mla_latent_norms")
+    if quant_q_fp8:
+        return q_out, kv_out, pe_out, q8, s8
     return q_out, kv_out, pe_out
 
 
@@ -818,15 +827,17 @@ def rmsnorm_ex(weight: torch.Tensor, eps: float, x: Optional[torch.Tensor] = Non
     return out, xq, xs
 
 
-def silu_and_mul_quant_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """per_token_quant_fp8(silu_and_mul(x)) in one launch: x [M, 2d] 16-bit -> (e4m3fn [M, d], scale [M, 1])."""
+def silu_and_mul_quant_fp8(x: torch.Tensor, pad_to: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """per_token_quant_fp8(silu_and_mul(x)) in one launch: x [M, 2d] 16-bit -> (e4m3fn [M, d], scale [M, 1]);
+    pad_to > d: rows of pad_to bytes with zeros behind the d values (see per_token_quant_fp8)."""
     _gpu(x)
     assert x.dim() == 2 and x.is_contiguous() and x.shape[1] % 2 == 0
     m, d = x.shape[0], x.shape[1] // 2
-    xq = torch.empty((m, d), dtype=torch.float8_e4m3fn, device=x.device)
+    qs = max(d, pad_to or 0)
+    xq = torch.empty((m, qs), dtype=torch.float8_e4m3fn, device=x.device)
     xs = torch.empty((m, 1), dtype=torch.float32, device=x.device)
     if m:
-        check(_lib_().mi355_silu_and_mul_quant_fp8(xq.data_ptr(), xs.data_ptr(), x.data_ptr(), m, d, _dt(x),
+        check(_lib_().mi355_silu_and_mul_quant_fp8(xq.data_ptr(), xs.data_ptr(), x.data_ptr(), m, d, qs, _dt(x),
                                                    _stream(x)), "silu_and_mul_quant_fp8")
     return xq, xs
 
@@ -868,15 +879,18 @@ def linear_packed_silu_mul(x: torch.Tensor, weight_packed: torch.Tensor, n: int)
     return y
 
 
-def per_token_quant_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """per_token_group_quant_fp8(x, group_size=K) (fp8_kernel.py:115-155) -> (xq e4m3fn, scale [M,1])."""
+def per_token_quant_fp8(x: torch.Tensor, pad_to: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """per_token_group_quant_fp8(x, group_size=K) (fp8_kernel.py:115-155) -> (xq e4m3fn, scale [M,1]).
+    pad_to > K: xq is [M, pad_to] with zeros behind the K values of every row -- the activation of a packed GEMM
+    whose reduction length was rounded up with zero weights."""
     _gpu(x)
     assert x.dim() == 2 and x.stride(1) == 1
     M, K = x.shape
-    xq = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=x.device)
+    qs = max(K, pad_to or 0)
+    xq = torch.empty((M, qs), dtype=torch.float8_e4m3fn, device=x.device)
     s = torch.empty((M, 1), dtype=torch.float32, device=x.device)
     check(_lib_().mi355_per_token_quant_fp8(xq.data_ptr(), s.data_ptr(), x.data_ptr(), M, K,
-                                            x.stride(0), _dt(x), _stream(x)), "per_token_quant_fp8")
+                                            x.stride(0), qs, _dt(x), _stream(x)), "per_token_quant_fp8")
     return xq, s
 
 

@@ -589,6 +589,12 @@ def test_mla_latent_norms_is_split_plus_two_rmsnorms_bit_for_bit(dt, rows, q_ran
     ref_kv = ops_ref.rmsnorm(x[:, q_rank: q_rank + kv_rank].cpu(), kvw.cpu(), eps)
     torch.testing.assert_close(want[1].float().cpu(), ref_kv.float(), atol=2e-2, rtol=2e-2)
 
+    if q_rank:   # + the per-token fp8 quantisation of the normed q_a rows (an fp8 q_b_proj's input)
+        out5 = ops.mla_latent_norms(qw, kvw, q_rank, kv_rank, rope, eps, x=x, quant_q_fp8=True)
+        same(out5[:3], want)
+        q8, s8 = ops.per_token_quant_fp8(want[0])
+        assert torch.equal(out5[3].view(torch.uint8), q8.view(torch.uint8)) and torch.equal(out5[4], s8)
+
     # split-K partials: summed in split order, rounded once, then normalised
     part = torch.randn(3, rows, width, generator=g).to(DEV)
     summed = ((part[0] + part[1]) + part[2]).to(dt)

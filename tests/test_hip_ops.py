@@ -1078,3 +1078,62 @@ def test_final_logit_softcap(ops):
     assert torch.equal(outs[None], outs[-1.0])
     assert outs[None].abs().max().item() > 20.0           # the cap bites
     assert (outs[20.0] - ops_ref.softcap(outs[None], 20.0)).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("m,k", [(64, 2304), (3, 2304), (1, 64), (17, 1000)])
+def test_fp8_rows_padded_for_the_packed_gemm(ops, m, k):
+    """A reduction length the packed fp8 GEMM does not stream (K % 512 != 0, e.g. DeepSeek-V3's down_proj shard
+    of 2304) is rounded up: the quantisers write rows of k_padded bytes with zeros behind the K codes, the weight
+    is packed with zero columns -- same codes, same scales, and the GEMM equals the unpadded row-major kernel."""
+    from sglang_custom_amd.layers.quantization.w8a8_fp8 import quantize_weight_per_channel
+    g = torch.Generator().manual_seed(m * 1000 + k)
+    kp = -(-k // 512) * 512
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    q0, s0 = ops.per_token_quant_fp8(x)
+    q1, s1 = ops.per_token_quant_fp8(x, pad_to=kp)
+    assert q1.shape == (m, kp) and torch.equal(s0, s1)
+    assert torch.equal(q1[:, :k].view(torch.uint8), q0.view(torch.uint8)) and not q1[:, k:].view(torch.uint8).any()
+    if k % 8 == 0:
+        gu = torch.randn(m, 2 * k, generator=g).to(torch.bfloat16).to(DEV)
+        a0, t0 = ops.silu_and_mul_quant_fp8(gu)
+        a1, t1 = ops.silu_and_mul_quant_fp8(gu, pad_to=kp)
+        assert a1.shape == (m, kp) and torch.equal(t0, t1)
+        assert torch.equal(a1[:, :k].view(torch.uint8), a0.view(torch.uint8)) and not a1[:, k:].view(torch.uint8).any()
+    if k % 16 == 0:
+        n = 256
+        wq, ws = quantize_weight_per_channel(torch.randn(n, k, generator=g) * k ** -0.5)
+        wq, ws = wq.to(DEV), ws.to(DEV)
+        wpad = torch.zeros(n, kp, dtype=torch.uint8, device=DEV)
+        wpad[:, :k] = wq.view(torch.uint8)
+        got = ops.fp8_scaled_mm_packed(q1, ops.pack_weight_fp8(wpad.view(torch.float8_e4m3fn)), n, s1, ws, torch.bfloat16)
+        base = ops.fp8_scaled_mm(q0, wq, s0, ws, torch.bfloat16)
+        assert maxdiff(got, base) <= 2e-2 * base.float().abs().max().item()
+        assert maxdiff(got, ops_ref.fp8_linear(x.cpu(), wq.cpu(), ws.cpu())) <= 1e-2 * max(1.0, base.float().abs().max().item())
+
+
+def test_fp8_linear_method_pads_odd_reduction_lengths(ops):
+    """W8A8Fp8LinearMethod on a [N, 2304] weight: the decode path runs the packed kernel on K rounded up to 2560
+    (from a tensor and from a producer's QuantizedAct) and equals the oracle's apply_fp8_linear."""
+    from types import SimpleNamespace
+    from sglang_custom_amd.layers.quantization.unquant import QuantizedAct, decode_linear_deferred
+    from sglang_custom_amd.layers.quantization.w8a8_fp8 import W8A8Fp8LinearMethod
+    g = torch.Generator().manual_seed(5)
+    n, k, m = 512, 2304, 48
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    qm = W8A8Fp8LinearMethod()
+    layer = SimpleNamespace(weight=torch.nn.Parameter(w.to(DEV), requires_grad=False), quant_method=qm, tp_size=1)
+    qm.process_weights_after_loading(layer)
+    assert layer.k_padded == 2560 and layer.weight_packed is not None and layer.weight.shape == (n, k)
+    ref = ops_ref.fp8_linear(x, layer.weight.data.cpu(), layer.weight_scale.data.cpu())
+    y = qm.apply(layer, x.to(DEV))
+    assert maxdiff(y, ref) <= 1e-2
+    gu = torch.randn(m, 2 * k, generator=g).to(torch.bfloat16).to(DEV)
+    aq, asc = ops.silu_and_mul_quant_fp8(gu, pad_to=layer.k_padded)
+    y2 = qm.apply(layer, QuantizedAct(aq, asc, torch.bfloat16))
+    ref2 = ops_ref.fp8_linear(ops_ref.silu_and_mul(gu.cpu()), layer.weight.data.cpu(), layer.weight_scale.data.cpu())
+    assert maxdiff(y2, ref2) <= 1e-2
+    part = decode_linear_deferred(layer, x.to(DEV))
+    assert part is not None
+    summed = ((part.part.sum(0) * part.x_scale) * part.w_scale.view(1, -1)).to(torch.bfloat16)
+    assert maxdiff(summed, ref) <= 1e-2
