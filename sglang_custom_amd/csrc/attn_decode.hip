@@ -1794,6 +1794,249 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// MLA decode over an fp8 (e4m3fn) latent cache through an LDS ring: rows of 576 BYTES land in LDS as they
+// are (global_load_lds_dwordx4) and are widened to T exactly when a fragment is used (one
+// v_cvt_scalef32_pk_*_fp8 per two values, scale 1: every e4m3 value is a value of T).
+// A step is 32 keys.  LDS image of a step: row r at 592 r (+ 128 for r >= 16): 576 bytes + 16 of padding, so
+// the score reads (ds_read_b64, 16 rows x 8 bytes) and the transposed value reads (ds_read_b64_tr_b8, rows
+// r .. r + 3 and r + 16 .. r + 19 per 16 lanes) are conflict-free.  Wave w fetches rows 8 w .. 8 w + 7 of a
+// step as five wave-wide loads over the 296 sixteen-byte pieces of its 4736-byte region (a lane's piece never
+// crosses a row; the 37th piece of a row is padding and its lane stays idle).
+// The scores are NOT computed four times: wave w takes tile w >> 1 (16 keys) and half w & 1 of the 18 feature
+// steps, the four partial tiles meet in LDS (one more barrier per step) and every wave adds the two halves
+// of both tiles in the same order -- identical softmax statistics in all waves, as in the 16-bit ring kernel,
+// at a quarter of its score work and LDS traffic, which is what the conversion instructions need to fit.
+// P.V: 16x16x32 steps whose 32 key slots are {4 c + j, 16 + 4 c + j} for lane group c -- the order the score
+// accumulators hold them in -- with the value fragment read transposed from the rows of exactly those keys.
+// grid (ceil(hq / 16), num_splits, B), block 256; NSB step buffers (NSB - 1 steps in flight).
+// ------------------------------------------------------------------------------------------
+constexpr int M8_ROWB = 592;                          // bytes between rows of a step image
+constexpr int M8_SHIFT = 128;                         // rows 16 .. 31 sit 32 banks further
+constexpr int M8_STEP = 32 * M8_ROWB + M8_SHIFT;      // 19072
+constexpr int M8_XCH = 2 * 4 * 64 * 16;               // partial scores: two parities x four waves x 1 KiB
+constexpr int m8_lds_bytes(int nsb) { return nsb * M8_STEP + M8_XCH; }
+__device__ __forceinline__ constexpr int m8_row(int r) { return r * M8_ROWB + (r >= 16 ? M8_SHIFT : 0); }
+
+template <typename T> struct Fp8Widen;
+template <> struct Fp8Widen<bf16_t> {
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ v2 run(int w, bool hi) {
+    return hi ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true) : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false);
+  }
+};
+template <> struct Fp8Widen<f16_t> {
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ v2 run(int w, bool hi) {
+    return hi ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true) : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false);
+  }
+};
+// eight e4m3fn bytes -> one MFMA fragment of eight T (exact)
+template <typename T> __device__ __forceinline__ typename Mfma<T>::frag widen8(uint2 raw) {
+  typedef typename Fp8Widen<T>::v2 v2;
+  struct alignas(16) Quad { v2 a, b, c, d; };
+  const Quad q{Fp8Widen<T>::run((int)raw.x, false), Fp8Widen<T>::run((int)raw.x, true),
+               Fp8Widen<T>::run((int)raw.y, false), Fp8Widen<T>::run((int)raw.y, true)};
+  return __builtin_bit_cast(typename Mfma<T>::frag, q);
+}
+
+template <typename T, bool CAP, int NSB>
+__global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
+    const T* __restrict__ q, const uint8_t* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p) {
+  constexpr int NH = MLA_D / 64;   // 9 of the 18 score k-steps per wave
+  using frag = typename Mfma<T>::frag;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  constexpr int P = NSB - 1;       // steps requested ahead of the one being computed
+  static_assert(P >= 1 && P <= 3, "the wait below knows 0, 5, 10 or 15 younger loads");
+  static_assert(MLA_D == 576 && MLA_RANK == 512, "the step image is laid out for 512 + 64 byte rows");
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // m8_lds_bytes(NSB)
+
+  const int head0 = blockIdx.x * 16, split = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, c4 = lane >> 4;
+  const int tile = wave >> 1, half = wave & 1;
+
+  int64_t page_off, len;
+  seq_range(p, b, page_off, len);
+  const int64_t chunk = split_chunk(p, len);
+  const int64_t k0 = (int64_t)split * chunk;
+  const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
+  const int n_steps = k1 > k0 ? (int)((k1 - k0 + 31) / 32) : 0;
+  const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  // page-table reads through the scalar unit (wave-uniform index, read-only data)
+  const int32_t __attribute__((address_space(4)))* pt =
+      (const int32_t __attribute__((address_space(4)))*)(p.page_table + page_off);
+  const int64_t last_key = len - 1;
+  struct Slots { int32_t s[8]; };   // rows 8 wave .. + 7 of a step
+  auto slots_of = [&](int step) -> Slots {
+    const int64_t key = k0 + (int64_t)step * 32 + 8 * wave;
+    Slots sl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sl.s[j] = pt[key + j < last_key ? key + j : last_key];
+    return sl;
+  };
+  const unsigned ring = lds_byte_address(sm_raw);
+  // load i (0 .. 4) of a step: this lane's piece 64 i + lane of the wave's region = (row, 16-byte chunk)
+  int pj[5], poff[5];
+  bool pact[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int g = 64 * i + lane;
+    const int j = g / 37, c = g - 37 * j;
+    pact[i] = g < 296 && c < 36;
+    pj[i] = j - (64 * i) / 37;   // 0 .. 2: which of the (at most three) rows this load touches
+    poff[i] = 16 * (c < 36 ? c : 0);
+  }
+  auto issue_step = [&](int step, const Slots& sl) {
+    const unsigned base = ring + (unsigned)(step % NSB) * M8_STEP + (unsigned)m8_row(8 * wave);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      constexpr int JB[5] = {0, 1, 3, 5, 6};
+      const int jb = JB[i];
+      const int32_t sa = sl.s[jb], sb = sl.s[jb + 1 < 8 ? jb + 1 : 7], sc = sl.s[jb + 2 < 8 ? jb + 2 : 7];
+      const uint32_t slot = (uint32_t)(pj[i] == 0 ? sa : (pj[i] == 1 ? sb : sc));
+      if (pact[i])
+        load_to_lds_16_v<true>(kvbuf + (uint64_t)slot * MLA_D + poff[i], base + 1024u * i);
+    }
+  };
+
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // read addresses inside a step image (bytes)
+  const int k_rd = m8_row(16 * tile + r16) + 32 * NH * half + 8 * c4;   // + 32 s'
+  // value fragment of lane (group c4, column r16): lane 2 q + pp supplies row q, columns 8 pp .. + 7 of its group's
+  // eight keys {4 c4 + (q & 3) + 16 (q >> 2)}
+  const int vq = r16 >> 1;
+  const int v_rd = m8_row(4 * c4 + (vq & 3) + 16 * (vq >> 2)) + 128 * wave + 8 * (r16 & 1);   // + 16 dt
+  char* xch = sm_raw + NSB * M8_STEP;
+
+  Slots s_nxt{};
+  if (n_steps > 0) {   // (an empty sequence has no page-table entry to read)
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      s_nxt = slots_of(i);   // clamped to the last key when past the end
+      if (i < n_steps) issue_step(i, s_nxt);
+    }
+    s_nxt = slots_of(P);
+  }
+
+  // B operand of this wave's score steps: head r16, features 32 (9 half + s') + 8 c4 .. + 7 (fetched after the
+  // first tiles were requested and waited for before the loop, as in the 16-bit kernel)
+  frag qf[NH];
+  {
+    const int hq_c = head0 + r16 < p.hq ? head0 + r16 : p.hq - 1;   // rows of heads past hq are computed and dropped
+    const T* qp = q + (int64_t)b * p.q_stride + (int64_t)hq_c * MLA_D + 32 * NH * half + 8 * c4;
+#pragma unroll
+    for (int s = 0; s < NH; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 32 * s);
+#pragma unroll
+    for (int s = 0; s < NH; ++s) asm volatile("" ::"v"(qf[s]));
+  }
+
+  for (int t = 0; t < n_steps; ++t) {
+    // this wave's part of step t has landed when at most the loads (5 per step) of the younger steps are out
+    const int younger = min(P - 1, n_steps - 1 - t);
+    if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its reads of step t - 1 have returned
+    __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's image is free
+    if (t + P < n_steps) issue_step(t + P, s_nxt);
+    s_nxt = slots_of(t + P + 1);
+    const char* img = sm_raw + (t % NSB) * M8_STEP;
+
+    // this wave's partial scores: 16 keys of its tile x 16 heads over its nine feature steps
+    uint2 kraw[NH];
+#pragma unroll
+    for (int s = 0; s < NH; ++s) kraw[s] = *reinterpret_cast<const uint2*>(img + k_rd + 32 * s);
+    f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NH; ++s) part = Mfma<T>::run(widen8<T>(kraw[s]), qf[s], part);
+    f32x4* xw = reinterpret_cast<f32x4*>(xch + (t & 1) * 4096);
+    xw[wave * 64 + lane] = part;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const f32x4 sa = xw[lane] + xw[64 + lane], sb = xw[128 + lane] + xw[192 + lane];
+
+    const int64_t kb0 = k0 + (int64_t)t * 32 + 4 * c4;
+    float x[8], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float v = (r < 4 ? sa[r & 3] : sb[r & 3]) * qmul;
+      if (CAP) v = p.logit_cap * tanhf(v / p.logit_cap) * kLog2e;
+      x[r] = kb0 + (r & 3) + 16 * (r >> 2) < k1 ? v : -INFINITY;
+      mx = fmaxf(mx, x[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // lazy rescale: the reference point moves only when a step's maximum exceeds it by 2^8
+    const bool need = mx > m + 8.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+      const float mnew = need ? mx : m;
+      const float alpha = exp2f(m - safe_m(mnew));
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) acc[dt] *= alpha;
+      m = mnew;
+    }
+    const float ms = safe_m(m);
+    float psum = 0.f;
+    Vec<T, 8> p8;   // key slots 8 c4 + j of the P.V step: keys 4 c4 + j (j < 4), 16 + 4 c4 + j - 4 (j >= 4)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float pe = exp2f(x[r] - ms);
+      psum += pe;
+      p8.v[r] = from_f32<T>(pe);
+    }
+    l += psum;
+    const frag pf = __builtin_bit_cast(frag, p8);
+    i32x2 vraw[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      vraw[dt] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((i32x2 __attribute__((address_space(3)))*)(img + v_rd + 16 * dt));
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      acc[dt] = Mfma<T>::run(widen8<T>(uint2{(unsigned)vraw[dt][0], (unsigned)vraw[dt][1]}), pf, acc[dt]);
+  }
+
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (head0 + r16 < p.hq) {
+    const int head = head0 + r16;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    // lane (head r16, c4) holds features 128 wave + 16 dt + 4 c4 .. + 3
+    if (p.num_splits == 1) {
+      T* dst = o + ((int64_t)b * p.hq + head) * MLA_RANK + 128 * wave + 4 * c4;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        Vec<T, 4> w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.v[r] = from_f32<T>(acc[dt][r] * inv);
+        stvec<T, 4>(dst + 16 * dt, w);
+      }
+    } else {
+      const int64_t ph0 = ((int64_t)b * p.hq + head0) * p.num_splits;
+      const int cell = r16 * p.num_splits + split;
+      const auto rs = wt_rsrc(p.part_o + ph0 * MLA_RANK, 16 * p.num_splits * MLA_RANK * 4);
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[dt] * inv), rs,
+                                               (cell * MLA_RANK + 128 * wave + 4 * c4 + 16 * dt) * 4, 0, 16);
+      if (c4 == 0 && wave == 0)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l > 0.f ? m * kLn2 + logf(l) : -INFINITY),
+                                              wt_rsrc(p.part_lse + ph0, 16 * p.num_splits * 4), cell * 4, 0, 16);
+    }
+  }
+  if (p.num_splits > 1 && p.tickets) {
+    const int nheads = p.hq - head0 < 16 ? p.hq - head0 : 16;
+    merge_splits_if_last<T, 4>(p, o, b, head0, nheads, MLA_RANK, b * (int)gridDim.x + (int)blockIdx.x, reinterpret_cast<float*>(sm_raw));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // MLA extend in the absorbed form over cached rows: the new tokens of a request attend to the request's
 // cached prefix and, causally, to each other (their latent rows are in the cache already).  The ring of the
 // decode kernel above, shared by FOUR consecutive new tokens of one request: wave w owns token 4 ty + w,
@@ -2446,12 +2689,32 @@ static int decode_attention_mla_impl(const MlaRope* rope, const void* q, const v
                   "decode_attention_mla_fused_rope: needs rank 512 + rope 64, a 16-bit dtype and cache, 16-byte aligned pointers");
   }
   if (kv8) {
-    // e4m3fn latent rows: the register kernel, widening on use (the LDS-ring kernel lands raw 16-bit rows)
+    // e4m3fn latent rows: the fp8 LDS ring (raw rows in LDS, widened per fragment); the register kernel (widening
+    // on use, merge launch) when a pointer is not 16-byte aligned or as development variant 2
     MI355_REQUIRE(kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
                       aligned16(q) && (reinterpret_cast<uintptr_t>(kv_buffer) & 7) == 0 && q_stride % 8 == 0,
                   MI355_ERR_UNSUPPORTED,
                   "decode_attention_mla: an fp8 latent cache needs rank 512 + rope 64, a 16-bit dtype and aligned pointers");
     const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)num_splits, (unsigned)bs);
+    if (g_decode_variant == 0 && aligned16(kv_buffer) && aligned16(attn_logits) && aligned16(o)) {
+      constexpr int NSB_ = 3;
+      if (num_splits > 1 && num_splits <= MERGE_MAX_SPLITS) p.tickets = split_tickets;   // merged inside the launch
+#define MLR8_LAUNCH(T_, CAP_)                                                                                  \
+  do {                                                                                                         \
+    auto kern = decode_attn_mla_ring8_kernel<T_, CAP_, NSB_>;                                                  \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m8_lds_bytes(NSB_)); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), m8_lds_bytes(NSB_), st, (const T_*)q, (const uint8_t*)kv_buffer,   \
+                       (T_*)o, p);                                                                             \
+    if (num_splits > 1 && !p.tickets)                                                                          \
+      hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
+                         p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
+  } while (0)
+      if (dtype == MI355_BF16) { if (logit_cap > 0.f) MLR8_LAUNCH(bf16_t, true); else MLR8_LAUNCH(bf16_t, false); }
+      else { if (logit_cap > 0.f) MLR8_LAUNCH(f16_t, true); else MLR8_LAUNCH(f16_t, false); }
+#undef MLR8_LAUNCH
+      MI355_CHECK_LAUNCH("decode_attention_mla");
+      return MI355_OK;
+    }
 #define MLA8_LAUNCH(T_, CAP_)                                                                                  \
   do {                                                                                                         \
     auto kern = decode_attn_mla_mfma_kernel<T_, CAP_, true>;                                                   \

@@ -121,11 +121,10 @@ class Mi355AttnBackend(AttentionBackend):
             # the MLA kernel keeps two workgroups per CU busy and streams 1152-byte rows: it is fastest at
             # 512 workgroups (64 sequences x 16 heads x 4096 keys: 190 / 107 / 75 / 68 us at 1 / 2 / 4 / 8 splits,
             # 91 at 10) with at least 256 keys per split (64 x 1024 keys: 31.6 us at 4 splits, 34.5 at 8)
+            # (the ring over an e4m3fn latent cache has the same shape: 64 x 16 x 4096: 103 / 68 / 57 / 81 us at
+            # 2 / 4 / 8 / 16 splits)
             wgs = max(1, bs * self.num_kv_head)
-            # an e4m3fn latent cache runs on the register kernel (one workgroup per CU, merge as a second
-            # launch): fastest at 256 workgroups (64 x 16 x 4096: 171 / 102 / 75 / 99 us at 1 / 2 / 4 / 8 splits)
-            target = 256 if self.kv_fp8 else 512
-            return max(1, min(MAX_KV_SPLITS, (target + wgs - 1) // wgs, max(1, max_seq_len // 256)))
+            return max(1, min(MAX_KV_SPLITS, (512 + wgs - 1) // wgs, max(1, max_seq_len // 256)))
         return get_ops().decode_num_splits(bs, self.num_kv_head, max_seq_len, MAX_KV_SPLITS)
 
     # ---- eager ----

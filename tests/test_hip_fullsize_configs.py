@@ -300,9 +300,10 @@ def test_deepseek_shard_mla_decode_fused_rope_is_bit_identical(ops, bs, splits):
 
 
 def test_deepseek_shard_mla_decode_over_fp8_latent_cache(ops):
-    """The same shape over an e4m3fn latent cache: bit for bit the same kernel over a 16-bit cache holding the
-    widened rows, and sampled sequences against float64 attention over the widened rows."""
-    bs, splits = 64, 4
+    """The same shape over an e4m3fn latent cache: the fp8 LDS-ring kernel with its in-launch merge == its merge
+    launch, sampled sequences against float64 attention over the widened rows; the register kernel (misaligned
+    split scratch) bit for bit the same kernel over a 16-bit cache holding the widened rows."""
+    bs, splits = 64, 8
     rank, rope, D_, lens, cache16, r2t, rpi, q, g = _mla_world(bs, 3900, 4160, 12)
     cache8 = torch.zeros(cache16.shape, dtype=torch.float8_e4m3fn, device=DEV)
     loc = torch.arange(cache16.shape[0], dtype=torch.int64, device=DEV)
@@ -313,10 +314,16 @@ def test_deepseek_shard_mla_decode_over_fp8_latent_cache(ops):
     ls = torch.empty(bs * 16 * splits, dtype=torch.float32, device=DEV)
     got = torch.full((bs, 16, rank), float("nan"), dtype=torch.bfloat16, device=DEV)
     same = torch.full_like(got, float("nan"))
-    ops.decode_attention_mla(q, cache8, got, r2t, rpi, lens, lg, ls, splits, rank, scale)
-    ops.decode_attention_mla(q, wide, same, r2t, rpi, lens, lg[1:], ls, splits, rank, scale)   # misaligned scratch: the register kernel
+    tickets = torch.zeros(bs * 16, dtype=torch.int32, device=DEV)
+    ops.decode_attention_mla(q, cache8, got, r2t, rpi, lens, lg, ls, splits, rank, scale, tickets=tickets)
+    ops.decode_attention_mla(q, cache8, same, r2t, rpi, lens, lg, ls, splits, rank, scale)
     torch.cuda.synchronize()
-    assert torch.equal(got.view(torch.int16), same.view(torch.int16))
+    assert torch.equal(got.view(torch.int16), same.view(torch.int16)) and not tickets.any()
+    reg8 = torch.full_like(got, float("nan"))
+    ops.decode_attention_mla(q, cache8, reg8, r2t, rpi, lens, lg[1:], ls, splits, rank, scale)   # misaligned scratch: the register kernel
+    ops.decode_attention_mla(q, wide, same, r2t, rpi, lens, lg[1:], ls, splits, rank, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(reg8.view(torch.int16), same.view(torch.int16))
     for b in (0, 31, 63):
         kv = wide[r2t[b, : int(lens[b])].long(), 0].double()
         ref = torch.softmax((q[b].double() @ kv.t()) * scale, -1) @ kv[:, :rank]

@@ -415,9 +415,10 @@ def test_mla_extend_tiled_refuses_other_latent_shapes():
 def test_mla_decode_over_fp8_latent_cache(H, dt, cap):
     """kv_cache_dtype fp8_e4m3 for the compressed cache (memory_pool.py:118-122, 769-909 of the reference):
     the rows are e4m3fn bytes, written by the scatter kernel (round to nearest even, saturating) and widened
-    exactly when a tile is computed.  Bit for bit the same kernel over a 16-bit cache that holds the widened
-    values (that kernel is selected for a 16-bit cache by handing it split scratch that is not 16-byte
-    aligned), one and three KV splits, and within one output rounding of float64 attention over the widened rows."""
+    exactly when a fragment is used.  The fp8 LDS-ring kernel (16-byte aligned pointers) within one output rounding
+    of float64 attention over the widened rows, its in-launch merge of the splits bit for bit its merge launch;
+    the register kernel (selected by split scratch that is not 16-byte aligned) bit for bit the same kernel over
+    a 16-bit cache that holds the widened values.  One and three KV splits."""
     from sglang_custom_amd import ops
 
     rank, rope = 512, 64
@@ -454,10 +455,16 @@ def test_mla_decode_over_fp8_latent_cache(H, dt, cap):
         got = torch.full((len(lens), H, rank), float("nan"), dtype=dt, device=DEV)
         ops.decode_attention_mla(q, cache8, got, r2t, rpi, lt, lg, ls, splits, rank, scale, cap)
         if splits > 1:
-            same = torch.full_like(got, float("nan"))
+            tickets = torch.zeros(len(lens) * H, dtype=torch.int32, device=DEV)
+            merged = torch.full_like(got, float("nan"))
+            ops.decode_attention_mla(q, cache8, merged, r2t, rpi, lt, lg, ls, splits, rank, scale, cap, tickets=tickets)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int16), merged.view(torch.int16)) and not tickets.any(), (H, splits)
+            reg8, same = torch.full_like(got, float("nan")), torch.full_like(got, float("nan"))
+            ops.decode_attention_mla(q, cache8, reg8, r2t, rpi, lt, lg[1:], ls, splits, rank, scale, cap)
             ops.decode_attention_mla(q, cache16, same, r2t, rpi, lt, lg[1:], ls, splits, rank, scale, cap)
             torch.cuda.synchronize()
-            assert torch.equal(got.view(torch.int16), same.view(torch.int16)), (H, splits)
+            assert torch.equal(reg8.view(torch.int16), same.view(torch.int16)), (H, splits)
         ring = torch.full_like(got, float("nan"))
         ops.decode_attention_mla(q, cache16, ring, r2t, rpi, lt, lg, ls, splits, rank, scale, cap)
         torch.cuda.synchronize()

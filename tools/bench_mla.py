@@ -48,18 +48,21 @@ for dbg in ((0,) if os.environ.get("MLA_AB") else (1, 2, 5, 0)):
         err = (o[:nb].float() - ref).abs().max().item()
         t = timeit(lambda i: ops.decode_attention_mla(q, kv[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5, tickets=tk))
         print(f"variant={dbg} splits={ns}{' in-kernel merge' if tk is not None and dbg in (0, 5) else ''}: {t:7.1f} us  {nbytes / t / 1e6:5.2f} TB/s  err={err:.4f}", flush=True)
-# e4m3fn latent cache (kv_cache_dtype fp8_e4m3): the register kernel widening on use; half the row bytes
+# e4m3fn latent cache (kv_cache_dtype fp8_e4m3): half the row bytes
 kv8 = [(t.float() * 2).to(torch.float8_e4m3fn) for t in kv]
 K8 = kv8[0][r2t[:nb].long(), 0].float()
 s8 = torch.einsum('bhd,bkd->bhk', q[:nb].float(), K8) * D ** -0.5
 ref8 = torch.einsum('bhk,bkd->bhd', s8.softmax(-1), K8[..., :rank])
+for dbg in (2, 0):   # 2 = register kernel (widening on use, merge launch), 0 = fp8 rows through the LDS ring (product)
+    lib.mi355_debug_set(6, dbg)
+    for ns in SPLIT_LIST:
+        o.zero_()
+        tk8 = tk if dbg == 0 else None
+        ops.decode_attention_mla(q, kv8[0], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5, tickets=tk8)
+        err = (o[:nb].float() - ref8).abs().max().item()
+        t = timeit(lambda i: ops.decode_attention_mla(q, kv8[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5, tickets=tk8))
+        print(f"fp8 latent cache variant={dbg} splits={ns}{' in-kernel merge' if tk8 is not None else ''}: {t:7.1f} us  {nbytes / 2 / t / 1e6:5.2f} TB/s of fp8 rows  err={err:.4f}", flush=True)
 lib.mi355_debug_set(6, 0)
-for ns in SPLIT_LIST:
-    o.zero_()
-    ops.decode_attention_mla(q, kv8[0], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5)
-    err = (o[:nb].float() - ref8).abs().max().item()
-    t = timeit(lambda i: ops.decode_attention_mla(q, kv8[i % NL], o, r2t, rpi, sl, lg, ls, ns, rank, D ** -0.5))
-    print(f"fp8 latent cache splits={ns}: {t:7.1f} us  {nbytes / 2 / t / 1e6:5.2f} TB/s of fp8 rows  err={err:.4f}", flush=True)
 # RoPE + latent-row write inside the launch against the three launches it replaces (rope, cache write, attention)
 lib.mi355_debug_set(6, 0)
 pos_t = sl - 1
