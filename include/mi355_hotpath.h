@@ -300,8 +300,9 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
  * and attends over the sequence INCLUDING that row (page_table must already name out_cache_loc[b] as the
  * last key; padded rows of a captured batch point out_cache_loc at the sink slot 0).  Bit for bit
  * mi355_rope_inplace on (q rope part, k_pe) + mi355_set_kv_buffer + mi355_decode_attention_mla, in one launch
- * instead of three.  Needs rank 512 + rope 64, a 16-bit dtype and cache (..._supported returns 1); everything
- * else as mi355_decode_attention_mla.
+ * instead of three.  Needs rank 512 + rope 64 and a 16-bit dtype (..._supported returns 1); the cache is 16-bit or
+ * e4m3fn (dtype | MI355_KV_FP8: the new row is quantised with mi355_set_kv_buffer's arithmetic); everything else
+ * as mi355_decode_attention_mla.
  * replaces: decode_attention_fwd_grouped_rope (layers/attention/triton_ops/rocm_mla_decode_rope.py:402-439),
  *           called from DeepseekV2AttentionMLA.forward_absorb_fused_mla_rope_{prepare,core}
  *           (python/sglang/srt/models/deepseek_v2.py:1337-1449, 1502-1536; dispatched at :973-980). */

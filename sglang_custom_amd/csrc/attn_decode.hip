@@ -1839,9 +1839,13 @@ template <typename T> __device__ __forceinline__ typename Mfma<T>::frag widen8(u
   return __builtin_bit_cast(typename Mfma<T>::frag, q);
 }
 
-template <typename T, bool CAP, int NSB>
+// ROPE: as in the 16-bit ring kernel -- the query's rope part is rotated in registers (the waves that own feature
+// steps 16 and 17), the new token's row [k_nope | rope(k_pe)] is built, quantised with the scatter kernel's
+// arithmetic, written to the cache by one workgroup per sequence and patched into the LDS image by every
+// workgroup whose key range ends at it.
+template <typename T, bool CAP, int NSB, bool ROPE = false>
 __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
-    const T* __restrict__ q, const uint8_t* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p) {
+    const T* __restrict__ q, const uint8_t* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p, MlaRope rp) {
   constexpr int NH = MLA_D / 64;   // 9 of the 18 score k-steps per wave
   using frag = typename Mfma<T>::frag;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -1863,6 +1867,55 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const int n_steps = k1 > k0 ? (int)((k1 - k0 + 31) / 32) : 0;
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+
+  // ROPE: threads 0..63 hold eight bytes of the new row's latent part, threads 64..71 (interleaved pairs) or
+  // 64..67 (neox pairs: a piece and its partner 32 features on) of its rotated rope part.
+  const bool has_new = ROPE && k1 == len && len > k0;   // this workgroup's range ends at the new token
+  uint2 new_qa = uint2{0u, 0u}, new_qb = uint2{0u, 0u};
+  int64_t rope_pos = 0;
+  if constexpr (ROPE) {
+    rope_pos = rp.positions[b];
+    if (has_new) {
+      const int tid = threadIdx.x;
+      Vec<T, 8> new_a, new_b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) new_a.v[j] = new_b.v[j] = from_f32<T>(0.f);
+      if (tid < 64) {
+        new_a = ldvec<T, 8>(static_cast<const T*>(rp.k_nope) + (int64_t)b * rp.k_nope_stride + 8 * tid);
+      } else if (tid < 72) {
+        const T* kp = static_cast<const T*>(rp.k_pe) + (int64_t)b * rp.k_pe_stride;
+        const int c = tid - 64;
+        if (!rp.is_neox) {
+          const Vec<T, 8> x = ldvec<T, 8>(kp + 8 * c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * c + j;
+            rope_pair<T>(to_f32(x.v[2 * j]), to_f32(x.v[2 * j + 1]), mla_cs_t<T>(rp, rope_pos, i),
+                         mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + i), new_a.v[2 * j], new_a.v[2 * j + 1]);
+          }
+        } else if (c < 4) {
+          const Vec<T, 8> x1 = ldvec<T, 8>(kp + 8 * c), x2 = ldvec<T, 8>(kp + MLA_ROPE / 2 + 8 * c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = 8 * c + j;
+            rope_pair<T>(to_f32(x1.v[j]), to_f32(x2.v[j]), mla_cs_t<T>(rp, rope_pos, i),
+                         mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + i), new_a.v[j], new_b.v[j]);
+          }
+        }
+      }
+      new_qa = quant8_fp8<T>(new_a, 1.0f);   // the scatter kernel's rounding (clamp to +-448, nearest even)
+      new_qb = quant8_fp8<T>(new_b, 1.0f);
+      if (blockIdx.x == 0) {   // one workgroup per sequence writes the row to the cache
+        uint8_t* dst = const_cast<uint8_t*>(kvbuf) + rp.out_loc[b] * MLA_D;
+        if (tid < 64) *reinterpret_cast<uint2*>(dst + 8 * tid) = new_qa;
+        else if (tid < 72 && !rp.is_neox) *reinterpret_cast<uint2*>(dst + MLA_RANK + 8 * (tid - 64)) = new_qa;
+        else if (tid < 68) {
+          *reinterpret_cast<uint2*>(dst + MLA_RANK + 8 * (tid - 64)) = new_qa;
+          *reinterpret_cast<uint2*>(dst + MLA_RANK + MLA_ROPE / 2 + 8 * (tid - 64)) = new_qb;
+        }
+      }
+    }
+  }
 
   // page-table reads through the scalar unit (wave-uniform index, read-only data)
   const int32_t __attribute__((address_space(4)))* pt =
@@ -1932,6 +1985,32 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
     const T* qp = q + (int64_t)b * p.q_stride + (int64_t)hq_c * MLA_D + 32 * NH * half + 8 * c4;
 #pragma unroll
     for (int s = 0; s < NH; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 32 * s);
+    if constexpr (ROPE) {
+      if (half == 1) {
+        // rope part = feature steps 16 and 17 = this wave's steps NH - 2 and NH - 1: the lane holds features
+        // 8 c4 .. + 7 and 32 + 8 c4 .. + 7 of its head
+        Vec<T, 8> a = __builtin_bit_cast(Vec<T, 8>, qf[NH - 2]), b2 = __builtin_bit_cast(Vec<T, 8>, qf[NH - 1]);
+        if (!rp.is_neox) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ia = 4 * c4 + j, ib = 16 + 4 * c4 + j;
+            rope_pair<T>(to_f32(a.v[2 * j]), to_f32(a.v[2 * j + 1]), mla_cs_t<T>(rp, rope_pos, ia),
+                         mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + ia), a.v[2 * j], a.v[2 * j + 1]);
+            rope_pair<T>(to_f32(b2.v[2 * j]), to_f32(b2.v[2 * j + 1]), mla_cs_t<T>(rp, rope_pos, ib),
+                         mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + ib), b2.v[2 * j], b2.v[2 * j + 1]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = 8 * c4 + j;
+            rope_pair<T>(to_f32(a.v[j]), to_f32(b2.v[j]), mla_cs_t<T>(rp, rope_pos, i),
+                         mla_cs_t<T>(rp, rope_pos, MLA_ROPE / 2 + i), a.v[j], b2.v[j]);
+          }
+        }
+        qf[NH - 2] = __builtin_bit_cast(frag, a);
+        qf[NH - 1] = __builtin_bit_cast(frag, b2);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NH; ++s) asm volatile("" ::"v"(qf[s]));
   }
@@ -1946,7 +2025,24 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
     __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's image is free
     if (t + P < n_steps) issue_step(t + P, s_nxt);
     s_nxt = slots_of(t + P + 1);
-    const char* img = sm_raw + (t % NSB) * M8_STEP;
+    char* img = sm_raw + (t % NSB) * M8_STEP;
+    if constexpr (ROPE) {
+      if (has_new && t == n_steps - 1) {
+        // the new token is the last key of the last step: its bytes go into the image over what was fetched from
+        // the slot (every wave's loads of this step have landed: the barrier above)
+        const int kl = (int)(len - 1 - k0) - 32 * t;           // 0 .. 31 inside the step
+        char* row = img + m8_row(kl);
+        const int tid = threadIdx.x;
+        if (tid < 64) *reinterpret_cast<uint2*>(row + 8 * tid) = new_qa;
+        else if (tid < 72 && !rp.is_neox) *reinterpret_cast<uint2*>(row + MLA_RANK + 8 * (tid - 64)) = new_qa;
+        else if (tid < 68) {
+          *reinterpret_cast<uint2*>(row + MLA_RANK + 8 * (tid - 64)) = new_qa;
+          *reinterpret_cast<uint2*>(row + MLA_RANK + MLA_ROPE / 2 + 8 * (tid - 64)) = new_qb;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
 
     // this wave's partial scores: 16 keys of its tile x 16 heads over its nine feature steps
     uint2 kraw[NH];
@@ -2682,11 +2778,11 @@ static int decode_attention_mla_impl(const MlaRope* rope, const void* q, const v
   hipStream_t st = (hipStream_t)stream;
   if (rope) {
     // rotation + cache write inside the launch: only the LDS-ring kernel has it
-    MI355_REQUIRE(!kv8 && kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
-                      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && aligned16(attn_logits) &&
+    MI355_REQUIRE(kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
+                      aligned16(q) && aligned16(kv_buffer) && q_stride % 8 == 0 && aligned16(attn_logits) && aligned16(o) &&
                       g_decode_variant == 0,
                   MI355_ERR_UNSUPPORTED,
-                  "decode_attention_mla_fused_rope: needs rank 512 + rope 64, a 16-bit dtype and cache, 16-byte aligned pointers");
+                  "decode_attention_mla_fused_rope: needs rank 512 + rope 64, a 16-bit dtype, a 16-bit or e4m3fn cache, 16-byte aligned pointers");
   }
   if (kv8) {
     // e4m3fn latent rows: the fp8 LDS ring (raw rows in LDS, widened per fragment); the register kernel (widening
@@ -2701,10 +2797,10 @@ static int decode_attention_mla_impl(const MlaRope* rope, const void* q, const v
       if (num_splits > 1 && num_splits <= MERGE_MAX_SPLITS) p.tickets = split_tickets;   // merged inside the launch
 #define MLR8_LAUNCH(T_, CAP_)                                                                                  \
   do {                                                                                                         \
-    auto kern = decode_attn_mla_ring8_kernel<T_, CAP_, NSB_>;                                                  \
+    auto kern = rope ? decode_attn_mla_ring8_kernel<T_, CAP_, NSB_, true> : decode_attn_mla_ring8_kernel<T_, CAP_, NSB_>; \
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m8_lds_bytes(NSB_)); \
     hipLaunchKernelGGL(kern, grid, dim3(256), m8_lds_bytes(NSB_), st, (const T_*)q, (const uint8_t*)kv_buffer,   \
-                       (T_*)o, p);                                                                             \
+                       (T_*)o, p, rope ? *rope : MlaRope{});                                                   \
     if (num_splits > 1 && !p.tickets)                                                                          \
       hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
                          p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
@@ -2795,8 +2891,9 @@ int mi355_decode_attention_mla(const void* q, const void* kv_buffer, void* o,
 }
 
 int mi355_decode_attention_mla_fused_rope_supported(int kv_lora_rank, int rope_dim, int dtype, int cache_is_fp8) {
+  (void)cache_is_fp8;   // 16-bit and e4m3fn caches both have an LDS-ring kernel with the rotation inside
   return kv_lora_rank == MLA_RANK && rope_dim == MLA_ROPE && (dtype == MI355_BF16 || dtype == MI355_F16) &&
-         !cache_is_fp8 && g_decode_variant == 0;
+         g_decode_variant == 0;
 }
 
 int mi355_decode_attention_mla_fused_rope(const void* q, const void* k_nope, int64_t k_nope_stride, const void* k_pe,

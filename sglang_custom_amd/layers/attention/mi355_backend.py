@@ -299,7 +299,7 @@ class Mi355AttnBackend(AttentionBackend):
         pool = forward_batch.token_to_kv_pool
         return (MLA_FUSED_ROPE and forward_batch.forward_mode.is_decode() and hasattr(pool, "kv_lora_rank")
                 and rotary_emb.rotary_dim == pool.qk_rope_head_dim
-                and rotary_emb.cos_sin_cache.dtype in (torch.float32, dtype) and pool.dtype == dtype
+                and rotary_emb.cos_sin_cache.dtype in (torch.float32, dtype) and pool.dtype in (dtype, torch.float8_e4m3fn)
                 and get_ops().decode_attention_mla_fused_rope_supported(pool.kv_lora_rank, pool.qk_rope_head_dim, dtype,
                                                                          pool.dtype))
 

@@ -454,11 +454,13 @@ def decode_attention_mla_fused_rope(q, k_nope, k_pe, positions, out_cache_loc, c
     """decode_attention_mla with RoPE and the cache write inside the launch (the reference's ROCm kernel
     decode_attention_fwd_grouped_rope, rocm_mla_decode_rope.py:402-439): q [B, H, rank + rope] with its rope part
     NOT rotated, k_nope [B, rank] (row-strided view allowed), k_pe [B, rope] not rotated (row-strided view allowed);
-    rotates both at positions, writes the row [k_nope | rope(k_pe)] to kv_buffer[out_cache_loc] and attends."""
+    rotates both at positions, writes the row [k_nope | rope(k_pe)] to kv_buffer[out_cache_loc] (quantised as
+    set_kv_buffer does when the cache is e4m3fn) and attends."""
     _gpu(q, k_nope, k_pe, positions, out_cache_loc, cos_sin_cache, kv_buffer, o, req_to_token, req_pool_indices, seq_lens)
     B, Hq, D = q.shape
     rope = D - kv_lora_rank
-    assert kv_buffer.is_contiguous() and kv_buffer.shape[1] == 1 and kv_buffer.shape[2] == D and kv_buffer.dtype == q.dtype
+    assert kv_buffer.is_contiguous() and kv_buffer.shape[1] == 1 and kv_buffer.shape[2] == D
+    assert kv_buffer.dtype in (q.dtype, torch.float8_e4m3fn)
     assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous() and o.shape == (B, Hq, kv_lora_rank)
     k_nope2, k_pe2 = k_nope.view(B, -1), k_pe.view(B, -1)
     assert k_nope2.shape[1] == kv_lora_rank and k_pe2.shape[1] == rope and k_nope2.stride(1) == 1 and k_pe2.stride(1) == 1
@@ -475,7 +477,7 @@ def decode_attention_mla_fused_rope(q, k_nope, k_pe, positions, out_cache_loc, c
         o.data_ptr(), req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
         req_to_token.stride(0), _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys),
         num_kv_splits, B, Hq, kv_lora_rank, rope, q.stride(0), kv_buffer.shape[0], float(sm_scale), float(logit_cap),
-        _dt(q), _stream(q)), "decode_attention_mla_fused_rope")
+        _kvdt(q, kv_buffer), _stream(q)), "decode_attention_mla_fused_rope")
 
 
 def mla_latent_norms_supported(q_rank: int, kv_rank: int, rope_dim: int, dtype: torch.dtype) -> bool:

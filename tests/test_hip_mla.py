@@ -497,13 +497,15 @@ def test_fp8_latent_cache_refuses_other_shapes():
 @pytest.mark.parametrize("H,splits,in_kernel_merge", [(16, 1, False), (16, 4, True), (20, 3, False), (128, 2, True), (5, 8, True)])
 @pytest.mark.parametrize("dt,cs_dt,neox,cap", [(torch.bfloat16, torch.bfloat16, False, 0.0), (torch.float16, torch.float32, False, 0.0),
                                                (torch.bfloat16, torch.float32, True, 30.0)])
-def test_mla_decode_with_rope_and_cache_write_inside_the_launch(H, splits, in_kernel_merge, dt, cs_dt, neox, cap):
+@pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
+def test_mla_decode_with_rope_and_cache_write_inside_the_launch(H, splits, in_kernel_merge, dt, cs_dt, neox, cap, kv8):
     """mi355_decode_attention_mla_fused_rope (the reference's ROCm decode_attention_fwd_grouped_rope,
     rocm_mla_decode_rope.py:402-439, selected at deepseek_v2.py:973-980): q's rope part and k_pe unrotated in,
     one launch rotates them, writes the new latent row and attends.  Bit for bit the three-launch sequence
     rope_inplace -> set_kv_buffer -> decode_attention_mla: the outputs AND the cache rows; lengths that put the
     new token first / last in a tile and in either tile of a step, empty splits, head counts around the
-    16-head tile, interleaved and neox pairing, fp32 and 16-bit tables."""
+    16-head tile, interleaved and neox pairing, fp32 and 16-bit tables; over a 16-bit cache and over an e4m3fn
+    cache (the new row quantised inside the launch with the scatter kernel's arithmetic)."""
     from sglang_custom_amd import ops
 
     rank, rope = 512, 64
@@ -511,6 +513,11 @@ def test_mla_decode_with_rope_and_cache_write_inside_the_launch(H, splits, in_ke
     lens = [1, 16, 17, 32, 33, 300, 1029, 48]
     B, total = len(lens), sum(lens)
     cache0 = _CASES.randn((total + 1, 1, D), 41, dt).to(DEV)
+    if kv8:
+        rows16 = (cache0.float() * 3.0).to(dt)
+        cache0 = torch.zeros((total + 1, 1, D), dtype=torch.float8_e4m3fn, device=DEV)
+        ops.set_kv_buffer(cache0, cache0, torch.arange(total + 1, dtype=torch.int64, device=DEV), rows16, rows16)
+    bits = torch.uint8 if kv8 else torch.int16
     r2t = torch.zeros((B, max(lens)), dtype=torch.int32)
     perm = torch.randperm(total, generator=torch.Generator().manual_seed(5)) + 1
     pos = 0
@@ -526,6 +533,8 @@ def test_mla_decode_with_rope_and_cache_write_inside_the_launch(H, splits, in_ke
     q = _CASES.randn((B, H, D), 42, dt).to(DEV)
     lat = _CASES.randn((B, 192 + D), 43, dt).to(DEV)        # [q_a | kv_a | k_pe] as the fused projection leaves it
     k_nope = _CASES.randn((B, rank), 44, dt).to(DEV)          # the normed latent
+    if kv8:
+        k_nope[0, :3] = torch.tensor([1000.0, -1000.0, 1e-3], dtype=dt, device=DEV)   # saturation and a tiny value
     k_pe_view = lat[:, 192 + rank:]
     g = torch.Generator().manual_seed(6)
     cs = torch.cat([torch.randn(4096 + 8, rope // 2, generator=g).cos(), torch.randn(4096 + 8, rope // 2, generator=g).sin()],
@@ -555,7 +564,7 @@ def test_mla_decode_with_rope_and_cache_write_inside_the_launch(H, splits, in_ke
                                             splits, rank, scale, cap, tickets=tickets)
         torch.cuda.synchronize()
         assert not torch.isnan(got.float()).any()
-        assert torch.equal(cache.view(torch.int16), cache_ref.view(torch.int16)), "cache rows differ"
+        assert torch.equal(cache.view(bits), cache_ref.view(bits)), "cache rows differ"
         bad = (got.view(torch.int16) != want.view(torch.int16)).any(-1).any(-1).nonzero().flatten().tolist()
         assert not bad, (bad, (got.float() - want.float()).abs().max().item())
         if tickets is not None:
