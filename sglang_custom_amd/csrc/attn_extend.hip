@@ -543,13 +543,20 @@ __device__ __forceinline__ int xor_image_off(int row, int ch) {   // bytes; ch =
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <typename T, bool KV8 = false>
+// DQ: query / key head dimension, 128 or 192 (the multi-head form of MLA prefill: 128 nope + 64 rope features
+// against 128-wide values).  Features 128 .. 191 of the K tile are a second 256-byte-row image (half of each row
+// used) with the same chunk XOR, so the fragment reads of score steps 8 .. 11 are as conflict-free as the others.
+template <typename T, bool KV8 = false, int DQ = 128>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void extend_attn_mfma32_kernel(
     const T* __restrict__ q_ext, const T* __restrict__ k_ext, const T* __restrict__ v_ext, T* __restrict__ o_ext,
     const T* __restrict__ kbuf, const T* __restrict__ vbuf, ExtendParams p, int nqb, int npairs) {
-  constexpr int D = 128;
+  constexpr int D = 128;          // value head dimension = width of one tile image
+  constexpr int NS = DQ / 16;     // score k-steps
+  constexpr bool WIDE = DQ > 128;
+  static_assert(DQ == 128 || (DQ == 192 && !KV8), "128, or 192 over a 16-bit cache");
   using frag = typename Mfma32<T>::frag;
   __shared__ __attribute__((aligned(16))) char ks[64 * 256];
+  __shared__ __attribute__((aligned(16))) char ks2[WIDE ? 64 * 256 : 16];
   __shared__ __attribute__((aligned(16))) char vs[64 * 256];
 
   const int G = p.hq / p.hkv;
@@ -574,11 +581,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float qmul = p.sm_scale * kLog2eE;
 
   // B operand of S^T: Q[qrow][16 s + 8 h + 0..7]
-  frag qf[8];
+  frag qf[NS];
   {
-    const T* qp = q_ext + (int64_t)(q_start + qrow_c) * p.q_stride + (int64_t)h * D + 8 * hh;
+    const T* qp = q_ext + (int64_t)(q_start + qrow_c) * p.q_stride + (int64_t)h * DQ + 8 * hh;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const frag*>(qp + 16 * s);
   }
 
   const int last_row = min(r0 + 127, ext - 1);
@@ -590,8 +597,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // tile staging: thread -> rows (threadIdx.x >> 4) + 16 i, 16-B chunk (threadIdx.x & 15)
   const int srow = threadIdx.x >> 4, sch = threadIdx.x & 15;
-  Vec<T, 8> kreg[4], vreg[4];
-  const T* k_lin = k_ext + (int64_t)(q_start - prefix + srow) * p.k_stride + (int64_t)kvh * D + sch * 8;
+  Vec<T, 8> kreg[4], vreg[4], kreg2[WIDE ? 4 : 1];   // kreg2: features 128 + 8 sch .. + 7 (threads with sch < 8)
+  const T* k_lin = k_ext + (int64_t)(q_start - prefix + srow) * p.k_stride + (int64_t)kvh * DQ + sch * 8;
   const T* v_lin = v_ext + (int64_t)(q_start - prefix + srow) * p.v_stride + (int64_t)kvh * D + sch * 8;
   auto load_tile = [&](int kt) {
     if (kt * 64 >= prefix && kt * 64 + 63 < total) {   // whole tile in the extend part (workgroup-uniform)
@@ -600,6 +607,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int64_t key = kt * 64 + 16 * i;
         kreg[i] = ldvec<T, 8>(k_lin + key * p.k_stride);
         vreg[i] = ldvec<T, 8>(v_lin + key * p.v_stride);
+        if constexpr (WIDE) {
+          if (sch < 8) kreg2[i] = ldvec<T, 8>(k_lin + key * p.k_stride + 128);
+        }
       }
       return;
     }
@@ -618,15 +628,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const T *kp, *vp;
       if (key < prefix) {
         const int64_t slot_ = p.kv_indices[kv_start + key];
-        kp = kbuf + (slot_ * p.hkv + kvh) * D;
+        kp = kbuf + (slot_ * p.hkv + kvh) * DQ;
         vp = vbuf + (slot_ * p.hkv + kvh) * D;
       } else {
         const int64_t tok = q_start + key - prefix;
-        kp = k_ext + tok * p.k_stride + (int64_t)kvh * D;
+        kp = k_ext + tok * p.k_stride + (int64_t)kvh * DQ;
         vp = v_ext + tok * p.v_stride + (int64_t)kvh * D;
       }
       kreg[i] = ldvec<T, 8>(kp + sch * 8);
       vreg[i] = ldvec<T, 8>(vp + sch * 8);
+      if constexpr (WIDE) {
+        if (sch < 8) kreg2[i] = ldvec<T, 8>(kp + 128 + sch * 8);
+      }
     }
   };
   auto store_tile = [&]() {
@@ -635,6 +648,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int off = xor_image_off(srow + 16 * i, sch);
       *reinterpret_cast<Vec<T, 8>*>(ks + off) = kreg[i];
       *reinterpret_cast<Vec<T, 8>*>(vs + off) = vreg[i];
+      if constexpr (WIDE) {
+        if (sch < 8) *reinterpret_cast<Vec<T, 8>*>(ks2 + off) = kreg2[i];
+      }
     }
   };
 
@@ -650,6 +666,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int fx = ((j32 & 3) << 2) | ((j32 >> 2) & 3);
   const int kcx = hh ^ fx;
   const char* k_rd = ks + 256 * j32;                        // + 8192 hf + 16 * ((2 s) ^ kcx)
+  const char* k_rd2 = ks2 + 256 * j32;                      // steps 8 .. : chunk 2 (s - 8) + h of the second image
+  auto k_frag = [&](int s_, int hf) -> frag {
+    const char* base = (WIDE && s_ >= 8) ? k_rd2 : k_rd;
+    return *reinterpret_cast<const frag*>(base + 8192 * hf + 16 * ((2 * (s_ & 7)) ^ kcx));
+  };
   // V^T fragment of (d tile dt, 16-key step u): lane group (l >> 4) = 2 h + dhalf serves features
   // 32 dt + 16 dhalf + 0..15; lane 4 q + pp of the group supplies row 16 u (+ 8) + 4 h + q, features 4 pp..4 pp + 3
   const int l16 = lane & 15, dhalf = (lane >> 4) & 1, tq = l16 >> 2, tpp = l16 & 3;
@@ -677,9 +698,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     frag kr[3][2];   // K fragments of k-steps s, s + 1, s + 2
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int co = 16 * ((2 * s) ^ kcx);
-      kr[s][0] = *reinterpret_cast<const frag*>(k_rd + co);
-      kr[s][1] = *reinterpret_cast<const frag*>(k_rd + 8192 + co);
+      kr[s][0] = k_frag(s, 0);
+      kr[s][1] = k_frag(s, 1);
     }
     // the first V^T fragments too: the tile is already in LDS, and the softmax below covers their latency
     typename TrRead<T>::v4 vlo[4], vhi[4];   // ring of four (u, dt) fragments
@@ -691,12 +711,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s + 2 < 8) {
-        const int co = 16 * ((2 * (s + 2)) ^ kcx);
-        kr[(s + 2) % 3][0] = *reinterpret_cast<const frag*>(k_rd + co);
-        kr[(s + 2) % 3][1] = *reinterpret_cast<const frag*>(k_rd + 8192 + co);
-      } else if (s == 6) {
+    for (int s = 0; s < NS; ++s) {
+      if (s + 2 < NS) {
+        kr[(s + 2) % 3][0] = k_frag(s + 2, 0);
+        kr[(s + 2) % 3][1] = k_frag(s + 2, 1);
+      } else if (s == NS - 2) {
         v_read(0, 0);
         v_read(1, 1);
       } else {
@@ -827,15 +846,18 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
                    p.k_stride % VE == 0 && p.v_stride % VE == 0 && aligned16(q) && aligned16(k) &&
                    aligned16(v) && aligned16(o) && aligned16(kb) && aligned16(vb);
   if constexpr (!std::is_same<T, float>::value) {
-    if (vec && p.D == 128 && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 && p.logit_cap <= 0.f &&
-        p.sm_scale > 0.f && g_extend_variant == 0) {   // the 32x32 kernel takes the maximum of unscaled scores
+    if (vec && (p.D == 128 || (p.D == 192 && !kv8)) && p.Dv == 128 && !p.custom_mask && p.sliding_window <= 0 &&
+        p.logit_cap <= 0.f && p.sm_scale > 0.f && g_extend_variant == 0) {   // the 32x32 kernel takes the maximum of unscaled scores
       // 128 query rows of one head per workgroup; (sequence, kv head) pairs dealt round-robin to the XCDs
       const int nqb = (int)((max_len_extend + 127) / 128);
       const int64_t npairs = bs * p.hkv;
       const int64_t wgs = 8 * ((npairs + 7) / 8) * (p.hq / p.hkv) * nqb;
       if (wgs < (int64_t)1 << 31) {
         const dim3 grid1((unsigned)wgs);
-        if (kv8)
+        if (p.D == 192)
+          hipLaunchKernelGGL((extend_attn_mfma32_kernel<T, false, 192>), grid1, dim3(256), 0, st, (const T*)q, (const T*)k,
+                             (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p, nqb, (int)npairs);
+        else if (kv8)
           hipLaunchKernelGGL((extend_attn_mfma32_kernel<T, true>), grid1, dim3(256), 0, st, (const T*)q, (const T*)k,
                              (const T*)v, (T*)o, (const T*)kb, (const T*)vb, p, nqb, (int)npairs);
         else

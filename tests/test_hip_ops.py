@@ -1137,3 +1137,38 @@ def test_fp8_linear_method_pads_odd_reduction_lengths(ops):
     assert part is not None
     summed = ((part.part.sum(0) * part.x_scale) * part.w_scale.view(1, -1)).to(torch.bfloat16)
     assert maxdiff(summed, ref) <= 1e-2
+
+
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+def test_extend_attention_matrix_core_tile_192_wide_keys(ops, dtn):
+    """The multi-head form of MLA prefill (deepseek_v2.py:1131-1179): query / key heads of 128 + 64 features against
+    128-wide values on the 32x32 matrix-core tile -- ragged lengths around the 128-row / 64-key tile edges, with
+    and without a cached prefix, against float64 attention."""
+    dt = DT[dtn]
+    Dq, Dv = 192, 128
+    for H, (pre, ext) in [(16, ([0, 0, 0], [64, 257, 129])), (5, ([0], [300])), (16, ([70, 0, 129], [65, 1, 200]))]:
+        seq = [a + b for a, b in zip(pre, ext)]
+        nslots = sum(seq) + 1
+        g = torch.Generator().manual_seed(H * 100 + sum(seq))
+        kc = torch.randn(nslots, H, Dq, generator=g).to(dt)
+        vc = torch.randn(nslots, H, Dv, generator=g).to(dt)
+        perm = torch.randperm(nslots - 1, generator=g) + 1
+        slots, p0 = [], 0
+        for n in seq:
+            slots.append(perm[p0: p0 + n])
+            p0 += n
+        q = torch.randn(sum(ext), H, Dq, generator=g).to(dt)
+        kext = torch.cat([kc[slots[b][pre[b]:]] for b in range(len(seq))])
+        vext = torch.cat([vc[slots[b][pre[b]:]] for b in range(len(seq))])
+        qo = torch.tensor([0] + list(torch.tensor(ext).cumsum(0)), dtype=torch.int32)
+        kvp = torch.tensor([0] + list(torch.tensor(pre).cumsum(0)), dtype=torch.int32)
+        kvi = torch.cat([slots[b][: pre[b]] for b in range(len(seq))] + [torch.zeros(1, dtype=torch.int64)]).to(torch.int32)
+        o = torch.full((sum(ext), H, Dv), float("nan"), dtype=dt, device=DEV)
+        ops.extend_attention_fwd(q.to(DEV), kext.to(DEV), vext.to(DEV), o, kc.to(DEV), vc.to(DEV), qo.to(DEV), kvp.to(DEV),
+                                 kvi.to(DEV), None, True, None, max(ext), Dq ** -0.5)
+        p = 0
+        for b in range(len(seq)):
+            ref = ops_ref.attention_fp64(q[p: p + ext[b]].transpose(0, 1), kc[slots[b]].transpose(0, 1),
+                                         vc[slots[b]].transpose(0, 1), Dq ** -0.5, pre[b]).transpose(0, 1)
+            assert maxdiff(o[p: p + ext[b]], ref) <= ATTN_TOL[dtn], (H, b)
+            p += ext[b]
