@@ -5,20 +5,24 @@ import ctypes
 from sglang_custom_amd import ops, _lib
 _lib.use_dev_library(os.environ.get('MI355_AB_LIB'))   # MI355_AB_LIB: a development build of another source tree; ablation switches live in the development build only
 lib = _lib.load()
-bs, L, hq, hkv, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 32, 8, 128
+# usage: bench_extend.py [bs L [hq hkv Dq Dv]]   (MLA prefill in its multi-head form: 16 16 192 128)
+_a = [int(x) for x in sys.argv[1:]]
+bs, L = (_a + [64, 1024])[:2] if len(_a) < 2 else _a[:2]
+hq, hkv, D, Dv = _a[2:6] if len(_a) >= 6 else (32, 8, 128, 128)
 torch.manual_seed(0)
 T = bs * L
 q = torch.randn(T, hq, D, device='cuda').bfloat16()
 k = torch.randn(T, hkv, D, device='cuda').bfloat16()
-v = torch.randn(T, hkv, D, device='cuda').bfloat16()
-o = torch.empty_like(q)
-kb = torch.zeros(16, hkv, D, device='cuda').bfloat16(); vb = torch.zeros_like(kb)
+v = torch.randn(T, hkv, Dv, device='cuda').bfloat16()
+o = torch.empty(T, hq, Dv, device='cuda', dtype=torch.bfloat16)
+kb = torch.zeros(16, hkv, D, device='cuda').bfloat16(); vb = torch.zeros(16, hkv, Dv, device='cuda').bfloat16()
 qo = torch.arange(0, T + 1, L, dtype=torch.int32, device='cuda')
 kvi = torch.zeros(bs + 1, dtype=torch.int32, device='cuda'); kidx = torch.zeros(1, dtype=torch.int32, device='cuda')
 def run():
     ops.extend_attention_fwd(q, k, v, o, kb, vb, qo, kvi, kidx, None, True, None, L, D ** -0.5)
 import torch.nn.functional as F
 for variant, name in ((1, "16x16x32 tile, 64 rows per workgroup (ablation)"), (0, "32x32x16 tile, 128 rows per workgroup (product)")):
+    if variant == 1 and D != 128: continue
     lib.mi355_debug_set(8, variant)
     for _ in range(30): run()   # clocks settle: a cold GPU times the same kernel 20-30 % slower
     torch.cuda.synchronize()
@@ -27,7 +31,7 @@ for variant, name in ((1, "16x16x32 tile, 64 rows per workgroup (ablation)"), (0
     for _ in range(30): run()
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 30
-    flops = 4 * bs * hq * D * L * L / 2
+    flops = 2 * bs * hq * (D + Dv) * L * L / 2
     print(f"{name}: bs={bs} L={L}: {t:.3f} ms  {flops / t / 1e9:.1f} TFLOP/s", flush=True)
     for b in (0, bs - 1):   # a few sequences against SDPA
         qq = q[b * L:(b + 1) * L].transpose(0, 1).float(); kk = k[b * L:(b + 1) * L].transpose(0, 1).float(); vv = v[b * L:(b + 1) * L].transpose(0, 1).float()
