@@ -2045,12 +2045,20 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
     }
 
     // this wave's partial scores: 16 keys of its tile x 16 heads over its nine feature steps
-    uint2 kraw[NH];
+    // (ds_read_b64 by hand: the compiler pairs these reads into ds_read2_b64, which banks modulo 32 over 16-lane
+    // groups -- rows r and r + 8 of the 592-byte image then collide, 32 conflict cycles per wave and step)
+    unsigned long long kraw[NH];
+    const unsigned k_addr = lds_byte_address(img + k_rd);
 #pragma unroll
-    for (int s = 0; s < NH; ++s) kraw[s] = *reinterpret_cast<const uint2*>(img + k_rd + 32 * s);
+    for (int s = 0; s < NH; ++s) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(kraw[s]) : "v"(k_addr), "n"(32 * s));
+    static_assert(NH == 9, "the wait below names nine fragments");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(kraw[0]), "+v"(kraw[1]), "+v"(kraw[2]), "+v"(kraw[3]), "+v"(kraw[4]), "+v"(kraw[5]), "+v"(kraw[6]),
+                   "+v"(kraw[7]), "+v"(kraw[8]));
     f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NH; ++s) part = Mfma<T>::run(widen8<T>(kraw[s]), qf[s], part);
+    for (int s = 0; s < NH; ++s)
+      part = Mfma<T>::run(widen8<T>(uint2{(unsigned)kraw[s], (unsigned)(kraw[s] >> 32)}), qf[s], part);
     f32x4* xw = reinterpret_cast<f32x4*>(xch + (t & 1) * 4096);
     xw[wave * 64 + lane] = part;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
