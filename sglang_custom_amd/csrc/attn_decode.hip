@@ -1839,12 +1839,25 @@ template <typename T> __device__ __forceinline__ typename Mfma<T>::frag widen8(u
   return __builtin_bit_cast(typename Mfma<T>::frag, q);
 }
 
+// 0 = plan (two teams per workgroup when the grid allows), 1 = one team (ablation; development build, mi355_debug_set key 10)
+#ifdef MI355_DEV_BUILD
+int g_mla_teams = 0;
+#else
+static constexpr int g_mla_teams = 0;
+#endif
+
 // ROPE: as in the 16-bit ring kernel -- the query's rope part is rotated in registers (the waves that own feature
 // steps 16 and 17), the new token's row [k_nope | rope(k_pe)] is built, quantised with the scatter kernel's
 // arithmetic, written to the cache by one workgroup per sequence and patched into the LDS image by every
 // workgroup whose key range ends at it.
-template <typename T, bool CAP, int NSB, bool ROPE = false>
-__global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
+// TEAMS = 2: a workgroup of 512 threads is two teams of four waves, each with its own ring, working on two
+// consecutive KV splits (2 y, 2 y + 1) of the launch's split plan; the teams' results meet in LDS at the end and ONE
+// partial leaves the workgroup.  Same waves per CU and bytes in flight as two 256-thread workgroups, half the
+// workgroups to dispatch, half the partials to write and to merge (the merge of S partials of 16 heads x 512
+// features is what a launch pays for its splits: 64 x 16 heads, 64 keys: 9 / 15 / 18 / 26 us at 1 / 2 / 4 / 8).
+// grid.y = num_splits / TEAMS; barriers are workgroup-wide, so both teams walk max(steps) iterations.
+template <typename T, bool CAP, int NSB, bool ROPE = false, int TEAMS = 1>
+__global__ __launch_bounds__(256 * TEAMS) void decode_attn_mla_ring8_kernel(
     const T* __restrict__ q, const uint8_t* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p, MlaRope rp) {
   constexpr int NH = MLA_D / 64;   // 9 of the 18 score k-steps per wave
   using frag = typename Mfma<T>::frag;
@@ -1852,11 +1865,15 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
   constexpr int P = NSB - 1;       // steps requested ahead of the one being computed
   static_assert(P >= 1 && P <= 3, "the wait below knows 0, 5, 10 or 15 younger loads");
   static_assert(MLA_D == 576 && MLA_RANK == 512, "the step image is laid out for 512 + 64 byte rows");
-  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // m8_lds_bytes(NSB)
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // TEAMS * m8_lds_bytes(NSB)
 
-  const int head0 = blockIdx.x * 16, split = blockIdx.y, b = blockIdx.z;
+  const int head0 = blockIdx.x * 16, b = blockIdx.z;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+  const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);   // within the team
+  const int tid = threadIdx.x & 255;                                         // within the team
+  const int split = blockIdx.y * TEAMS + team;
+  char* sm_team = sm_raw + team * m8_lds_bytes(NSB);
   const int r16 = lane & 15, c4 = lane >> 4;
   const int tile = wave >> 1, half = wave & 1;
 
@@ -1867,6 +1884,17 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const int n_steps = k1 > k0 ? (int)((k1 - k0 + 31) / 32) : 0;
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+  // every team's step count and whether its range ends at the new token: the barriers are shared
+  int n_team[TEAMS], n_all = 0;
+  bool new_team[TEAMS];
+#pragma unroll
+  for (int tt = 0; tt < TEAMS; ++tt) {
+    const int64_t a0 = (int64_t)(blockIdx.y * TEAMS + tt) * chunk;
+    const int64_t a1 = a0 + chunk < len ? a0 + chunk : len;
+    n_team[tt] = a1 > a0 ? (int)((a1 - a0 + 31) / 32) : 0;
+    new_team[tt] = ROPE && a1 == len && len > a0;
+    n_all = n_team[tt] > n_all ? n_team[tt] : n_all;
+  }
 
   // ROPE: threads 0..63 hold eight bytes of the new row's latent part, threads 64..71 (interleaved pairs) or
   // 64..67 (neox pairs: a piece and its partner 32 features on) of its rotated rope part.
@@ -1876,7 +1904,6 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
   if constexpr (ROPE) {
     rope_pos = rp.positions[b];
     if (has_new) {
-      const int tid = threadIdx.x;
       Vec<T, 8> new_a, new_b;
 #pragma unroll
       for (int j = 0; j < 8; ++j) new_a.v[j] = new_b.v[j] = from_f32<T>(0.f);
@@ -1929,7 +1956,7 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
     for (int j = 0; j < 8; ++j) sl.s[j] = pt[key + j < last_key ? key + j : last_key];
     return sl;
   };
-  const unsigned ring = lds_byte_address(sm_raw);
+  const unsigned ring = lds_byte_address(sm_team);
   // load i (0 .. 4) of a step: this lane's piece 64 i + lane of the wave's region = (row, 16-byte chunk)
   int pj[5], poff[5];
   bool pact[5];
@@ -1965,7 +1992,7 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
   // eight keys {4 c4 + (q & 3) + 16 (q >> 2)}
   const int vq = r16 >> 1;
   const int v_rd = m8_row(4 * c4 + (vq & 3) + 16 * (vq >> 2)) + 128 * wave + 8 * (r16 & 1);   // + 16 dt
-  char* xch = sm_raw + NSB * M8_STEP;
+  char* xch = sm_team + NSB * M8_STEP;
 
   Slots s_nxt{};
   if (n_steps > 0) {   // (an empty sequence has no page-table entry to read)
@@ -2015,30 +2042,39 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
     for (int s = 0; s < NH; ++s) asm volatile("" ::"v"(qf[s]));
   }
 
-  for (int t = 0; t < n_steps; ++t) {
-    // this wave's part of step t has landed when at most the loads (5 per step) of the younger steps are out
-    const int younger = min(P - 1, n_steps - 1 - t);
-    if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int t = 0; t < n_all; ++t) {
+    const bool live = t < n_steps;   // (team-uniform; a team that has run out of steps keeps the barriers company)
+    if (live) {
+      // this wave's part of step t has landed when at most the loads (5 per step) of the younger steps are out
+      const int younger = min(P - 1, n_steps - 1 - t);
+      if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its reads of step t - 1 have returned
     __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's image is free
-    if (t + P < n_steps) issue_step(t + P, s_nxt);
-    s_nxt = slots_of(t + P + 1);
-    char* img = sm_raw + (t % NSB) * M8_STEP;
+    if (live) {
+      if (t + P < n_steps) issue_step(t + P, s_nxt);
+      s_nxt = slots_of(t + P + 1);
+    }
+    char* img = sm_team + (t % NSB) * M8_STEP;
     if constexpr (ROPE) {
-      if (has_new && t == n_steps - 1) {
+      bool patch_any = false;   // some team patches the new row into its image in this iteration (workgroup-uniform)
+#pragma unroll
+      for (int tt = 0; tt < TEAMS; ++tt) patch_any |= new_team[tt] && t == n_team[tt] - 1;
+      if (patch_any) {
+       if (has_new && t == n_steps - 1) {
         // the new token is the last key of the last step: its bytes go into the image over what was fetched from
         // the slot (every wave's loads of this step have landed: the barrier above)
         const int kl = (int)(len - 1 - k0) - 32 * t;           // 0 .. 31 inside the step
         char* row = img + m8_row(kl);
-        const int tid = threadIdx.x;
         if (tid < 64) *reinterpret_cast<uint2*>(row + 8 * tid) = new_qa;
         else if (tid < 72 && !rp.is_neox) *reinterpret_cast<uint2*>(row + MLA_RANK + 8 * (tid - 64)) = new_qa;
         else if (tid < 68) {
           *reinterpret_cast<uint2*>(row + MLA_RANK + 8 * (tid - 64)) = new_qa;
           *reinterpret_cast<uint2*>(row + MLA_RANK + MLA_ROPE / 2 + 8 * (tid - 64)) = new_qb;
         }
+       }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
@@ -2047,6 +2083,8 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
     // this wave's partial scores: 16 keys of its tile x 16 heads over its nine feature steps
     // (ds_read_b64 by hand: the compiler pairs these reads into ds_read2_b64, which banks modulo 32 over 16-lane
     // groups -- rows r and r + 8 of the 592-byte image then collide, 32 conflict cycles per wave and step)
+    f32x4* xw = reinterpret_cast<f32x4*>(xch + (t & 1) * 4096);
+    if (live) {
     unsigned long long kraw[NH];
     const unsigned k_addr = lds_byte_address(img + k_rd);
 #pragma unroll
@@ -2059,10 +2097,11 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
 #pragma unroll
     for (int s = 0; s < NH; ++s)
       part = Mfma<T>::run(widen8<T>(uint2{(unsigned)kraw[s], (unsigned)(kraw[s] >> 32)}), qf[s], part);
-    f32x4* xw = reinterpret_cast<f32x4*>(xch + (t & 1) * 4096);
     xw[wave * 64 + lane] = part;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (!live) continue;
     const f32x4 sa = xw[lane] + xw[64 + lane], sb = xw[128 + lane] + xw[192 + lane];
 
     const int64_t kb0 = k0 + (int64_t)t * 32 + 4 * c4;
@@ -2108,11 +2147,40 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
 
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
-  if (head0 + r16 < p.hq) {
+  if constexpr (TEAMS > 1) {
+    // the teams' (reference point, sum, 512-feature accumulators) meet in LDS; team 0 carries the result out
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every team is done with its rings
+    constexpr int TEAM_FLOATS = 4 * 8 * 64 * 4 + 4 * 64 * 2;
+    float* mine = reinterpret_cast<float*>(sm_raw) + (team - 1) * TEAM_FLOATS;
+    if (team > 0) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) reinterpret_cast<f32x4*>(mine)[(wave * 8 + dt) * 64 + lane] = acc[dt];
+      reinterpret_cast<float2*>(mine + 4 * 8 * 64 * 4)[wave * 64 + lane] = float2{m, l};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (team == 0) {
+#pragma unroll
+      for (int tt = 1; tt < TEAMS; ++tt) {
+        const float* other = reinterpret_cast<const float*>(sm_raw) + (tt - 1) * TEAM_FLOATS;
+        const float2 ml = reinterpret_cast<const float2*>(other + 4 * 8 * 64 * 4)[wave * 64 + lane];
+        const float mn = fmaxf(m, ml.x), msn = safe_m(mn);
+        const float a0 = exp2f(m - msn), a1 = exp2f(ml.x - msn);
+        l = l * a0 + ml.y * a1;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+          acc[dt] = acc[dt] * a0 + reinterpret_cast<const f32x4*>(other)[(wave * 8 + dt) * 64 + lane] * a1;
+        m = mn;
+      }
+    }
+  }
+  const int s_out = p.num_splits / TEAMS;   // partials that leave the launch per (sequence, head)
+  if (team == 0 && head0 + r16 < p.hq) {
     const int head = head0 + r16;
     const float inv = l > 0.f ? 1.f / l : 0.f;
     // lane (head r16, c4) holds features 128 wave + 16 dt + 4 c4 .. + 3
-    if (p.num_splits == 1) {
+    if (s_out == 1) {
       T* dst = o + ((int64_t)b * p.hq + head) * MLA_RANK + 128 * wave + 4 * c4;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
@@ -2122,21 +2190,23 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring8_kernel(
         stvec<T, 4>(dst + 16 * dt, w);
       }
     } else {
-      const int64_t ph0 = ((int64_t)b * p.hq + head0) * p.num_splits;
-      const int cell = r16 * p.num_splits + split;
-      const auto rs = wt_rsrc(p.part_o + ph0 * MLA_RANK, 16 * p.num_splits * MLA_RANK * 4);
+      const int64_t ph0 = ((int64_t)b * p.hq + head0) * s_out;
+      const int cell = r16 * s_out + (int)blockIdx.y;
+      const auto rs = wt_rsrc(p.part_o + ph0 * MLA_RANK, 16 * s_out * MLA_RANK * 4);
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[dt] * inv), rs,
                                                (cell * MLA_RANK + 128 * wave + 4 * c4 + 16 * dt) * 4, 0, 16);
       if (c4 == 0 && wave == 0)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l > 0.f ? m * kLn2 + logf(l) : -INFINITY),
-                                              wt_rsrc(p.part_lse + ph0, 16 * p.num_splits * 4), cell * 4, 0, 16);
+                                              wt_rsrc(p.part_lse + ph0, 16 * s_out * 4), cell * 4, 0, 16);
     }
   }
-  if (p.num_splits > 1 && p.tickets) {
+  if (s_out > 1 && p.tickets) {
     const int nheads = p.hq - head0 < 16 ? p.hq - head0 : 16;
-    merge_splits_if_last<T, 4>(p, o, b, head0, nheads, MLA_RANK, b * (int)gridDim.x + (int)blockIdx.x, reinterpret_cast<float*>(sm_raw));
+    DecodeParams po = p;
+    po.num_splits = s_out;
+    merge_splits_if_last<T, 4>(po, o, b, head0, nheads, MLA_RANK, b * (int)gridDim.x + (int)blockIdx.x, reinterpret_cast<float*>(sm_raw));
   }
 }
 
@@ -2802,19 +2872,35 @@ static int decode_attention_mla_impl(const MlaRope* rope, const void* q, const v
     const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)num_splits, (unsigned)bs);
     if (g_decode_variant == 0 && aligned16(kv_buffer) && aligned16(attn_logits) && aligned16(o)) {
       constexpr int NSB_ = 3;
-      if (num_splits > 1 && num_splits <= MERGE_MAX_SPLITS) p.tickets = split_tickets;   // merged inside the launch
+      // two KV splits per workgroup (two teams of four waves) when the halved grid still gives every CU a workgroup
+      const bool two = num_splits % 2 == 0 && (int64_t)grid.x * grid.y * grid.z >= 512 && g_mla_teams != 1;
+      const int s_out = two ? num_splits / 2 : num_splits;
+      const dim3 grid_t(grid.x, (unsigned)s_out, grid.z);
+      if (s_out > 1 && s_out <= MERGE_MAX_SPLITS) p.tickets = split_tickets;   // merged inside the launch
+#define MLR8_GO(T_, KERN_, TEAMS_)                                                                                \
+  do {                                                                                                         \
+    auto kern = KERN_;                                                                                         \
+    const int lds_ = TEAMS_ * m8_lds_bytes(NSB_);                                                              \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
+    hipLaunchKernelGGL(kern, grid_t, dim3(256 * TEAMS_), lds_, st, (const T_*)q, (const uint8_t*)kv_buffer,    \
+                       (T_*)o, p, rope ? *rope : MlaRope{});                                                   \
+  } while (0)
 #define MLR8_LAUNCH(T_, CAP_)                                                                                  \
   do {                                                                                                         \
-    auto kern = rope ? decode_attn_mla_ring8_kernel<T_, CAP_, NSB_, true> : decode_attn_mla_ring8_kernel<T_, CAP_, NSB_>; \
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m8_lds_bytes(NSB_)); \
-    hipLaunchKernelGGL(kern, grid, dim3(256), m8_lds_bytes(NSB_), st, (const T_*)q, (const uint8_t*)kv_buffer,   \
-                       (T_*)o, p, rope ? *rope : MlaRope{});                                                   \
-    if (num_splits > 1 && !p.tickets)                                                                          \
+    if (two) {                                                                                                 \
+      if (rope) MLR8_GO(T_, (decode_attn_mla_ring8_kernel<T_, CAP_, NSB_, true, 2>), 2);                           \
+      else MLR8_GO(T_, (decode_attn_mla_ring8_kernel<T_, CAP_, NSB_, false, 2>), 2);                               \
+    } else {                                                                                                   \
+      if (rope) MLR8_GO(T_, (decode_attn_mla_ring8_kernel<T_, CAP_, NSB_, true, 1>), 1);                           \
+      else MLR8_GO(T_, (decode_attn_mla_ring8_kernel<T_, CAP_, NSB_, false, 1>), 1);                               \
+    }                                                                                                          \
+    if (s_out > 1 && !p.tickets)                                                                               \
       hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
-                         p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
+                         p.part_lse, (T_*)o, s_out, kv_lora_rank);                                             \
   } while (0)
       if (dtype == MI355_BF16) { if (logit_cap > 0.f) MLR8_LAUNCH(bf16_t, true); else MLR8_LAUNCH(bf16_t, false); }
       else { if (logit_cap > 0.f) MLR8_LAUNCH(f16_t, true); else MLR8_LAUNCH(f16_t, false); }
+#undef MLR8_GO
 #undef MLR8_LAUNCH
       MI355_CHECK_LAUNCH("decode_attention_mla");
       return MI355_OK;

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(
 #ifdef MI355_DEV_BUILD
 extern int g_decode_variant;
 extern int g_extend_variant;
+extern int g_mla_teams;
 int g_gemm_variant = 0;
 int g_force_splits = 0;
 #else
@@ -850,6 +851,7 @@ void mi355_debug_set(int key, int value) {
   if (key == 4) g_force_waves = value;    // 4 | 6 | 7 | 8 overrides the tiles-per-workgroup plan
   if (key == 6) g_decode_variant = value; // decode attention: 0 = product, 1 = P.V on the vector ALU, 3 = K rows straight into fragments
   if (key == 8) g_extend_variant = value; // prefill attention: 0 = 32x32x16 tile (product), 1 = 16x16x32 tile
+  if (key == 10) g_mla_teams = value;     // MLA decode rings: 0 = two KV splits per workgroup when the grid allows (product), 1 = one
 }
 #endif
 

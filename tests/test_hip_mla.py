@@ -670,3 +670,78 @@ def test_mla_absorb_refuses_what_it_does_not_serve():
         ops.mla_absorb(a[:4, :, :120], torch.zeros(2, 512, 120, dtype=torch.bfloat16, device=DEV))
     assert not ops.mla_absorb_supported(65, 512, 128, 64, torch.bfloat16)
     assert not ops.mla_absorb_supported(8, 512, 128, 64, torch.float32)
+
+
+@pytest.mark.parametrize("bs,splits,fused_rope", [(128, 4, False), (256, 2, False), (128, 4, True), (64, 8, True)])
+def test_mla_fp8_ring_two_splits_per_workgroup_on_ragged_batches(bs, splits, fused_rope):
+    """Launches of at least 512 workgroups run the fp8 ring with TWO KV splits per workgroup (two teams of four waves
+    whose results meet in LDS).  Ragged lengths: sequences shorter than one step (the second team of a workgroup has
+    nothing to do), lengths around the 32-key step and 16-key tile edges, the new token in either team.  Every
+    sequence against float64 attention over the widened rows; the in-launch merge bit for bit the merge launch; with
+    RoPE + row write inside the launch bit for bit rope -> scatter -> decode, outputs and cache bytes."""
+    from sglang_custom_amd import ops
+
+    H, rank, rope = 16, 512, 64
+    D = rank + rope
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(bs * 10 + splits)
+    lens = torch.randint(1, 301, (bs,), generator=g).tolist()
+    lens[:10] = [1, 2, 15, 16, 17, 31, 32, 33, 64, 65]
+    total = sum(lens)
+    rows16 = (torch.randn(total + 1, 1, D, generator=g) * 2.0).to(dt).to(DEV)
+    cache0 = torch.zeros((total + 1, 1, D), dtype=torch.float8_e4m3fn, device=DEV)
+    ops.set_kv_buffer(cache0, cache0, torch.arange(total + 1, dtype=torch.int64, device=DEV), rows16, rows16)
+    r2t = torch.zeros((bs, max(lens)), dtype=torch.int32)
+    perm = torch.randperm(total, generator=g) + 1
+    pos = 0
+    for b, n in enumerate(lens):
+        r2t[b, :n] = perm[pos: pos + n].int()
+        pos += n
+    r2t = r2t.to(DEV)
+    rpi = torch.arange(bs, dtype=torch.int64, device=DEV)
+    lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    q = torch.randn(bs, H, D, generator=g).to(dt).to(DEV)
+    scale = D ** -0.5
+    lg = torch.empty(bs * H * splits * rank, dtype=torch.float32, device=DEV)
+    ls = torch.empty(bs * H * splits, dtype=torch.float32, device=DEV)
+    tickets = torch.zeros(bs * H, dtype=torch.int32, device=DEV)
+    if not fused_rope:
+        cache, q_used = cache0, q
+        got = torch.full((bs, H, rank), float("nan"), dtype=dt, device=DEV)
+        ops.decode_attention_mla(q, cache, got, r2t, rpi, lt, lg, ls, splits, rank, scale, tickets=tickets)
+        again = torch.full_like(got, float("nan"))
+        ops.decode_attention_mla(q, cache, again, r2t, rpi, lt, lg, ls, splits, rank, scale)      # merge launch
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), again.view(torch.int16)) and not tickets.any()
+    else:
+        loc = torch.stack([r2t[b, n - 1] for b, n in enumerate(lens)]).to(torch.int64)
+        positions = (lt - 1).clone()
+        k_nope = torch.randn(bs, rank, generator=g).to(dt).to(DEV)
+        k_pe_raw = torch.randn(bs, rope, generator=g).to(dt).to(DEV)
+        cs = torch.cat([torch.randn(512, rope // 2, generator=g).cos(), torch.randn(512, rope // 2, generator=g).sin()], dim=1).to(DEV).contiguous()
+        q_used = q.clone()
+        q_pe = q_used[..., rank:].contiguous().view(bs, -1)
+        k_pe = k_pe_raw.clone()
+        ops.rope_inplace(positions, q_pe, k_pe, rope, cs, False)
+        q_used[..., rank:] = q_pe.view(bs, H, rope)
+        cache = cache0.clone()
+        row = torch.cat([k_nope, k_pe], dim=-1).view(bs, 1, D)
+        ops.set_kv_buffer(cache, cache, loc, row, row)
+        want = torch.full((bs, H, rank), float("nan"), dtype=dt, device=DEV)
+        ops.decode_attention_mla(q_used, cache, want, r2t, rpi, lt, lg, ls, splits, rank, scale, tickets=tickets)
+        cache_f = cache0.clone()
+        got = torch.full_like(want, float("nan"))
+        ops.decode_attention_mla_fused_rope(q, k_nope, k_pe_raw, positions, loc, cs, False, cache_f, got, r2t, rpi, lt, lg, ls,
+                                            splits, rank, scale, tickets=tickets)
+        torch.cuda.synchronize()
+        assert torch.equal(cache_f.view(torch.uint8), cache.view(torch.uint8)), "cache rows differ"
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)) and not tickets.any()
+    assert not torch.isnan(got.float()).any()
+    wide = cache.float()
+    worst = 0.0
+    for b, nkeys in enumerate(lens):
+        kv = wide[r2t[b, :nkeys].long(), 0].double()
+        ref = torch.softmax((q_used[b].double() @ kv.t()) * scale, -1) @ kv[:, :rank]
+        err = (got[b].double() - ref).abs().max().item() / max(ref.abs().max().item(), 1.0)
+        worst = max(worst, err)
+        assert err <= 2e-2, (b, nkeys, err)
