@@ -1404,6 +1404,13 @@ __global__ __launch_bounds__(256) void decode_attn_mla_mfma_kernel(const T* __re
 // A wave issues 5 loads per tile: rows 4 w .. 4 w + 3 (1 KiB each) and their rope parts (half a wave).
 // grid (ceil(hq / 16), num_splits, B), block 256.
 // ------------------------------------------------------------------------------------------
+// 0 = plan (two teams per workgroup when the grid allows), 1 = one team (ablation; development build, mi355_debug_set key 10)
+#ifdef MI355_DEV_BUILD
+int g_mla_teams = 0;
+#else
+static constexpr int g_mla_teams = 0;
+#endif
+
 constexpr int MLR_ROWB = 1056;                       // bytes between rows' latent parts
 constexpr int MLR_TAIL = 16 * MLR_ROWB;              // byte offset of the rope parts
 constexpr int MLR_TILE = MLR_TAIL + 16 * 128;        // 18944
@@ -1484,19 +1491,26 @@ template <typename T> __device__ __forceinline__ float mla_cs_t(const MlaRope& r
 // latent row to the cache (one workgroup per sequence) and -- in every workgroup whose key range ends at the
 // new token -- puts that row into the LDS tile over whatever the load unit fetched from the not yet written
 // slot.  Same bits as mi355_rope_inplace + mi355_set_kv_buffer + this kernel without ROPE.
-template <typename T, bool CAP, int NSB, bool ROPE = false>
-__global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
+// TEAMS = 2: two teams of four waves per workgroup, each with its own ring, on two consecutive KV splits of the
+// launch's plan; their results meet in LDS and ONE partial leaves the workgroup (see the fp8 ring kernel below:
+// what a launch pays for its splits is the merge of S partials of 16 heads x 512 features).  grid.y = num_splits / TEAMS.
+template <typename T, bool CAP, int NSB, bool ROPE = false, int TEAMS = 1>
+__global__ __launch_bounds__(256 * TEAMS) void decode_attn_mla_ring_kernel(
     const T* __restrict__ q, const T* __restrict__ kvbuf, T* __restrict__ o, DecodeParams p, MlaRope rp) {
   constexpr int NS = MLA_D / 32;   // 18 score k-steps
   using frag = typename Mfma<T>::frag;
   using frag4 = typename Mfma16<T>::frag;
   constexpr int P = NSB - 1;   // steps requested ahead of the one being computed
   static_assert(P >= 1 && P <= 3, "the wait below knows 0, 10 or 20 younger loads");
-  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // mlr_lds_bytes(NSB)
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];   // TEAMS * mlr_lds_bytes(NSB)
 
-  const int head0 = blockIdx.x * 16, split = blockIdx.y, b = blockIdx.z;
+  const int head0 = blockIdx.x * 16, b = blockIdx.z;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+  const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);   // within the team
+  const int tid = threadIdx.x & 255;                                         // within the team
+  const int split = blockIdx.y * TEAMS + team;
+  char* sm_team = sm_raw + team * mlr_lds_bytes(NSB);
   const int r16 = lane & 15, c4 = lane >> 4;
 
   int64_t page_off, len;
@@ -1506,6 +1520,17 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
   const int64_t k1 = k0 + chunk < len ? k0 + chunk : len;
   const int n_steps = k1 > k0 ? (int)((k1 - k0 + 31) / 32) : 0;   // 32 keys (two tiles) per step
   const float qmul = CAP ? p.sm_scale : p.sm_scale * kLog2e;
+  // every team's step count and whether its range ends at the new token: the barriers are shared
+  int n_team[TEAMS], n_all = 0;
+  bool new_team[TEAMS];
+#pragma unroll
+  for (int tt = 0; tt < TEAMS; ++tt) {
+    const int64_t a0 = (int64_t)(blockIdx.y * TEAMS + tt) * chunk;
+    const int64_t a1 = a0 + chunk < len ? a0 + chunk : len;
+    n_team[tt] = a1 > a0 ? (int)((a1 - a0 + 31) / 32) : 0;
+    new_team[tt] = ROPE && a1 == len && len > a0;
+    n_all = n_team[tt] > n_all ? n_team[tt] : n_all;
+  }
 
   // ROPE: threads 0..63 hold one 16-byte piece of the new row's latent part, threads 64..71 (interleaved
   // pairs) or 64..67 (neox pairs: a piece and its partner 32 features on) its rotated rope part.
@@ -1515,7 +1540,6 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
   if constexpr (ROPE) {
     rope_pos = rp.positions[b];
     if (has_new) {
-      const int tid = threadIdx.x;
       if (tid < 64) {
         new_a = ldvec<T, 8>(static_cast<const T*>(rp.k_nope) + (int64_t)b * rp.k_nope_stride + 8 * tid);
       } else if (tid < 72) {
@@ -1562,7 +1586,7 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
     return Slots{slot_of(key), slot_of(key + 1), slot_of(key + 2), slot_of(key + 3),
                  slot_of(key + 16), slot_of(key + 17), slot_of(key + 18), slot_of(key + 19)};
   };
-  const unsigned ring = lds_byte_address(sm_raw);
+  const unsigned ring = lds_byte_address(sm_team);
   const uint64_t kv_base = (uint64_t)(uintptr_t)kvbuf;
   const uint64_t row_bytes = (uint64_t)p.k_slot_stride * sizeof(T);
   const unsigned lane16 = 16u * lane;
@@ -1724,46 +1748,85 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
   };
 
   {
-    for (int t = 0; t < n_steps; ++t) {
-      // this wave's part of step t has landed when at most the loads (10 per step) of the younger steps are out
-      const int younger = min(P - 1, n_steps - 1 - t);
-      if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = 0; t < n_all; ++t) {
+      const bool live = t < n_steps;   // (team-uniform; a team that has run out of steps keeps the barriers company)
+      if (live) {
+        // this wave's part of step t has landed when at most the loads (10 per step) of the younger steps are out
+        const int younger = min(P - 1, n_steps - 1 - t);
+        if (P >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (P >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its reads of step t - 1 have returned
       __builtin_amdgcn_s_barrier();                         // every wave's part of step t is in LDS; step t - 1's tiles are free
-      if (t + P < n_steps) issue_step(t + P, s_nxt);
-      s_nxt = slots_of(t + P + 1);
+      if (live) {
+        if (t + P < n_steps) issue_step(t + P, s_nxt);
+        s_nxt = slots_of(t + P + 1);
+      }
       if constexpr (ROPE) {
-        if (has_new && t == n_steps - 1) {
-          // the new token is the last key of the last step: its row goes into the tile over what was fetched
-          // from the slot (every wave's loads of this step have landed: the barrier above)
-          const int kl = (int)(len - 1 - k0) - 32 * t;           // 0 .. 31 inside the step
-          char* row_tile = sm_raw + (2 * (t % NSB) + (kl >> 4)) * MLR_TILE;
-          const int r = kl & 15, tid = threadIdx.x;
-          if (tid < 64) {
-            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_ROWB * r + 16 * tid) = new_a;
-          } else if (tid < 72 && !rp.is_neox) {
-            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 64) ^ ((r >> 1) & 7))) = new_a;
-          } else if (tid < 68) {
-            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 64) ^ ((r >> 1) & 7))) = new_a;
-            *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 60) ^ ((r >> 1) & 7))) = new_b;
+        bool patch_any = false;   // some team patches the new row into its tile in this iteration (workgroup-uniform)
+#pragma unroll
+        for (int tt = 0; tt < TEAMS; ++tt) patch_any |= new_team[tt] && t == n_team[tt] - 1;
+        if (patch_any) {
+          if (has_new && t == n_steps - 1) {
+            // the new token is the last key of the last step: its row goes into the tile over what was fetched
+            // from the slot (every wave's loads of this step have landed: the barrier above)
+            const int kl = (int)(len - 1 - k0) - 32 * t;           // 0 .. 31 inside the step
+            char* row_tile = sm_team + (2 * (t % NSB) + (kl >> 4)) * MLR_TILE;
+            const int r = kl & 15;
+            if (tid < 64) {
+              *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_ROWB * r + 16 * tid) = new_a;
+            } else if (tid < 72 && !rp.is_neox) {
+              *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 64) ^ ((r >> 1) & 7))) = new_a;
+            } else if (tid < 68) {
+              *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 64) ^ ((r >> 1) & 7))) = new_a;
+              *reinterpret_cast<Vec<T, 8>*>(row_tile + MLR_TAIL + 128 * r + 16 * ((tid - 60) ^ ((r >> 1) & 7))) = new_b;
+            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
         }
       }
-      step_compute(t, sm_raw + 2 * (t % NSB) * MLR_TILE);
+      if (live) step_compute(t, sm_team + 2 * (t % NSB) * MLR_TILE);
     }
   }
 
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
-  if (head0 + r16 < p.hq) {
+  if constexpr (TEAMS > 1) {
+    // the teams' (reference point, sum, 512-feature accumulators) meet in LDS; team 0 carries the result out
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every team is done with its rings
+    constexpr int TEAM_FLOATS = 4 * 8 * 64 * 4 + 4 * 64 * 2;
+    float* mine = reinterpret_cast<float*>(sm_raw) + (team - 1) * TEAM_FLOATS;
+    if (team > 0) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) reinterpret_cast<f32x4*>(mine)[(wave * 8 + dt) * 64 + lane] = acc[dt];
+      reinterpret_cast<float2*>(mine + 4 * 8 * 64 * 4)[wave * 64 + lane] = float2{m, l};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (team == 0) {
+#pragma unroll
+      for (int tt = 1; tt < TEAMS; ++tt) {
+        const float* other = reinterpret_cast<const float*>(sm_raw) + (tt - 1) * TEAM_FLOATS;
+        const float2 ml = reinterpret_cast<const float2*>(other + 4 * 8 * 64 * 4)[wave * 64 + lane];
+        const float mn = fmaxf(m, ml.x), msn = safe_m(mn);
+        const float a0 = exp2f(m - msn), a1 = exp2f(ml.x - msn);
+        l = l * a0 + ml.y * a1;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+          acc[dt] = acc[dt] * a0 + reinterpret_cast<const f32x4*>(other)[(wave * 8 + dt) * 64 + lane] * a1;
+        m = mn;
+      }
+    }
+  }
+  const int s_out = p.num_splits / TEAMS;   // partials that leave the launch per (sequence, head)
+  if (team == 0 && head0 + r16 < p.hq) {
     const int head = head0 + r16;
     const float inv = l > 0.f ? 1.f / l : 0.f;
     // lane (head r16, c4) holds features 128 wave + 16 dt + 4 c4 .. + 3
-    if (p.num_splits == 1) {
+    if (s_out == 1) {
       T* dst = o + ((int64_t)b * p.hq + head) * MLA_RANK + 128 * wave + 4 * c4;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
@@ -1775,21 +1838,23 @@ __global__ __launch_bounds__(256) void decode_attn_mla_ring_kernel(
     } else {
       // write-through, so that the workgroup that merges the splits (below) sees them without a fence
       // (the resources start at the workgroup's first head: wave-uniform; the lane adds its head and features)
-      const int64_t ph0 = ((int64_t)b * p.hq + head0) * p.num_splits;
-      const int cell = r16 * p.num_splits + split;
-      const auto rs = wt_rsrc(p.part_o + ph0 * MLA_RANK, 16 * p.num_splits * MLA_RANK * 4);
+      const int64_t ph0 = ((int64_t)b * p.hq + head0) * s_out;
+      const int cell = r16 * s_out + (int)blockIdx.y;
+      const auto rs = wt_rsrc(p.part_o + ph0 * MLA_RANK, 16 * s_out * MLA_RANK * 4);
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[dt] * inv), rs,
                                                (cell * MLA_RANK + 128 * wave + 4 * c4 + 16 * dt) * 4, 0, 16);
       if (c4 == 0 && wave == 0)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l > 0.f ? m * kLn2 + logf(l) : -INFINITY),
-                                              wt_rsrc(p.part_lse + ph0, 16 * p.num_splits * 4), cell * 4, 0, 16);
+                                              wt_rsrc(p.part_lse + ph0, 16 * s_out * 4), cell * 4, 0, 16);
     }
   }
-  if (p.num_splits > 1 && p.tickets) {
+  if (s_out > 1 && p.tickets) {
     const int nheads = p.hq - head0 < 16 ? p.hq - head0 : 16;
-    merge_splits_if_last<T, 4>(p, o, b, head0, nheads, MLA_RANK, b * (int)gridDim.x + (int)blockIdx.x, reinterpret_cast<float*>(sm_raw));
+    DecodeParams po = p;
+    po.num_splits = s_out;
+    merge_splits_if_last<T, 4>(po, o, b, head0, nheads, MLA_RANK, b * (int)gridDim.x + (int)blockIdx.x, reinterpret_cast<float*>(sm_raw));
   }
 }
 
@@ -1838,13 +1903,6 @@ template <typename T> __device__ __forceinline__ typename Mfma<T>::frag widen8(u
                Fp8Widen<T>::run((int)raw.y, false), Fp8Widen<T>::run((int)raw.y, true)};
   return __builtin_bit_cast(typename Mfma<T>::frag, q);
 }
-
-// 0 = plan (two teams per workgroup when the grid allows), 1 = one team (ablation; development build, mi355_debug_set key 10)
-#ifdef MI355_DEV_BUILD
-int g_mla_teams = 0;
-#else
-static constexpr int g_mla_teams = 0;
-#endif
 
 // ROPE: as in the 16-bit ring kernel -- the query's rope part is rotated in registers (the waves that own feature
 // steps 16 and 17), the new token's row [k_nope | rope(k_pe)] is built, quantised with the scatter kernel's
@@ -2926,21 +2984,32 @@ static int decode_attention_mla_impl(const MlaRope* rope, const void* q, const v
     if ((g_decode_variant == 0 || g_decode_variant == 5) && aligned16(attn_logits)) {   // rows through the LDS ring (2 = the register kernel, 5 = the deep ring, for ablation)
       constexpr int NSB_ = 2;
       const bool deep = g_decode_variant == 5;
-      if (num_splits > 1 && num_splits <= MERGE_MAX_SPLITS && aligned16(o)) p.tickets = split_tickets;   // this kernel merges the splits itself
+      // two KV splits per workgroup (two teams of four waves) when the halved grid still gives every CU a workgroup
+      const bool two = !deep && num_splits % 2 == 0 && (int64_t)grid.x * grid.y * grid.z >= 512 && g_mla_teams != 1;
+      const int s_out = two ? num_splits / 2 : num_splits;
+      const dim3 grid_t(grid.x, (unsigned)s_out, grid.z);
+      if (s_out > 1 && s_out <= MERGE_MAX_SPLITS && aligned16(o)) p.tickets = split_tickets;   // this kernel merges the splits itself
+#define MLR_GO(T_, KERN_, LDS_, THREADS_)                                                                      \
+  do {                                                                                                         \
+    auto kern = KERN_;                                                                                         \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);            \
+    hipLaunchKernelGGL(kern, grid_t, dim3(THREADS_), LDS_, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p,  \
+                       rope ? *rope : MlaRope{});                                                              \
+  } while (0)
 #define MLR_LAUNCH(T_, CAP_)                                                                                   \
   do {                                                                                                         \
-    auto kern = rope ? decode_attn_mla_ring_kernel<T_, CAP_, NSB_, true>                                       \
-                     : deep ? decode_attn_mla_ring_kernel<T_, CAP_, 4> : decode_attn_mla_ring_kernel<T_, CAP_, NSB_>; \
-    const int lds_ = deep && !rope ? mlr_lds_bytes(4) : mlr_lds_bytes(NSB_);                                   \
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_, st, (const T_*)q, (const T_*)kv_buffer, (T_*)o, p,         \
-                       rope ? *rope : MlaRope{});                                                              \
-    if (num_splits > 1 && !p.tickets)                                                                          \
+    if (two && rope) MLR_GO(T_, (decode_attn_mla_ring_kernel<T_, CAP_, NSB_, true, 2>), 2 * mlr_lds_bytes(NSB_), 512); \
+    else if (two) MLR_GO(T_, (decode_attn_mla_ring_kernel<T_, CAP_, NSB_, false, 2>), 2 * mlr_lds_bytes(NSB_), 512);   \
+    else if (rope) MLR_GO(T_, (decode_attn_mla_ring_kernel<T_, CAP_, NSB_, true>), mlr_lds_bytes(NSB_), 256);  \
+    else if (deep) MLR_GO(T_, (decode_attn_mla_ring_kernel<T_, CAP_, 4>), mlr_lds_bytes(4), 256);              \
+    else MLR_GO(T_, (decode_attn_mla_ring_kernel<T_, CAP_, NSB_>), mlr_lds_bytes(NSB_), 256);                  \
+    if (s_out > 1 && !p.tickets)                                                                               \
       hipLaunchKernelGGL((decode_merge_kernel<T_>), dim3((unsigned)(bs * hq)), dim3(128), 0, st, p.part_o,     \
-                         p.part_lse, (T_*)o, num_splits, kv_lora_rank);                                        \
+                         p.part_lse, (T_*)o, s_out, kv_lora_rank);                                             \
   } while (0)
       if (dtype == MI355_BF16) { if (logit_cap > 0.f) MLR_LAUNCH(bf16_t, true); else MLR_LAUNCH(bf16_t, false); }
       else { if (logit_cap > 0.f) MLR_LAUNCH(f16_t, true); else MLR_LAUNCH(f16_t, false); }
+#undef MLR_GO
 #undef MLR_LAUNCH
       MI355_CHECK_LAUNCH("decode_attention_mla");
       return MI355_OK;
