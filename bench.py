@@ -111,6 +111,16 @@ def spawn_ranks(n: int) -> int:
 
 def weight_bytes_per_step(cfg, tp, dtype_bytes, quant):
     """Bytes of every matmul weight touched once per decode step on one GPU (layers + LM head)."""
+    if "kv_lora_rank" in cfg:   # multi-head latent attention (dense DeepSeek layers)
+        h, H = cfg["hidden_size"], cfg["num_attention_heads"] // tp
+        qr, kr, rope = cfg.get("q_lora_rank") or 0, cfg["kv_lora_rank"], cfg["qk_rope_head_dim"]
+        nope, vd = cfg["qk_nope_head_dim"], cfg["v_head_dim"]
+        inter, vocab, L = cfg["intermediate_size"] // tp, cfg["vocab_size"] // tp, cfg["num_hidden_layers"]
+        a_proj = (qr + kr + rope) * h + H * (nope + rope) * qr if qr else H * (nope + rope) * h + (kr + rope) * h
+        per_layer = a_proj + h * H * vd + 3 * inter * h
+        absorbed = H * (nope + vd) * kr   # w_kc / w_vc: kv_b_proj folded into q and out of the attention output, 16-bit
+        wb = 1 if quant == "w8a8_fp8" else dtype_bytes
+        return L * (per_layer * wb + absorbed * dtype_bytes) + vocab * h * dtype_bytes, L * (per_layer + absorbed) + vocab * h
     h, d = cfg["hidden_size"], cfg["head_dim"]
     hq, hkv = cfg["num_attention_heads"] // tp, max(1, cfg["num_key_value_heads"] // tp)
     inter, vocab, L = cfg["intermediate_size"] // tp, cfg["vocab_size"] // tp, cfg["num_hidden_layers"]
@@ -412,7 +422,10 @@ def main():
     wbytes, _ = weight_bytes_per_step(cfg, tp, dtype_bytes, args.quantization)
     mean_ctx = in_len + args.warmup + (args.steps + 1) / 2.0
     kv_bytes = 1 if args.kv_cache_dtype == "fp8_e4m3" else dtype_bytes
-    kv_tok = 2 * max(1, cfg["num_key_value_heads"] // tp) * cfg["head_dim"] * cfg["num_hidden_layers"] * kv_bytes
+    if "kv_lora_rank" in cfg:   # one latent row per token and layer, shared by all heads and ranks
+        kv_tok = (cfg["kv_lora_rank"] + cfg["qk_rope_head_dim"]) * cfg["num_hidden_layers"] * kv_bytes
+    else:
+        kv_tok = 2 * max(1, cfg["num_key_value_heads"] // tp) * cfg["head_dim"] * cfg["num_hidden_layers"] * kv_bytes
     bytes_step = wbytes + bs * mean_ctx * kv_tok + bs * kv_tok
     step_gbs = bytes_step / (ms_per_step * 1e-3) / 1e9
 
@@ -451,7 +464,8 @@ def main():
                               "ranks": world, "all_reduces_per_step": n_ar,
                               "all_reduce_message_bytes": bs * cfg["hidden_size"] * dtype_bytes,
                               "all_gather_bytes_per_rank": bs * (cfg["vocab_size"] // tp) * dtype_bytes}
-    if rank == 0 and not args.no_roofline:
+    mla = "kv_lora_rank" in cfg   # the per-kernel roofline and the CPU port below are written for the Llama layer
+    if rank == 0 and not args.no_roofline and not mla:
         # rank 0's shard: the projection kernels launch no collective, so measuring on one rank is safe
         k = measure_dominant_kernel(mr, bs, cfg, tp, dtype_bytes, args.quantization)
         traffic, traffic_src = committed_pmc_traffic(k["kernel"], args.quantization) if tp == 1 else (None, None)
@@ -461,7 +475,7 @@ def main():
                            "avg_duration_us": round(k["avg_duration_us"], 2),
                            "bytes_per_launch": int(k["bytes_per_launch"]),
                            "launches_per_step": k["launches_per_step"]}
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not mla:
         del mr
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(cfg, bs, in_len + args.warmup + args.steps // 2,
