@@ -70,6 +70,12 @@ DEEPSEEK_PRESETS = {
         hidden_size=7168, num_hidden_layers=4, num_attention_heads=128, q_lora_rank=1536, kv_lora_rank=512,
         qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=18432, vocab_size=129280,
         rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192, rope_scaling=_YARN_V3),
+    # ONE dense layer of DeepSeek-V3 at its real attention / MLP shapes (all 128 heads) under a small vocabulary:
+    # small enough for a CPU oracle, for end-to-end checks at the real shapes
+    "deepseek-v3-dense1-vocab2k": dict(
+        hidden_size=7168, num_hidden_layers=1, num_attention_heads=128, q_lora_rank=1536, kv_lora_rank=512,
+        qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=18432, vocab_size=2048,
+        rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192, rope_scaling=_YARN_V3),
     "tiny-deepseek-yarn": dict(
         hidden_size=512, num_hidden_layers=2, num_attention_heads=16, q_lora_rank=192, kv_lora_rank=512,
         qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, intermediate_size=1024, vocab_size=2048,
