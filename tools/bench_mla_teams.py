@@ -18,7 +18,7 @@ def timeit(fn, reps=8):
     for _ in range(3): g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (3 * reps) * 1e3
-for ctx in (64, 1024, 4096, 8192):
+for ctx in [int(a) for a in sys.argv[1:]] or (64, 1024, 4096, 8192):
     kv = [torch.randn(bs * ctx + 16, 1, D, device='cuda').bfloat16() for _ in range(3)]
     kv8 = [(t.float() * 2).to(torch.float8_e4m3fn) for t in kv]
     q = torch.randn(bs, H, D, device='cuda').bfloat16()
