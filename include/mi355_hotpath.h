@@ -367,6 +367,21 @@ int mi355_mla_absorb(void* out, const void* a, const void* w_t, int64_t m, int h
                      int64_t a_row_stride, int64_t a_head_stride, int64_t out_row_stride, int64_t out_head_stride,
                      int dtype, void* stream);
 
+/* mi355_mla_prefill_assemble: the glue of MLA's multi-head prefill in one launch.  In place: q [tokens, heads, nope +
+ * rope] (row stride q_stride) gets its rope part rotated at positions[t].  Out: k [tokens, heads, nope + rope] =
+ * [kv's nope part | rope(k_pe[t])] and v [tokens, heads, v_dim] (both dense) from kv [tokens, heads, nope + v_dim]
+ * (kv_b_proj's output, dense); the latent row [c_kv[t] (kv_lora_rank, the normed latent) | rope(k_pe[t])] is written to
+ * kv_cache[out_cache_loc[t]] (16-bit rows, or e4m3fn with mi355_set_kv_buffer's arithmetic under dtype | MI355_KV_FP8).
+ * cos_sin_cache [max_pos, rope]: cos | sin, fp32 or the tensor dtype; interleaved pairs, or neox pairs when is_neox.
+ * Same bits as mi355_rope_inplace on (q rope part, k_pe) + the copies + mi355_set_kv_buffer.
+ * replaces: the rotary_emb call, the k / v assembly and set_kv_buffer of DeepseekV2AttentionMLA.forward_normal
+ *           (python/sglang/srt/models/deepseek_v2.py:1131-1179). */
+int mi355_mla_prefill_assemble(void* q, void* k, void* v, const void* kv, const void* k_pe, int64_t k_pe_stride,
+                               const void* c_kv, int64_t c_kv_stride, const int64_t* positions, const void* cos_sin_cache,
+                               int cache_dtype, int is_neox, void* kv_cache, const int64_t* out_cache_loc, int64_t tokens,
+                               int heads, int nope_dim, int rope_dim, int v_dim, int kv_lora_rank, int64_t q_stride,
+                               int64_t num_slots, int dtype, void* stream);
+
 /* ---- K12/K13 dense projection y = x @ W^T ------------------------------------------------------
  * x [M, K] (row stride x_stride), W [N, K] contiguous (nn.Linear layout), y [M, N] contiguous.
  * M <= 64 uses the weight-streaming MFMA kernel (bf16/f16); fp32 uses an exact-fp32 tiled kernel

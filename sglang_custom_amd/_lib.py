@@ -48,6 +48,7 @@ _SIGNATURES = {
     "mi355_extend_attention_mla": (I, [P, P, P, P, P, P, P, L, L, L, I, I, I, L, L, F, F, I, P]),
     "mi355_mla_latent_norms": (I, [P, P, P, P, L, P, I, P, P, P, P, P, P, L, I, I, I, F, I, P]),
     "mi355_mla_absorb": (I, [P, P, P, L, I, I, I, I, L, L, L, L, I, P]),
+    "mi355_mla_prefill_assemble": (I, [P, P, P, P, P, L, P, L, P, P, I, I, P, P, L, I, I, I, I, I, L, L, I, P]),
     "mi355_linear_packed": (I, [P, P, P, P, L, L, L, L, P, L, I, I, P]),
     "mi355_linear_packed_silu_mul": (I, [P, P, P, L, L, L, L, P, L, I, P]),
     "mi355_linear_tiled_supported": (I, [L, L, L, I, I]),

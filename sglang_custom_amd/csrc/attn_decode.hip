@@ -1472,16 +1472,6 @@ struct MlaRope {
   int cache_f32, is_neox;
 };
 
-// One rotation pair with the rounding points of rope_kernel (cos, sin -> T; every product and the sum /
-// difference round to T on their own).
-template <typename T>
-__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float sn, T& o1, T& o2) {
-#pragma clang fp contract(off)
-  c = round_to<T>(c);
-  sn = round_to<T>(sn);
-  o1 = from_f32<T>(round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * sn)));
-  o2 = from_f32<T>(round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * sn)));
-}
 template <typename T> __device__ __forceinline__ float mla_cs_t(const MlaRope& rp, int64_t pos, int idx) {
   return rp.cache_f32 ? static_cast<const float*>(rp.cos_sin)[pos * MLA_ROPE + idx]
                       : to_f32(static_cast<const T*>(rp.cos_sin)[pos * MLA_ROPE + idx]);

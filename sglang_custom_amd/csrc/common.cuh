@@ -288,6 +288,16 @@ template <> struct Mfma<f16_t> {
   }
 };
 
+// One rotation pair with the rounding points of rope_kernel (cos, sin -> T; every product and the sum /
+// difference round to T on their own).
+template <typename T>
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float sn, T& o1, T& o2) {
+#pragma clang fp contract(off)
+  c = round_to<T>(c);
+  sn = round_to<T>(sn);
+  o1 = from_f32<T>(round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * sn)));
+  o2 = from_f32<T>(round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * sn)));
+}
 // ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x 16 columns of 16-bit elements, delivered
 // column-major -- lane i of the group receives column i of the four rows.  Lane 4 q + pp supplies
 // the address of row q, columns 4 pp .. 4 pp + 3 (8-byte aligned).  EXEC must be all ones.

@@ -192,6 +192,70 @@ static void launch_absorb(void* out, const void* a, const void* w_t, int m, int 
 #undef LAUNCH
 }
 
+// ------------------------------------------------------------------------------------------
+// The glue of MLA's multi-head prefill (deepseek_v2.py:1131-1179) as one launch, one workgroup per token:
+// rotate q's rope part in place and the token's k_pe (interleaved or neox pairs, the rounding of rope_kernel),
+// assemble k [T, H, nope + rope] = [kv's nope part | roped k_pe] and v [T, H, vd] from kv_b_proj's output
+// kv [T, H, nope + vd], and write the latent row [normed c_kv | roped k_pe] to the cache slot of the token
+// (16-bit, or e4m3fn with the scatter kernel's arithmetic).  All widths multiples of 8, rope <= 256.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mla_prefill_assemble_kernel(
+    T* __restrict__ q, T* __restrict__ k, T* __restrict__ v, const T* __restrict__ kv, const T* __restrict__ k_pe,
+    int64_t k_pe_stride, const T* __restrict__ c_kv, int64_t c_kv_stride, const int64_t* __restrict__ positions,
+    const void* __restrict__ cos_sin, int cache_f32, int is_neox, void* __restrict__ cache,
+    const int64_t* __restrict__ out_loc, int cache_fp8, int H, int nope, int rope, int vd, int rank, int64_t q_stride) {
+  __shared__ __attribute__((aligned(16))) T s_pe[256];
+  const int64_t t = blockIdx.x;
+  const int64_t pos = positions[t];
+  const int half = rope / 2;
+  auto cs = [&](int idx) -> float {
+    return cache_f32 ? static_cast<const float*>(cos_sin)[pos * rope + idx]
+                     : to_f32(static_cast<const T*>(cos_sin)[pos * rope + idx]);
+  };
+  // pair i of a rope vector x: (x[2 i], x[2 i + 1]) interleaved, (x[i], x[i + half]) neox
+  const int ia = is_neox ? 1 : 2, ib = is_neox ? half : 1;
+  const T* pe = k_pe + t * k_pe_stride;
+  for (int i = threadIdx.x; i < half; i += 256) {
+    T o1, o2;
+    rope_pair<T>(to_f32(pe[ia * i]), to_f32(pe[ia * i + ib]), cs(i), cs(half + i), o1, o2);
+    s_pe[ia * i] = o1;
+    s_pe[ia * i + ib] = o2;
+  }
+  T* qt = q + t * q_stride;
+  for (int it = threadIdx.x; it < H * half; it += 256) {
+    const int h = it / half, i = it - h * half;
+    T* qp = qt + (int64_t)h * (nope + rope) + nope;
+    T o1, o2;
+    rope_pair<T>(to_f32(qp[ia * i]), to_f32(qp[ia * i + ib]), cs(i), cs(half + i), o1, o2);
+    qp[ia * i] = o1;
+    qp[ia * i + ib] = o2;
+  }
+  __syncthreads();
+  // copies in 16-byte vectors: per head nope / 8 + rope / 8 vectors of k and vd / 8 of v
+  const int vn = nope / 8, vr = rope / 8, vv = vd / 8, per_head = vn + vr + vv;
+  const T* kvt = kv + t * (int64_t)H * (nope + vd);
+  T* kt = k + t * (int64_t)H * (nope + rope);
+  T* vt = v + t * (int64_t)H * vd;
+  for (int it = threadIdx.x; it < H * per_head; it += 256) {
+    const int h = it / per_head, c = it - h * per_head;
+    if (c < vn) stvec<T, 8>(kt + (int64_t)h * (nope + rope) + 8 * c, ldvec<T, 8>(kvt + (int64_t)h * (nope + vd) + 8 * c));
+    else if (c < vn + vr) stvec<T, 8>(kt + (int64_t)h * (nope + rope) + nope + 8 * (c - vn), *reinterpret_cast<const Vec<T, 8>*>(s_pe + 8 * (c - vn)));
+    else stvec<T, 8>(vt + (int64_t)h * vd + 8 * (c - vn - vr), ldvec<T, 8>(kvt + (int64_t)h * (nope + vd) + nope + 8 * (c - vn - vr)));
+  }
+  // the latent cache row
+  const int64_t slot = out_loc[t];
+  const int row_vecs = (rank + rope) / 8;
+  for (int c = threadIdx.x; c < row_vecs; c += 256) {
+    const Vec<T, 8> x = c < rank / 8 ? ldvec<T, 8>(c_kv + t * c_kv_stride + 8 * c)
+                                     : *reinterpret_cast<const Vec<T, 8>*>(s_pe + 8 * (c - rank / 8));
+    if (cache_fp8)
+      *reinterpret_cast<uint2*>(static_cast<uint8_t*>(cache) + slot * (rank + rope) + 8 * c) = quant8_fp8<T>(x, 1.0f);
+    else
+      stvec<T, 8>(static_cast<T*>(cache) + slot * (rank + rope) + 8 * c, x);
+  }
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -261,6 +325,42 @@ int mi355_mla_absorb(void* out, const void* a, const void* w_t, int64_t m, int h
     launch_absorb<f16_t>(out, a, w_t, (int)m, heads, n, k, tail, a_row_stride, a_head_stride, out_row_stride,
                          out_head_stride, (hipStream_t)stream);
   MI355_CHECK_LAUNCH("mla_absorb");
+  return MI355_OK;
+}
+
+int mi355_mla_prefill_assemble(void* q, void* k, void* v, const void* kv, const void* k_pe, int64_t k_pe_stride,
+                               const void* c_kv, int64_t c_kv_stride, const int64_t* positions, const void* cos_sin_cache,
+                               int cache_dtype, int is_neox, void* kv_cache, const int64_t* out_cache_loc, int64_t tokens,
+                               int heads, int nope_dim, int rope_dim, int v_dim, int kv_lora_rank, int64_t q_stride,
+                               int64_t num_slots, int dtype, void* stream) {
+  MI355_REQUIRE(q && k && v && kv && k_pe && c_kv && positions && cos_sin_cache && kv_cache && out_cache_loc,
+                MI355_ERR_INVALID, "mla_prefill_assemble: null pointer");
+  const bool kv8 = (dtype & MI355_KV_FP8) != 0;
+  dtype &= 0xff;
+  MI355_REQUIRE(dtype == MI355_BF16 || dtype == MI355_F16, MI355_ERR_UNSUPPORTED, "mla_prefill_assemble: only 16-bit dtypes");
+  MI355_REQUIRE(cache_dtype == MI355_F32 || cache_dtype == dtype, MI355_ERR_UNSUPPORTED,
+                "mla_prefill_assemble: cos_sin_cache must be fp32 or the tensor dtype");
+  MI355_REQUIRE(tokens >= 0 && heads >= 1 && nope_dim > 0 && rope_dim > 0 && v_dim > 0 && kv_lora_rank > 0 && num_slots > 0 &&
+                    nope_dim % 8 == 0 && rope_dim % 8 == 0 && rope_dim <= 256 && v_dim % 8 == 0 && kv_lora_rank % 8 == 0,
+                MI355_ERR_UNSUPPORTED,
+                "mla_prefill_assemble: widths must be multiples of 8 and rope_dim <= 256 (nope=%d rope=%d v=%d rank=%d)",
+                nope_dim, rope_dim, v_dim, kv_lora_rank);
+  MI355_REQUIRE(q_stride >= (int64_t)heads * (nope_dim + rope_dim) && q_stride % 8 == 0 && k_pe_stride >= rope_dim &&
+                    k_pe_stride % 8 == 0 && c_kv_stride >= kv_lora_rank && c_kv_stride % 8 == 0,
+                MI355_ERR_INVALID, "mla_prefill_assemble: row strides must cover the rows and be multiples of 8");
+  MI355_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(kv) && aligned16(k_pe) && aligned16(c_kv) &&
+                    (reinterpret_cast<uintptr_t>(kv_cache) & (kv8 ? 7 : 15)) == 0,
+                MI355_ERR_INVALID, "mla_prefill_assemble: misaligned pointer");
+  if (tokens == 0) return MI355_OK;
+#define LAUNCH(T)                                                                                                    \
+  hipLaunchKernelGGL((mla_prefill_assemble_kernel<T>), dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream,    \
+                     (T*)q, (T*)k, (T*)v, (const T*)kv, (const T*)k_pe, k_pe_stride, (const T*)c_kv, c_kv_stride,    \
+                     positions, cos_sin_cache, cache_dtype == MI355_F32 ? 1 : 0, is_neox, kv_cache, out_cache_loc,   \
+                     kv8 ? 1 : 0, heads, nope_dim, rope_dim, v_dim, kv_lora_rank, q_stride)
+  if (dtype == MI355_BF16) LAUNCH(bf16_t);
+  else LAUNCH(f16_t);
+#undef LAUNCH
+  MI355_CHECK_LAUNCH("mla_prefill_assemble");
   return MI355_OK;
 }
 

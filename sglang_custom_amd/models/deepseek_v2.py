@@ -166,6 +166,19 @@ class DeepseekV2AttentionMLA(nn.Module):
         q, latent = self._q_and_latent(hidden_states)
         kv_a = self.kv_a_layernorm(latent[..., : self.kv_lora_rank].contiguous())
         kv = self.kv_b_proj(kv_a)[0].view(-1, self.num_local_heads, self.qk_nope_head_dim + self.v_head_dim)
+        ops, pool, rot = get_ops(), forward_batch.token_to_kv_pool, self.rotary_emb
+        if (q.is_cuda and hasattr(pool, "kv_lora_rank") and rot.rotary_dim == self.qk_rope_head_dim
+                and rot.cos_sin_cache.dtype in (torch.float32, q.dtype) and pool.dtype in (q.dtype, torch.float8_e4m3fn)
+                and positions.dtype == torch.int64 and kv.is_contiguous() and q.is_contiguous()
+                and ops.mla_prefill_assemble_supported(self.qk_nope_head_dim, self.qk_rope_head_dim, self.v_head_dim,
+                                                       self.kv_lora_rank, q.dtype)):
+            # RoPE of q and k_pe, the k / v assembly and the write of the latent rows in one launch
+            k, v = ops.mla_prefill_assemble(
+                q, kv, latent[..., self.kv_lora_rank:], kv_a, positions.flatten(), rot.cos_sin_cache, rot.is_neox_style,
+                pool.get_key_buffer(self.attn_mha.layer_id), forward_batch.out_cache_loc, self.qk_nope_head_dim,
+                self.qk_rope_head_dim, self.v_head_dim)
+            attn_output = self.attn_mha(q, k, v, forward_batch, save_kv_cache=False)
+            return self.o_proj(attn_output.reshape(-1, self.num_local_heads * self.v_head_dim))[0]
         k_pe = self._rope(positions, q, latent)
         k = torch.empty_like(q)
         k[..., : self.qk_nope_head_dim] = kv[..., : self.qk_nope_head_dim]

@@ -551,6 +551,41 @@ def mla_absorb(a: torch.Tensor, w_t: torch.Tensor, tail: int = 0) -> torch.Tenso
     return out
 
 
+def mla_prefill_assemble_supported(nope: int, rope: int, vd: int, rank: int, dtype: torch.dtype) -> bool:
+    """Whether mla_prefill_assemble serves the shape (16-bit; widths multiples of 8, rope <= 256)."""
+    return (dtype in (torch.bfloat16, torch.float16) and nope % 8 == 0 and rope % 8 == 0 and 0 < rope <= 256
+            and vd % 8 == 0 and rank % 8 == 0)
+
+
+def mla_prefill_assemble(q, kv, k_pe, c_kv, positions, cos_sin_cache, is_neox: bool, kv_cache, out_cache_loc,
+                         nope: int, rope: int, vd: int):
+    """The glue of MLA's multi-head prefill (deepseek_v2.py:1131-1179) in one launch: q [T, H, nope + rope] gets its
+    rope part rotated in place; returns k [T, H, nope + rope] = [kv nope part | rope(k_pe)] and v [T, H, vd] from
+    kv [T, H, nope + vd]; writes the latent row [c_kv | rope(k_pe)] to kv_cache[out_cache_loc] (quantised when the
+    cache is e4m3fn).  k_pe [T, rope] and c_kv [T, rank] may be row-strided views."""
+    _gpu(q, kv, k_pe, c_kv, positions, cos_sin_cache, kv_cache, out_cache_loc)
+    T, H, D = q.shape
+    rank = c_kv.shape[1]
+    assert D == nope + rope and q.stride(2) == 1 and q.stride(1) == D
+    assert kv.is_contiguous() and kv.shape == (T, H, nope + vd) and kv.dtype == q.dtype
+    assert k_pe.shape == (T, rope) and k_pe.stride(1) == 1 and c_kv.shape[0] == T and c_kv.stride(1) == 1
+    assert k_pe.dtype == q.dtype and c_kv.dtype == q.dtype
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == T
+    assert out_cache_loc.dtype == torch.int64 and out_cache_loc.is_contiguous() and out_cache_loc.numel() == T
+    assert cos_sin_cache.is_contiguous() and cos_sin_cache.shape[1] == rope
+    assert kv_cache.is_contiguous() and kv_cache.shape[1] == 1 and kv_cache.shape[2] == rank + rope
+    assert kv_cache.dtype in (q.dtype, torch.float8_e4m3fn)
+    k = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
+    v = torch.empty((T, H, vd), dtype=q.dtype, device=q.device)
+    if T:
+        check(_lib_().mi355_mla_prefill_assemble(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), kv.data_ptr(), k_pe.data_ptr(), k_pe.stride(0), c_kv.data_ptr(),
+            c_kv.stride(0), positions.data_ptr(), cos_sin_cache.data_ptr(), _dt(cos_sin_cache), 1 if is_neox else 0,
+            kv_cache.data_ptr(), out_cache_loc.data_ptr(), T, H, nope, rope, vd, rank, q.stride(0), kv_cache.shape[0],
+            _kvdt(q, kv_cache), _stream(q)), "mla_prefill_assemble")
+    return k, v
+
+
 def extend_attention_mla_supported(hq: int, kv_lora_rank: int, rope_dim: int, dtype: torch.dtype) -> bool:
     """Whether extend_attention_mla serves the shape (latent row of 512 + 64 features, 16-bit)."""
     return dtype in (torch.bfloat16, torch.float16) and bool(

@@ -179,3 +179,9 @@ def mla_absorb_supported(m, n, k, tail, dtype):
     """The one-launch absorbed products are a GPU kernel only: the double declines and the model takes
     torch.bmm + cat / transpose, which is what the oracle restates."""
     return False
+
+
+def mla_prefill_assemble_supported(nope, rope, vd, rank, dtype):
+    """The one-launch prefill glue is a GPU kernel only: the double declines and the model takes rotary_emb + the
+    copies + set_kv_buffer, which is what the oracle restates."""
+    return False

@@ -745,3 +745,78 @@ def test_mla_fp8_ring_two_splits_per_workgroup_on_ragged_batches(bs, splits, fus
         err = (got[b].double() - ref).abs().max().item() / max(ref.abs().max().item(), 1.0)
         worst = max(worst, err)
         assert err <= 2e-2, (b, nkeys, err)
+
+
+@pytest.mark.parametrize("T,H,nope,rope,vd,rank", [(37, 16, 128, 64, 128, 512), (1, 128, 128, 64, 128, 512), (300, 3, 64, 32, 40, 128),
+                                                   (5, 2, 8, 8, 8, 8), (0, 16, 128, 64, 128, 512)])
+@pytest.mark.parametrize("dt,cs_dt,neox", [(torch.bfloat16, torch.bfloat16, False), (torch.float16, torch.float32, False),
+                                           (torch.bfloat16, torch.float32, True)])
+@pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
+def test_mla_prefill_assemble_is_rope_copies_and_cache_write_bit_for_bit(T, H, nope, rope, vd, rank, dt, cs_dt, neox, kv8):
+    """mi355_mla_prefill_assemble == the glue of MLA's multi-head prefill (deepseek_v2.py:1131-1179) launch by
+    launch: rope_inplace on (q's rope part, k_pe), k = [kv nope | k_pe per head], v = kv's value part,
+    set_kv_buffer of [c_kv | k_pe].  q, k, v and the cache rows, bit for bit; k_pe and c_kv as row-strided views
+    of the fused projection's output, scattered slots, 16-bit and e4m3fn caches, saturating values."""
+    from sglang_custom_amd import ops
+
+    assert ops.mla_prefill_assemble_supported(nope, rope, vd, rank, dt)
+    slots = 2 * T + 3
+    q = _CASES.randn((T, H, nope + rope), 51, dt).to(DEV)
+    kv = _CASES.randn((T, H, nope + vd), 52, dt).to(DEV)
+    lat = _CASES.randn((T, 24 + rank + rope), 53, dt).to(DEV)
+    k_pe_view = lat[:, 24 + rank:]
+    c_kv_all = _CASES.randn((T, rank + 8), 54, dt).to(DEV)
+    c_kv = c_kv_all[:, :rank]
+    if kv8 and T:
+        c_kv[0, :3] = torch.tensor([1000.0, -1000.0, 1e-3], dtype=dt, device=DEV)
+    g = torch.Generator().manual_seed(7)
+    cs = torch.cat([torch.randn(5000, rope // 2, generator=g).cos(), torch.randn(5000, rope // 2, generator=g).sin()],
+                   dim=1).to(cs_dt).to(DEV).contiguous()
+    positions = torch.randint(0, 5000, (T,), generator=g, dtype=torch.int64).to(DEV)
+    loc = (torch.randperm(slots - 1, generator=g)[:T] + 1).to(torch.int64).to(DEV)
+    cdt = torch.float8_e4m3fn if kv8 else dt
+    bits = torch.uint8 if kv8 else torch.int16
+    cache0 = torch.zeros((slots, 1, rank + rope), dtype=cdt, device=DEV)
+    # launch by launch
+    q_ref = q.clone()
+    k_pe = k_pe_view.clone()             # (contiguous() of a one-row view is the view itself)
+    if T:
+        q_pe = q_ref[..., nope:].contiguous().view(T, -1)
+        ops.rope_inplace(positions, q_pe, k_pe, rope, cs, neox)
+        q_ref[..., nope:] = q_pe.view(T, H, rope)
+    k_ref = torch.empty_like(q_ref)
+    k_ref[..., :nope] = kv[..., :nope]
+    k_ref[..., nope:] = k_pe.view(T, 1, rope)
+    v_ref = kv[..., nope:].contiguous()
+    cache_ref = cache0.clone()
+    if T:
+        row = torch.cat([c_kv, k_pe], dim=-1).view(T, 1, rank + rope)
+        ops.set_kv_buffer(cache_ref, cache_ref, loc, row, row)
+    # one launch
+    cache = cache0.clone()
+    q_got = q.clone()
+    k_got, v_got = ops.mla_prefill_assemble(q_got, kv, k_pe_view, c_kv, positions, cs, neox, cache, loc, nope, rope, vd)
+    torch.cuda.synchronize()
+    assert torch.equal(q_got.view(torch.int16), q_ref.view(torch.int16))
+    bad = (k_got.view(torch.int16) != k_ref.view(torch.int16)).nonzero()
+    assert bad.numel() == 0, ("k differs at (token, head, feature)", bad[:8].tolist(), len(bad))
+    assert torch.equal(v_got.view(torch.int16), v_ref.view(torch.int16))
+    assert torch.equal(cache.view(bits), cache_ref.view(bits))
+
+
+def test_mla_prefill_assemble_refuses_what_it_does_not_serve():
+    from sglang_custom_amd import ops
+    from sglang_custom_amd._lib import Mi355Error
+
+    assert not ops.mla_prefill_assemble_supported(128, 64, 128, 512, torch.float32)
+    assert not ops.mla_prefill_assemble_supported(128, 60, 128, 512, torch.bfloat16)
+    assert not ops.mla_prefill_assemble_supported(128, 512, 128, 512, torch.bfloat16)
+    dt = torch.bfloat16
+    q = torch.zeros((2, 2, 128 + 36), dtype=dt, device=DEV)
+    kv = torch.zeros((2, 2, 256), dtype=dt, device=DEV)
+    cache = torch.zeros((4, 1, 512 + 36), dtype=dt, device=DEV)
+    i64 = torch.zeros(2, dtype=torch.int64, device=DEV)
+    cs = torch.zeros((8, 36), dtype=torch.float32, device=DEV)
+    with pytest.raises(Mi355Error):
+        ops.mla_prefill_assemble(q, kv, torch.zeros((2, 36), dtype=dt, device=DEV), torch.zeros((2, 512), dtype=dt, device=DEV),
+                                 i64, cs, False, cache, i64, 128, 36, 128)
