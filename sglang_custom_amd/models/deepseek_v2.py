@@ -163,8 +163,14 @@ class DeepseekV2AttentionMLA(nn.Module):
 
     # ---- prefill without prefix ----
     def forward_normal(self, positions, hidden_states, forward_batch):
-        q, latent = self._q_and_latent(hidden_states)
-        kv_a = self.kv_a_layernorm(latent[..., : self.kv_lora_rank].contiguous())
+        front = self._decode_front(hidden_states, max_rows=None)
+        if front is not None:       # both latent norms and the k_pe copy in one launch, as in decode
+            q, kv_a, k_pe_raw = front
+            latent = None
+        else:
+            q, latent = self._q_and_latent(hidden_states)
+            kv_a = self.kv_a_layernorm(latent[..., : self.kv_lora_rank].contiguous())
+            k_pe_raw = latent[..., self.kv_lora_rank:]
         kv = self.kv_b_proj(kv_a)[0].view(-1, self.num_local_heads, self.qk_nope_head_dim + self.v_head_dim)
         ops, pool, rot = get_ops(), forward_batch.token_to_kv_pool, self.rotary_emb
         if (q.is_cuda and hasattr(pool, "kv_lora_rank") and rot.rotary_dim == self.qk_rope_head_dim
@@ -174,11 +180,13 @@ class DeepseekV2AttentionMLA(nn.Module):
                                                        self.kv_lora_rank, q.dtype)):
             # RoPE of q and k_pe, the k / v assembly and the write of the latent rows in one launch
             k, v = ops.mla_prefill_assemble(
-                q, kv, latent[..., self.kv_lora_rank:], kv_a, positions.flatten(), rot.cos_sin_cache, rot.is_neox_style,
+                q, kv, k_pe_raw, kv_a, positions.flatten(), rot.cos_sin_cache, rot.is_neox_style,
                 pool.get_key_buffer(self.attn_mha.layer_id), forward_batch.out_cache_loc, self.qk_nope_head_dim,
                 self.qk_rope_head_dim, self.v_head_dim)
             attn_output = self.attn_mha(q, k, v, forward_batch, save_kv_cache=False)
             return self.o_proj(attn_output.reshape(-1, self.num_local_heads * self.v_head_dim))[0]
+        if latent is None:
+            latent = torch.cat([kv_a, k_pe_raw], dim=-1)
         k_pe = self._rope(positions, q, latent)
         k = torch.empty_like(q)
         k[..., : self.qk_nope_head_dim] = kv[..., : self.qk_nope_head_dim]
@@ -190,8 +198,8 @@ class DeepseekV2AttentionMLA(nn.Module):
         return self.o_proj(attn_output.reshape(-1, self.num_local_heads * self.v_head_dim))[0]
 
     # ---- decode ----
-    def _decode_front(self, hidden_states):
-        """Decode-sized batches: the "a" projection's split-K partials (or its output) go through ONE launch that
+    def _decode_front(self, hidden_states, max_rows=64):
+        """Decode-sized batches (and, with max_rows=None, prefill batches from the projection's dense output): the "a" projection's split-K partials (or its output) go through ONE launch that
         sums them and applies q_a_layernorm and kv_a_layernorm (ops.mla_latent_norms) instead of a split, two
         copies and two norms.  Returns (q [T, H, nope + rope], normed c_kv [T, rank], k_pe [T, rope] unrotated),
         or None when the shape or the ops backend does not serve it."""
@@ -199,7 +207,7 @@ class DeepseekV2AttentionMLA(nn.Module):
         x = hidden_states.dense if isinstance(hidden_states, QuantizedAct) else hidden_states   # (the norm's 16-bit rows)
         rank, rope = self.kv_lora_rank, self.qk_rope_head_dim
         q_rank = self.q_lora_rank or 0
-        if (x.dim() != 2 or not x.is_cuda or x.shape[0] > 64
+        if (x.dim() != 2 or not x.is_cuda or x.shape[0] == 0 or (max_rows is not None and x.shape[0] > max_rows)
                 or not ops.mla_latent_norms_supported(q_rank, rank, rope, x.dtype)):
             return None
         proj = self.fused_qkv_a_proj_with_mqa if q_rank else self.kv_a_proj_with_mqa
