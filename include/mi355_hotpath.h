@@ -41,6 +41,12 @@ extern "C" {
  * 436-446) while q / k / v / o keep the 16-bit dtype in the low byte.  Values are stored as
  * clamp(x, +-448) rounded to nearest even and read back by exact widening. */
 #define MI355_KV_FP8 0x100
+/* OR into the same `dtype` argument: k_buffer / v_buffer are laid out [Hkv, num_slots, D] (head-major: the rows
+ * one kv head's workgroup streams are adjacent in memory) instead of [num_slots, Hkv, D].  The same slots, heads
+ * and values -- MHATokenToKVPool.get_key_buffer(layer) (mem_cache/memory_pool.py:395-418) seen through
+ * buffer.permute(1, 0, 2); num_slots must then be the buffer's true slot count (it is the head stride).  Latent
+ * (MLA) caches have one head and ignore the flag. */
+#define MI355_KV_HEAD_MAJOR 0x200
 
 #define MI355_ABI_VERSION 1
 int mi355_abi_version(void);
@@ -110,6 +116,14 @@ int mi355_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const voi
                         const void* loc, int loc_itype, int64_t tokens, int64_t k_row_elems,
                         int64_t v_row_elems, int64_t k_stride, int64_t v_stride,
                         int64_t num_slots, int dtype, void* stream);
+
+/* The same scatter with the row seen as `heads` heads of k_head_dim / v_head_dim features, so that it can follow either
+ * cache layout: [num_slots, heads, d] or, under dtype | MI355_KV_HEAD_MAJOR, [heads, num_slots, d] (and e4m3fn bytes
+ * under MI355_KV_FP8, same arithmetic).  16-bit k / v, head dims multiples of 8.
+ * replaces: MHATokenToKVPool.set_kv_buffer (mem_cache/memory_pool.py:420-458). */
+int mi355_set_kv_buffer_heads(void* k_buffer, void* v_buffer, const void* k, const void* v, const void* loc,
+                              int loc_itype, int64_t tokens, int heads, int k_head_dim, int v_head_dim, int64_t k_stride,
+                              int64_t v_stride, int64_t num_slots, int dtype, void* stream);
 
 /* ---- K15 embedding gather -----------------------------------------------------------------
  * out[t,:] = (vocab_start <= ids[t] < vocab_end) ? table[ids[t]-vocab_start,:] : 0

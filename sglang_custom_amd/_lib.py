@@ -26,6 +26,7 @@ _SIGNATURES = {
     "mi355_softcap_inplace": (I, [P, L, F, P]),
     "mi355_rope_inplace": (I, [P, P, P, P, P, I, L, I, I, I, I, L, L, L, I, P, P, P, I, L, I, P]),
     "mi355_set_kv_buffer": (I, [P, P, P, P, P, I, L, L, L, L, L, L, I, P]),
+    "mi355_set_kv_buffer_heads": (I, [P, P, P, P, P, I, L, I, I, I, L, L, L, I, P]),
     "mi355_embedding": (I, [P, P, P, L, L, L, L, I, P]),
     "mi355_create_kv_indices": (I, [P, P, I, P, I, P, P, P, L, L, P]),
     "mi355_write_req_to_token": (I, [P, P, P, P, P, P, L, L, P]),

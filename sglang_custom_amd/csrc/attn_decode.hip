@@ -30,7 +30,10 @@ struct DecodeParams {
   float* part_lse;  // [B, Hq, S]
   int mode, num_splits, hq, hkv;
   float sm_scale, logit_cap;
-  int64_t k_slot_stride, v_slot_stride;  // elements between consecutive slots (generic kernel)
+  // The cache as the caller laid it out: elements between consecutive slots and between consecutive kv heads
+  // ([slots, hkv, d]: hkv * d and d; head-major [hkv, slots, d]: d and slots * d).
+  int64_t k_slot_stride, v_slot_stride;
+  int64_t k_head_stride, v_head_stride;
   // Arrival counters of the in-kernel merge, one per (sequence, blockIdx.x), zero between launches; null:
   // the splits are merged by decode_merge_kernel in a second launch.  Only the kernels that say so use them.
   unsigned* tickets = nullptr;
@@ -290,9 +293,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   }
 
   const int32_t* pt = p.page_table + page_off;
-  const int64_t row_stride = (int64_t)p.hkv * D;
-  const T* kbase = kbuf + (int64_t)kvh * D + dchunk * VE;
-  const T* vbase = vbuf + (int64_t)kvh * D + dchunk * VE;
+  const int64_t row_stride = p.k_slot_stride;   // (D == Dv here: the value cache has the same geometry)
+  const T* kbase = kbuf + (int64_t)kvh * p.k_head_stride + dchunk * VE;
+  const T* vbase = vbuf + (int64_t)kvh * p.v_head_stride + dchunk * VE;
 
   const int64_t first = k0 + (int64_t)wave * KPW + kslot;   // this lane's row in step 0, u = 0
   const int64_t wave_first = k0 + (int64_t)wave * KPW;
@@ -496,9 +499,9 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_kernel(const T* __restri
     for (int j = 0; j < VE; ++j) acc[g][j] = 0.f;
 
   const int32_t* pt = p.page_table + page_off;
-  const int64_t row_stride = (int64_t)p.hkv * D;
-  const T* kbase = kbuf + (int64_t)kvh * D + 8 * c4;     // + slot * row_stride + 32 s
-  const T* vbase = vbuf + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
+  const int64_t row_stride = p.k_slot_stride;
+  const T* kbase = kbuf + (int64_t)kvh * p.k_head_stride + 8 * c4;     // + slot * row_stride + 32 s
+  const T* vbase = vbuf + (int64_t)kvh * p.v_head_stride + 8 * r16;    // + slot * row_stride
   // A wave takes TL tiles of 16 keys per step (all their K/V loads are issued before the first
   // tile is computed); the 4 waves interleave steps.  Measured: TL = 2 (16 KiB per wave per memory
   // round trip) is no faster than TL = 1 and costs 32 VGPRs.
@@ -825,9 +828,9 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int32_t* pt = p.page_table + page_off;
-  const int64_t row_stride = (int64_t)p.hkv * D;
-  const KVT* kbase = reinterpret_cast<const KVT*>(kbuf) + (int64_t)kvh * D + 8 * (KROW ? r16 : c4);   // + slot * row_stride (+ 32 s)
-  const KVT* vbase = reinterpret_cast<const KVT*>(vbuf) + (int64_t)kvh * D + 8 * r16;    // + slot * row_stride
+  const int64_t row_stride = p.k_slot_stride;
+  const KVT* kbase = reinterpret_cast<const KVT*>(kbuf) + (int64_t)kvh * p.k_head_stride + 8 * (KROW ? r16 : c4);   // + slot * row_stride (+ 32 s)
+  const KVT* vbase = reinterpret_cast<const KVT*>(vbuf) + (int64_t)kvh * p.v_head_stride + 8 * r16;    // + slot * row_stride
   const int64_t wave_first = k0 + (int64_t)wave * 16;
   const int n_iter = wave_first < k1 ? (int)((k1 - wave_first + 63) / 64) : 0;
   const int64_t last_key = len - 1;
@@ -1018,8 +1021,8 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
       frags_from_lds(G, knew);
       vnew = ldvec<T, VE>(&sm_qkv[(G + 1) * D + 8 * r16]);
       const int64_t slot = fz.out_loc[b];
-      KVT* kd = const_cast<KVT*>(reinterpret_cast<const KVT*>(kbuf)) + slot * row_stride + (int64_t)kvh * D + 8 * c4;
-      KVT* vd = const_cast<KVT*>(reinterpret_cast<const KVT*>(vbuf)) + slot * row_stride + (int64_t)kvh * D + 8 * r16;
+      KVT* kd = const_cast<KVT*>(reinterpret_cast<const KVT*>(kbuf)) + slot * row_stride + (int64_t)kvh * p.k_head_stride + 8 * c4;
+      KVT* vd = const_cast<KVT*>(reinterpret_cast<const KVT*>(vbuf)) + slot * row_stride + (int64_t)kvh * p.v_head_stride + 8 * r16;
       if constexpr (KV8) {
         // quantise once; the attention below sees exactly what a later step will read from the cache
 #pragma unroll
@@ -1120,8 +1123,8 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
   float m = -INFINITY, l = 0.f;
   for (int64_t key = k0; key < k1; ++key) {
     const int64_t slot = p.page_table[page_off + key];
-    const T* kr = kbuf + slot * p.k_slot_stride + (int64_t)kvh * D;
-    const T* vr = vbuf + slot * p.v_slot_stride + (int64_t)kvh * Dv;
+    const T* kr = kbuf + slot * p.k_slot_stride + (int64_t)kvh * p.k_head_stride;
+    const T* vr = vbuf + slot * p.v_slot_stride + (int64_t)kvh * p.v_head_stride;
     float d = 0.f;
     for (int i = lane; i < D; i += 64) d = fmaf(to_f32(qh[i]), to_f32(kr[i]), d);
     d = wave_sum(d) * p.sm_scale;
@@ -2693,8 +2696,8 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   p.hkv = hkv;
   p.sm_scale = sm_scale;
   p.logit_cap = logit_cap;
-  p.k_slot_stride = (int64_t)hkv * head_dim;
-  p.v_slot_stride = (int64_t)hkv * v_head_dim;
+  kv_strides(dtype, num_slots, hkv, head_dim, p.k_slot_stride, p.k_head_stride);
+  kv_strides(dtype, num_slots, hkv, v_head_dim, p.v_slot_stride, p.v_head_stride);
   int rc = MI355_OK;
   const bool kv8 = (dtype & MI355_KV_FP8) != 0;
   dtype &= 0xff;
@@ -2808,6 +2811,7 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
                     nsplit <= 64,
                 MI355_ERR_INVALID, "decode_attention_fused_qkv: bad shape hq=%d hkv=%d nsplit=%d", hq, hkv, nsplit);
   const bool kv8 = (dtype & MI355_KV_FP8) != 0;
+  const int kv_flags = dtype;
   dtype &= 0xff;
   MI355_REQUIRE(head_dim == 128 && (dtype == MI355_BF16 || dtype == MI355_F16), MI355_ERR_UNSUPPORTED,
                 "decode_attention_fused_qkv: needs head_dim 128 and a 16-bit dtype");
@@ -2837,8 +2841,8 @@ int mi355_decode_attention_fused_qkv(const float* qkv_part, int nsplit, const fl
   p.hkv = hkv;
   p.sm_scale = sm_scale;
   p.logit_cap = 0.f;
-  p.k_slot_stride = (int64_t)hkv * head_dim;
-  p.v_slot_stride = (int64_t)hkv * head_dim;
+  kv_strides(kv_flags, num_slots, hkv, head_dim, p.k_slot_stride, p.k_head_stride);
+  kv_strides(kv_flags, num_slots, hkv, head_dim, p.v_slot_stride, p.v_head_stride);
   FusedQkv fz;
   fz.part = qkv_part;
   fz.nsplit = nsplit;
@@ -2901,6 +2905,7 @@ static int decode_attention_mla_impl(const MlaRope* rope, const void* q, const v
   p.chunk_keys = kv_chunk_keys;
   p.k_slot_stride = D;   // one latent row per slot; the value is its first kv_lora_rank features
   p.v_slot_stride = D;
+  p.k_head_stride = p.v_head_stride = D;
   hipStream_t st = (hipStream_t)stream;
   if (rope) {
     // rotation + cache write inside the launch: only the LDS-ring kernel has it
@@ -3117,6 +3122,7 @@ int mi355_extend_attention_mla(const void* q, const void* kv_buffer, void* o, co
   p.logit_cap = logit_cap;
   p.k_slot_stride = MLA_D;
   p.v_slot_stride = MLA_D;
+  p.k_head_stride = p.v_head_stride = MLA_D;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)((hq + 15) / 16), (unsigned)((max_extend_len + MLX_TOKENS - 1) / MLX_TOKENS), (unsigned)bs);
   constexpr int lds = mlr_lds_bytes(4);

@@ -26,6 +26,8 @@ struct ExtendParams {
   int64_t q_stride, k_stride, v_stride;
   int is_causal, skip_prefix_custom_mask, hq, hkv, D, Dv, sliding_window;
   float sm_scale, logit_cap;
+  // the cache buffers: elements between consecutive slots / consecutive kv heads ([slots, hkv, d] or head-major)
+  int64_t kb_slot, kb_head, vb_slot, vb_head;
 };
 
 // DP: padded head dim (>= D, Dv; multiple of 64). BN: keys per tile. VEC: 16-B global loads.
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const T* __restrict
           const T *ksrc, *vsrc;
           if (phase == 0) {
             const int64_t slot = p.kv_indices[kv_start + key];
-            ksrc = kbuf + (slot * p.hkv + kvh) * (int64_t)D;
-            vsrc = vbuf + (slot * p.hkv + kvh) * (int64_t)Dv;
+            ksrc = kbuf + slot * p.kb_slot + kvh * p.kb_head;
+            vsrc = vbuf + slot * p.vb_slot + kvh * p.vb_head;
           } else {
             ksrc = k_ext + (int64_t)(q_start + key) * p.k_stride + (int64_t)kvh * D;
             vsrc = v_ext + (int64_t)(q_start + key) * p.v_stride + (int64_t)kvh * Dv;
@@ -393,8 +395,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       key = key < total ? key : total - 1;
       if (KV8 && key < prefix) {
         const int64_t slot = p.kv_indices[kv_start + key];
-        const uint8_t* kp8 = reinterpret_cast<const uint8_t*>(kbuf) + (slot * p.hkv + kvh) * D + sch * 8;
-        const uint8_t* vp8 = reinterpret_cast<const uint8_t*>(vbuf) + (slot * p.hkv + kvh) * D + sch * 8;
+        const uint8_t* kp8 = reinterpret_cast<const uint8_t*>(kbuf) + slot * p.kb_slot + kvh * p.kb_head + sch * 8;
+        const uint8_t* vp8 = reinterpret_cast<const uint8_t*>(vbuf) + slot * p.vb_slot + kvh * p.vb_head + sch * 8;
         kreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(kp8));
         vreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(vp8));
         continue;
@@ -402,8 +404,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const T *kp, *vp;
       if (key < prefix) {
         const int64_t slot = p.kv_indices[kv_start + key];
-        kp = kbuf + (slot * p.hkv + kvh) * D;
-        vp = vbuf + (slot * p.hkv + kvh) * D;
+        kp = kbuf + slot * p.kb_slot + kvh * p.kb_head;
+        vp = vbuf + slot * p.vb_slot + kvh * p.vb_head;
       } else {
         const int64_t tok = q_start + key - prefix;
         kp = k_ext + tok * p.k_stride + (int64_t)kvh * D;
@@ -619,8 +621,8 @@ __device__ __forceinline__ void extend_attn_mfma32_body(
       key = key < total ? key : total - 1;
       if (KV8 && key < prefix) {
         const int64_t slot_ = p.kv_indices[kv_start + key];
-        const uint8_t* kp8 = reinterpret_cast<const uint8_t*>(kbuf) + (slot_ * p.hkv + kvh) * D + sch * 8;
-        const uint8_t* vp8 = reinterpret_cast<const uint8_t*>(vbuf) + (slot_ * p.hkv + kvh) * D + sch * 8;
+        const uint8_t* kp8 = reinterpret_cast<const uint8_t*>(kbuf) + slot_ * p.kb_slot + kvh * p.kb_head + sch * 8;
+        const uint8_t* vp8 = reinterpret_cast<const uint8_t*>(vbuf) + slot_ * p.vb_slot + kvh * p.vb_head + sch * 8;
         kreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(kp8));
         vreg[i] = cvt8_from_fp8<T>(*reinterpret_cast<const uint2*>(vp8));
         continue;
@@ -628,8 +630,8 @@ __device__ __forceinline__ void extend_attn_mfma32_body(
       const T *kp, *vp;
       if (key < prefix) {
         const int64_t slot_ = p.kv_indices[kv_start + key];
-        kp = kbuf + (slot_ * p.hkv + kvh) * DQ;
-        vp = vbuf + (slot_ * p.hkv + kvh) * D;
+        kp = kbuf + slot_ * p.kb_slot + kvh * p.kb_head;
+        vp = vbuf + slot_ * p.vb_slot + kvh * p.vb_head;
       } else {
         const int64_t tok = q_start + key - prefix;
         kp = k_ext + tok * p.k_stride + (int64_t)kvh * DQ;
@@ -961,6 +963,8 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
   p.sliding_window = sliding_window_size;
   p.sm_scale = sm_scale;
   p.logit_cap = logit_cap;
+  kv_strides(dtype, num_slots, hkv, head_dim, p.kb_slot, p.kb_head);
+  kv_strides(dtype, num_slots, hkv, v_head_dim, p.vb_slot, p.vb_head);
   int rc = MI355_OK;
   const bool kv8 = (dtype & MI355_KV_FP8) != 0;
   dtype &= 0xff;

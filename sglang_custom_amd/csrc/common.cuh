@@ -154,6 +154,18 @@ __device__ __forceinline__ float block_max256(float x, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// Strides (elements) of a KV cache buffer of `heads` heads x `d` features over `num_slots` slots:
+// [num_slots, heads, d], or [heads, num_slots, d] when the dtype argument carries MI355_KV_HEAD_MAJOR.
+inline void kv_strides(int dtype_flags, int64_t num_slots, int heads, int d, int64_t& slot_stride, int64_t& head_stride) {
+  if (dtype_flags & MI355_KV_HEAD_MAJOR) {
+    slot_stride = d;
+    head_stride = num_slots * (int64_t)d;
+  } else {
+    slot_stride = (int64_t)heads * d;
+    head_stride = d;
+  }
+}
+
 // ---- L2 warm-up of the next GEMM's packed weights --------------------------------------------
 // A kernel that leaves HBM idle (row norms, RoPE: tens of KB of traffic) can carry extra
 // workgroups that pull the head of the NEXT skinny GEMM's weight stream into L2.  L2 contents

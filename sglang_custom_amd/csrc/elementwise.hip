@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
                                                    int64_t k_stride, int64_t v_stride, int is_neox,
                                                    T* __restrict__ k_buffer,
                                                    T* __restrict__ v_buffer,
-                                                   const LT* __restrict__ loc) {
+                                                   const LT* __restrict__ loc, int64_t kv_slot, int64_t kv_head) {
+  // kv_slot / kv_head: elements between consecutive slots / kv heads of the cache buffers.
   // Every product and sum below must round on its own (torch evaluates x1*cos, x2*sin and their
   // difference as separate elementwise ops): no fused multiply-add contraction in this kernel.
 #pragma clang fp contract(off)
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
   T* kt = k + t * k_stride;
   const int nheads = hq + hkv;
   const int64_t slot = k_buffer ? (int64_t)loc[t] : 0;
-  T* kdst = k_buffer ? k_buffer + slot * (int64_t)hkv * head_dim : nullptr;
+  T* kdst = k_buffer ? k_buffer + slot * kv_slot : nullptr;
   const int rot_chunks = VEC ? (nheads * (half / V16<T>::n) + 255) / 256 : (nheads * half + 255) / 256;
 
   if ((int)blockIdx.y < rot_chunks) {
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
       stvec<T, VE>(base + i, o1v);
       stvec<T, VE>(base + i + half, o2v);
       if (kdst && h >= hq) {
-        T* d = kdst + (int64_t)(h - hq) * head_dim;
+        T* d = kdst + (int64_t)(h - hq) * kv_head;
         stvec<T, VE>(d + i, o1v);
         stvec<T, VE>(d + i + half, o2v);
       }
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
     base[i1] = from_f32<T>(o1);
     base[i2] = from_f32<T>(o2);
     if (kdst && h >= hq) {
-      T* d = kdst + (int64_t)(h - hq) * head_dim;
+      T* d = kdst + (int64_t)(h - hq) * kv_head;
       d[i1] = from_f32<T>(o1);
       d[i2] = from_f32<T>(o2);
     }
@@ -432,17 +433,17 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ q, T* __restr
     const int pass = head_dim - rotary_dim;
     if (cw < hkv * pass) {
       const int h = cw / pass, i = rotary_dim + (cw - h * pass);
-      kdst[(int64_t)h * head_dim + i] = kt[(int64_t)h * head_dim + i];
+      kdst[(int64_t)h * kv_head + i] = kt[(int64_t)h * head_dim + i];
     }
     if constexpr (VEC) {
       constexpr int VE = V16<T>::n;
       if (cw * VE < hkv * head_dim) {
-        T* vdst = v_buffer + slot * (int64_t)hkv * head_dim;
-        stvec<T, VE>(vdst + cw * VE, ldvec<T, VE>(v + t * v_stride + cw * VE));
+        const int h = cw * VE / head_dim, d = cw * VE - h * head_dim;    // (VE divides head_dim on this path)
+        stvec<T, VE>(v_buffer + slot * kv_slot + (int64_t)h * kv_head + d, ldvec<T, VE>(v + t * v_stride + cw * VE));
       }
     } else if (cw < hkv * head_dim) {
-      T* vdst = v_buffer + slot * (int64_t)hkv * head_dim;
-      vdst[cw] = v[t * v_stride + cw];
+      const int h = cw / head_dim, d = cw - h * head_dim;
+      v_buffer[slot * kv_slot + (int64_t)h * kv_head + d] = v[t * v_stride + cw];
     }
   }
 }
@@ -488,6 +489,33 @@ __global__ __launch_bounds__(256) void set_kv_fp8_kernel(uint8_t* __restrict__ k
     *reinterpret_cast<uint2*>(vb + slot * v_row + i) = quant8_fp8<T>(ldvec<T, 8>(vs + i), 1.0f);
 }
 
+// KV-cache scatter by head: row t of k / v is `heads` heads of kd / vd features; head h goes to
+// buffer + slot * slot_stride + h * head_stride (any layout kv_strides() describes), 16-bit or quantised to e4m3fn
+// with set_kv_fp8_kernel's arithmetic.  kd, vd multiples of 8.
+template <typename T, typename LT, bool FP8>
+__global__ __launch_bounds__(256) void set_kv_heads_kernel(void* __restrict__ kb, void* __restrict__ vb,
+                                                           const T* __restrict__ k, const T* __restrict__ v,
+                                                           const LT* __restrict__ loc, int heads, int kd, int vd,
+                                                           int64_t k_stride, int64_t v_stride, int64_t kb_slot,
+                                                           int64_t kb_head, int64_t vb_slot, int64_t vb_head) {
+  const int64_t t = blockIdx.x;
+  const int64_t slot = (int64_t)loc[t];
+  for (int i = threadIdx.x * 8; i < heads * kd; i += 256 * 8) {
+    const int h = i / kd, d = i - h * kd;
+    const Vec<T, 8> x = ldvec<T, 8>(k + t * k_stride + i);
+    const int64_t off = slot * kb_slot + (int64_t)h * kb_head + d;
+    if constexpr (FP8) *reinterpret_cast<uint2*>(static_cast<uint8_t*>(kb) + off) = quant8_fp8<T>(x, 1.0f);
+    else stvec<T, 8>(static_cast<T*>(kb) + off, x);
+  }
+  for (int i = threadIdx.x * 8; i < heads * vd; i += 256 * 8) {
+    const int h = i / vd, d = i - h * vd;
+    const Vec<T, 8> x = ldvec<T, 8>(v + t * v_stride + i);
+    const int64_t off = slot * vb_slot + (int64_t)h * vb_head + d;
+    if constexpr (FP8) *reinterpret_cast<uint2*>(static_cast<uint8_t*>(vb) + off) = quant8_fp8<T>(x, 1.0f);
+    else stvec<T, 8>(static_cast<T*>(vb) + off, x);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Embedding gather
 // ------------------------------------------------------------------------------------------
@@ -517,7 +545,7 @@ static void rope_launch(void* q, void* k, const void* v, const int64_t* position
                         const void* cache, int cache_dtype, int64_t tokens, int hq, int hkv,
                         int head_dim, int rotary_dim, int64_t q_stride, int64_t k_stride,
                         int64_t v_stride, int is_neox, void* k_buffer, void* v_buffer,
-                        const void* loc, int loc_itype, hipStream_t st) {
+                        const void* loc, int loc_itype, int64_t kv_slot, int64_t kv_head, hipStream_t st) {
   constexpr int VE = V16<T>::n;
   // 16-byte path: neox pairs, whole head rotated, everything 16-byte aligned
   const bool vec = is_neox && rotary_dim == head_dim && (rotary_dim / 2) % VE == 0 && q_stride % VE == 0 &&
@@ -532,7 +560,7 @@ static void rope_launch(void* q, void* k, const void* v, const int64_t* position
   const bool i32 = loc_itype == MI355_I32;
 #define ROPE_ARGS(CT, LT)                                                                    \
   (T*)q, (T*)k, (const T*)v, positions, (const CT*)cache, hq, hkv, head_dim, rotary_dim,      \
-      q_stride, k_stride, v_stride, is_neox, (T*)k_buffer, (T*)v_buffer, (const LT*)loc
+      q_stride, k_stride, v_stride, is_neox, (T*)k_buffer, (T*)v_buffer, (const LT*)loc, kv_slot, kv_head
 #define ROPE_LAUNCH(CT, LT)                                                                              \
   do {                                                                                                   \
     if (vec) hipLaunchKernelGGL((rope_kernel<T, CT, LT, true>), grid, block, 0, st, ROPE_ARGS(CT, LT));  \
@@ -730,6 +758,8 @@ int mi355_rope_inplace(void* q, void* k, const void* v, const int64_t* positions
                        int64_t v_stride, int is_neox, void* k_buffer, void* v_buffer,
                        const void* loc, int loc_itype, int64_t num_slots, int dtype,
                        void* stream) {
+  const int kv_flags = dtype;
+  dtype &= ~MI355_KV_HEAD_MAJOR;
   MI355_REQUIRE(q && k && positions && cos_sin_cache, MI355_ERR_INVALID, "rope: null pointer");
   MI355_REQUIRE(tokens >= 0 && hq > 0 && hkv >= 0 && head_dim > 0 && rotary_dim > 0 &&
                     rotary_dim <= head_dim && rotary_dim % 2 == 0,
@@ -746,10 +776,12 @@ int mi355_rope_inplace(void* q, void* k, const void* v, const int64_t* positions
   }
   if (tokens == 0) return MI355_OK;
   hipStream_t st = (hipStream_t)stream;
+  int64_t kv_slot = 0, kv_head = 0;
+  kv_strides(kv_flags, num_slots, hkv, head_dim, kv_slot, kv_head);
   MI355_DISPATCH_DTYPE(dtype, "rope",
                        rope_launch<T>(q, k, v, positions, cos_sin_cache, cache_dtype, tokens, hq,
                                       hkv, head_dim, rotary_dim, q_stride, k_stride, v_stride,
-                                      is_neox, k_buffer, v_buffer, loc, loc_itype, st));
+                                      is_neox, k_buffer, v_buffer, loc, loc_itype, kv_slot, kv_head, st));
   MI355_CHECK_LAUNCH("rope");
   return MI355_OK;
 }
@@ -760,6 +792,8 @@ int mi355_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const voi
                         int64_t num_slots, int dtype, void* stream) {
   MI355_REQUIRE(k_buffer && v_buffer && k && v && loc, MI355_ERR_INVALID,
                 "set_kv_buffer: null pointer");
+  MI355_REQUIRE(!(dtype & MI355_KV_HEAD_MAJOR), MI355_ERR_UNSUPPORTED,
+                "set_kv_buffer: rows are opaque here; a head-major cache is written by mi355_set_kv_buffer_heads");
   MI355_REQUIRE(tokens >= 0 && k_row_elems > 0 && v_row_elems > 0 && k_stride >= k_row_elems &&
                     v_stride >= v_row_elems && num_slots > 0,
                 MI355_ERR_INVALID, "set_kv_buffer: bad shape");
@@ -785,6 +819,40 @@ int mi355_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const voi
                        set_kv_launch<T>(k_buffer, v_buffer, k, v, loc, loc_itype, tokens,
                                         k_row_elems, v_row_elems, k_stride, v_stride, st));
   MI355_CHECK_LAUNCH("set_kv_buffer");
+  return MI355_OK;
+}
+
+int mi355_set_kv_buffer_heads(void* k_buffer, void* v_buffer, const void* k, const void* v, const void* loc,
+                              int loc_itype, int64_t tokens, int heads, int k_head_dim, int v_head_dim, int64_t k_stride,
+                              int64_t v_stride, int64_t num_slots, int dtype, void* stream) {
+  MI355_REQUIRE(k_buffer && v_buffer && k && v && loc, MI355_ERR_INVALID, "set_kv_buffer_heads: null pointer");
+  const bool kv8 = (dtype & MI355_KV_FP8) != 0;
+  const int dt = dtype & 0xff;
+  MI355_REQUIRE(tokens >= 0 && heads > 0 && k_head_dim > 0 && v_head_dim > 0 && num_slots > 0 &&
+                    k_stride >= (int64_t)heads * k_head_dim && v_stride >= (int64_t)heads * v_head_dim,
+                MI355_ERR_INVALID, "set_kv_buffer_heads: bad shape");
+  MI355_REQUIRE(loc_itype == MI355_I32 || loc_itype == MI355_I64, MI355_ERR_INVALID, "set_kv_buffer_heads: loc must be int32 or int64");
+  MI355_REQUIRE((dt == MI355_BF16 || dt == MI355_F16) && k_head_dim % 8 == 0 && v_head_dim % 8 == 0 && k_stride % 8 == 0 &&
+                    v_stride % 8 == 0 && aligned16(k) && aligned16(v) &&
+                    (reinterpret_cast<uintptr_t>(k_buffer) & (kv8 ? 7 : 15)) == 0 &&
+                    (reinterpret_cast<uintptr_t>(v_buffer) & (kv8 ? 7 : 15)) == 0,
+                MI355_ERR_UNSUPPORTED,
+                "set_kv_buffer_heads: needs 16-bit k / v, head dims and row strides in multiples of 8, aligned pointers");
+  if (tokens == 0) return MI355_OK;
+  int64_t ks, kh, vs, vh;
+  kv_strides(dtype, num_slots, heads, k_head_dim, ks, kh);
+  kv_strides(dtype, num_slots, heads, v_head_dim, vs, vh);
+  const dim3 grid((unsigned)tokens), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define KVH_LAUNCH(T_, LT_, F8_)                                                                                   \
+  hipLaunchKernelGGL((set_kv_heads_kernel<T_, LT_, F8_>), grid, block, 0, st, k_buffer, v_buffer, (const T_*)k,      \
+                     (const T_*)v, (const LT_*)loc, heads, k_head_dim, v_head_dim, k_stride, v_stride, ks, kh, vs, vh)
+#define KVH_LT(T_, F8_) do { if (loc_itype == MI355_I32) KVH_LAUNCH(T_, int32_t, F8_); else KVH_LAUNCH(T_, int64_t, F8_); } while (0)
+  if (dt == MI355_BF16) { if (kv8) KVH_LT(bf16_t, true); else KVH_LT(bf16_t, false); }
+  else { if (kv8) KVH_LT(f16_t, true); else KVH_LT(f16_t, false); }
+#undef KVH_LT
+#undef KVH_LAUNCH
+  MI355_CHECK_LAUNCH("set_kv_buffer_heads");
   return MI355_OK;
 }
 

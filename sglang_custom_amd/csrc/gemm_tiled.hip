@@ -57,8 +57,9 @@ struct GemmTiledParams {
   const void* cos_sin;        // [max_pos, 128]: cos | sin, fp32 or the tensor dtype
   int cs_f32;
   int hq, hkv;                // local query / kv heads (head_dim 128)
-  void* k_buffer;             // [slots, hkv, 128]
+  void* k_buffer;             // [slots, hkv, 128], or head-major [hkv, slots, 128]
   void* v_buffer;
+  int64_t kv_slot, kv_head;   // elements between consecutive slots / kv heads of the two buffers
   const void* loc;            // [M] cache slot of each row, int64 or int32
   int loc_i32;
 };
@@ -98,8 +99,8 @@ __device__ __forceinline__ void qkv_rope_epilogue(const GemmTiledParams& p, f32x
   const int mbase = tm * 256 + g * 128 + r16;
   const bool rot = head < p.hq + p.hkv;
   T* cache_dst = nullptr;
-  if (head >= p.hq + p.hkv) cache_dst = (T*)p.v_buffer + (int64_t)(head - p.hq - p.hkv) * 128 + d0;
-  else if (head >= p.hq) cache_dst = (T*)p.k_buffer + (int64_t)(head - p.hq) * 128 + d0;
+  if (head >= p.hq + p.hkv) cache_dst = (T*)p.v_buffer + (int64_t)(head - p.hq - p.hkv) * p.kv_head + d0;
+  else if (head >= p.hq) cache_dst = (T*)p.k_buffer + (int64_t)(head - p.hq) * p.kv_head + d0;
   float slo[8], shi[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -184,7 +185,7 @@ __device__ __forceinline__ void qkv_rope_epilogue(const GemmTiledParams& p, f32x
         stvec<T, 8>(yg + (int64_t)m * p.ldy + col0, o1);
         stvec<T, 8>(yg + (int64_t)m * p.ldy + col0 + 64, o2);
         if (cache_dst != nullptr) {
-          T* dst = cache_dst + (int64_t)slotv[mi] * p.hkv * 128;
+          T* dst = cache_dst + (int64_t)slotv[mi] * p.kv_slot;
           stvec<T, 8>(dst, o1);
           stvec<T, 8>(dst + 64, o2);
         }
@@ -459,7 +460,7 @@ int launch_gemm_tiled(const GemmTiledParams& p, hipStream_t st) {
 
 void fill_tiles(GemmTiledParams& p, int64_t m, int64_t n, int epilogue) {
   p.positions = nullptr; p.cos_sin = nullptr; p.cs_f32 = 0; p.hq = p.hkv = 0;
-  p.k_buffer = p.v_buffer = nullptr; p.loc = nullptr; p.loc_i32 = 0;
+  p.k_buffer = p.v_buffer = nullptr; p.loc = nullptr; p.loc_i32 = 0; p.kv_slot = p.kv_head = 0;
   const int ncols = epilogue == 1 ? (int)(n / 2) : (int)n;
   p.ldy = ncols;
   p.mt = cdiv(m, 256);
@@ -548,6 +549,8 @@ extern "C" int mi355_qkv_proj_rope_tiled(void* qkv, const void* x, const void* w
                                          void* k_buffer, void* v_buffer, const void* loc, int loc_itype,
                                          int64_t num_slots, int dtype, void* stream) {
   const bool fp8 = x_scale != nullptr;
+  const int kv_flags = dtype;
+  dtype &= ~MI355_KV_HEAD_MAJOR;
   MI355_REQUIRE(qkv && x && w && positions && cos_sin_cache && k_buffer && v_buffer && loc, MI355_ERR_INVALID,
                 "mi355_qkv_proj_rope_tiled: null pointer");
   MI355_REQUIRE(!fp8 || w_scale, MI355_ERR_INVALID, "mi355_qkv_proj_rope_tiled: x_scale without w_scale");
@@ -574,6 +577,7 @@ extern "C" int mi355_qkv_proj_rope_tiled(void* qkv, const void* x, const void* w
   fill_tiles(p, m, n, 0);
   p.positions = positions; p.cos_sin = cos_sin_cache; p.cs_f32 = cache_dtype == MI355_F32;
   p.hq = hq; p.hkv = hkv; p.k_buffer = k_buffer; p.v_buffer = v_buffer; p.loc = loc;
+  kv_strides(kv_flags, num_slots, hkv, 128, p.kv_slot, p.kv_head);
   p.loc_i32 = loc_itype == MI355_I32;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MI355_BF16)

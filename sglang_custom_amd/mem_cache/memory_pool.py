@@ -6,7 +6,10 @@
   v_buffer[l]   T     [size + page_size, Hkv, Dv]
 
 One contiguous allocation backs all layers of K (and one of V), so a layer's buffer is a view;
-with 288 GB of HBM3E the pool is sized by the caller, not squeezed."""
+with 288 GB of HBM3E the pool is sized by the caller, not squeezed.  With head_major=True the
+memory behind a layer is [Hkv, size + page_size, D] and k_buffer[l] is its permute(1, 0, 2)
+view: the same tensor to every reader, but the rows one kv head's decode workgroup streams (one
+head, consecutive slots) are adjacent in HBM instead of Hkv * D elements apart."""
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -47,8 +50,9 @@ class ReqToTokenPool:
 
 class MHATokenToKVPool:
     def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int,
-                 layer_num: int, device: str, v_head_dim: Optional[int] = None):
+                 layer_num: int, device: str, v_head_dim: Optional[int] = None, head_major: bool = False):
         self.size = size
+        self.head_major = head_major
         self.page_size = page_size
         self.dtype = dtype
         self.store_dtype = dtype
@@ -58,10 +62,16 @@ class MHATokenToKVPool:
         self.layer_num = layer_num
         self.device = device
         rows = size + page_size
-        self._k_all = torch.zeros((layer_num, rows, head_num, head_dim), dtype=dtype, device=device)
-        self._v_all = torch.zeros((layer_num, rows, head_num, self.v_head_dim), dtype=dtype, device=device)
-        self.k_buffer = [self._k_all[i] for i in range(layer_num)]
-        self.v_buffer = [self._v_all[i] for i in range(layer_num)]
+        if head_major:
+            self._k_all = torch.zeros((layer_num, head_num, rows, head_dim), dtype=dtype, device=device)
+            self._v_all = torch.zeros((layer_num, head_num, rows, self.v_head_dim), dtype=dtype, device=device)
+            self.k_buffer = [self._k_all[i].permute(1, 0, 2) for i in range(layer_num)]
+            self.v_buffer = [self._v_all[i].permute(1, 0, 2) for i in range(layer_num)]
+        else:
+            self._k_all = torch.zeros((layer_num, rows, head_num, head_dim), dtype=dtype, device=device)
+            self._v_all = torch.zeros((layer_num, rows, head_num, self.v_head_dim), dtype=dtype, device=device)
+            self.k_buffer = [self._k_all[i] for i in range(layer_num)]
+            self.v_buffer = [self._v_all[i] for i in range(layer_num)]
 
     def get_kv_size_bytes(self) -> Tuple[int, int]:
         return (self._k_all.numel() * self._k_all.element_size(),

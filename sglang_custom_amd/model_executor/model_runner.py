@@ -139,9 +139,15 @@ class ModelRunner:
                 self.max_total_num_tokens, page, self.kv_cache_dtype, cfg.kv_lora_rank, cfg.qk_rope_head_dim,
                 cfg.num_hidden_layers, self.device)
         else:
+            layout = getattr(sa, "kv_layout", "auto")
+            if layout not in ("auto", "token_major", "head_major"):
+                raise ValueError(f"kv_layout {layout!r}: expected auto, token_major or head_major")
+            head_major = layout == "head_major" or (
+                layout == "auto" and str(self.device).startswith("cuda")
+                and self.dtype in (torch.bfloat16, torch.float16) and cfg.head_dim % 8 == 0)
             self.token_to_kv_pool = MHATokenToKVPool(
                 self.max_total_num_tokens, page, self.kv_cache_dtype, kv_heads, cfg.head_dim,
-                cfg.num_hidden_layers, self.device)
+                cfg.num_hidden_layers, self.device, head_major=head_major)
         if page == 1:
             self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(
                 self.max_total_num_tokens, self.dtype, self.device, self.token_to_kv_pool)

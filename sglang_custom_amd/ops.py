@@ -41,9 +41,25 @@ def _gpu(*ts):
 KV_FP8 = 0x100   # MI355_KV_FP8: OR'ed into the dtype code when the KV cache holds e4m3fn bytes
 
 
-def _kvdt(t: torch.Tensor, cache: torch.Tensor) -> int:
-    """dtype code of the 16-bit tensors, flagged when `cache` is an fp8 KV buffer."""
-    return _dt(t) | (KV_FP8 if cache.dtype == torch.float8_e4m3fn else 0)
+KV_HEAD_MAJOR = 0x200   # MI355_KV_HEAD_MAJOR: the [slots, heads, d] cache tensors are views of [heads, slots, d] memory
+
+
+def _kv_layout(buf: torch.Tensor) -> int:
+    """0 for a contiguous [slots, heads, d] cache tensor, KV_HEAD_MAJOR for the permute(1, 0, 2) view of a
+    contiguous [heads, slots, d] one; anything else is refused."""
+    if buf.is_contiguous():
+        return 0
+    assert buf.dim() == 3 and buf.stride() == (buf.shape[2], buf.shape[0] * buf.shape[2], 1), \
+        f"KV cache tensor is neither [slots, heads, d] contiguous nor a head-major view: strides {buf.stride()}"
+    return KV_HEAD_MAJOR
+
+
+def _kvdt(t: torch.Tensor, cache: torch.Tensor, v_cache: Optional[torch.Tensor] = None) -> int:
+    """dtype code of the 16-bit tensors, flagged when `cache` is an fp8 KV buffer and when it is head-major."""
+    lay = _kv_layout(cache)
+    if v_cache is not None:
+        assert _kv_layout(v_cache) == lay and v_cache.shape[0] == cache.shape[0], "k and v cache layouts differ"
+    return _dt(t) | (KV_FP8 if cache.dtype == torch.float8_e4m3fn else 0) | lay
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -129,7 +145,7 @@ def rope_inplace(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, head
     if fused:
         assert v is not None and v_buffer is not None and loc is not None
         v2 = v.view(T, -1)
-        assert v2.stride(1) == 1 and k_buffer.is_contiguous() and v_buffer.is_contiguous()
+        assert v2.stride(1) == 1
         assert k_buffer.dtype == q.dtype and v_buffer.dtype == q.dtype and v.dtype == q.dtype
         assert loc.is_contiguous() and loc.numel() == T
     check(_lib_().mi355_rope_inplace(
@@ -138,7 +154,7 @@ def rope_inplace(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, head
         k2.stride(0), v.view(T, -1).stride(0) if fused else 0, 1 if is_neox else 0,
         _p(k_buffer) if fused else None, _p(v_buffer) if fused else None,
         _p(loc) if fused else None, _IT[loc.dtype] if fused else I64,
-        k_buffer.shape[0] if fused else 0, _dt(q), _stream(q)), "rope_inplace")
+        k_buffer.shape[0] if fused else 0, _kvdt(q, k_buffer, v_buffer) if fused else _dt(q), _stream(q)), "rope_inplace")
 
 
 def set_kv_buffer(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor,
@@ -148,16 +164,23 @@ def set_kv_buffer(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Ten
     T = loc.numel()
     k2, v2 = cache_k.view(T, -1), cache_v.view(T, -1)
     assert k2.stride(1) == 1 and v2.stride(1) == 1 and loc.is_contiguous()
-    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
     assert cache_k.dtype == cache_v.dtype and k_buffer.dtype == v_buffer.dtype
     assert k_buffer.dtype in (cache_k.dtype, torch.float8_e4m3fn)
     k_row = k_buffer.numel() // k_buffer.shape[0]
     v_row = v_buffer.numel() // v_buffer.shape[0]
     assert k2.shape[1] == k_row and v2.shape[1] == v_row
+    kvdt = _kvdt(cache_k, k_buffer, v_buffer)
+    if kvdt & KV_HEAD_MAJOR:     # the scatter must know the heads: rows of the cache are not contiguous
+        heads = k_buffer.shape[1]
+        check(_lib_().mi355_set_kv_buffer_heads(k_buffer.data_ptr(), v_buffer.data_ptr(), k2.data_ptr(), v2.data_ptr(),
+                                                loc.data_ptr(), _IT[loc.dtype], T, heads, k_buffer.shape[2],
+                                                v_buffer.shape[2], k2.stride(0), v2.stride(0), k_buffer.shape[0],
+                                                kvdt, _stream(cache_k)), "set_kv_buffer_heads")
+        return
     check(_lib_().mi355_set_kv_buffer(k_buffer.data_ptr(), v_buffer.data_ptr(), k2.data_ptr(),
                                       v2.data_ptr(), loc.data_ptr(), _IT[loc.dtype], T, k_row,
                                       v_row, k2.stride(0), v2.stride(0), k_buffer.shape[0],
-                                      _kvdt(cache_k, k_buffer), _stream(cache_k)), "set_kv_buffer")
+                                      kvdt, _stream(cache_k)), "set_kv_buffer")
 
 
 def embedding(ids: torch.Tensor, table: torch.Tensor, vocab_start: int = 0,
@@ -335,7 +358,6 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     B, Hq, D = q.shape
     Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
     assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous()
-    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
     assert kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
     assert num_kv_splits <= max_kv_splits
     _split_scratch(attn_logits, attn_lse, B * Hq, Dv, num_kv_splits)
@@ -343,7 +365,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         kv_indices.data_ptr(), 1, None, None, kv_indptr.data_ptr(), 0, _p(attn_logits),
         _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), k_buffer.shape[0], float(sm_scale),
-        float(logit_cap), _dt(q), _stream(q)), "decode_attention")
+        float(logit_cap), _kvdt(q, k_buffer, v_buffer), _stream(q)), "decode_attention")
 
 
 def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
@@ -357,7 +379,6 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
     B, Hq, D = q.shape
     Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
     assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous()
-    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
     assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
     assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
     _split_scratch(attn_logits, attn_lse, B * Hq, Dv, num_kv_splits)
@@ -365,7 +386,7 @@ def decode_attention_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indi
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
         req_to_token.stride(0), _p(attn_logits), _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, Hkv, D, Dv,
-        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer), _stream(q)),
+        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer, v_buffer), _stream(q)),
         "decode_attention")
 
 
@@ -378,14 +399,13 @@ def decode_attention_paged_static(q, k_buffer, v_buffer, o, req_to_token, req_po
     B, Hq, D = q.shape
     Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
     assert q.stride(2) == 1 and q.stride(1) == D and o.is_contiguous()
-    assert k_buffer.is_contiguous() and v_buffer.is_contiguous()
     assert req_to_token.dtype == torch.int32 and req_to_token.stride(1) == 1
     assert req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
     check(_lib_().mi355_decode_attention_static(
         q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(),
         req_to_token.data_ptr(), 0, req_pool_indices.data_ptr(), seq_lens.data_ptr(), None,
         req_to_token.stride(0), num_kv_splits, B, Hq, Hkv, D, Dv,
-        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer), _stream(q)),
+        q.stride(0), k_buffer.shape[0], float(sm_scale), float(logit_cap), _kvdt(q, k_buffer, v_buffer), _stream(q)),
         "decode_attention_static")
 
 
@@ -400,7 +420,7 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
     Hkv = k_buffer.shape[1]
     assert qkv_part.dim() == 3 and qkv_part.is_contiguous() and qkv_part.dtype == torch.float32
     assert qkv_part.shape[1] == B and qkv_part.shape[2] == (Hq + 2 * Hkv) * D
-    assert k_buffer.is_contiguous() and v_buffer.is_contiguous() and o.is_contiguous()
+    assert o.is_contiguous()
     assert k_buffer.shape[1:] == (Hkv, D) and v_buffer.shape == k_buffer.shape
     assert k_buffer.dtype == v_buffer.dtype and k_buffer.dtype in (o.dtype, torch.float8_e4m3fn)
     assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == B
@@ -417,7 +437,7 @@ def decode_attention_fused_qkv(qkv_part, positions, out_cache_loc, cos_sin_cache
         out_cache_loc.data_ptr(), cos_sin_cache.data_ptr(),
         _dt(cos_sin_cache), k_buffer.data_ptr(), v_buffer.data_ptr(), o.data_ptr(), req_to_token.data_ptr(), 0,
         req_pool_indices.data_ptr(), seq_lens.data_ptr(), None, req_to_token.stride(0), _p(attn_logits),
-        _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _kvdt(o, k_buffer), _stream(o)),
+        _p(attn_lse), _tickets(tickets, B * Hq), _chunk(kv_chunk_keys), num_kv_splits, B, Hq, Hkv, D, k_buffer.shape[0], float(sm_scale), _kvdt(o, k_buffer, v_buffer), _stream(o)),
         "decode_attention_fused_qkv")
 
 
@@ -624,7 +644,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
     assert q_extend.stride(2) == 1 and q_extend.stride(1) == D
     assert k_extend.stride(2) == 1 and k_extend.stride(1) == D
     assert v_extend.stride(2) == 1 and v_extend.stride(1) == Dv
-    assert o_extend.is_contiguous() and k_buffer.is_contiguous() and v_buffer.is_contiguous()
+    assert o_extend.is_contiguous()
     assert qo_indptr.dtype == torch.int32 and kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
     if sm_scale is None:
         sm_scale = 1.0 / (D ** 0.5)
@@ -641,7 +661,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         1 if is_causal else 0, 1 if skip_prefix_custom_mask else 0, bs, int(max_len_extend), Hq,
         Hkv, D, Dv, q_extend.stride(0), k_extend.stride(0), v_extend.stride(0),
         k_buffer.shape[0], float(sm_scale), float(logit_cap), int(sliding_window_size),
-        _kvdt(q_extend, k_buffer), _stream(q_extend)), "extend_attention")
+        _kvdt(q_extend, k_buffer, v_buffer), _stream(q_extend)), "extend_attention")
 
 
 # ---------------------------------------------------------------------------------- linear
@@ -736,8 +756,9 @@ def qkv_proj_rope_tiled(x: torch.Tensor, weight: torch.Tensor, hq: int, hkv: int
     assert weight.shape == (N, K)
     assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == M
     assert cos_sin_cache.is_contiguous() and cos_sin_cache.dim() == 2
-    assert k_buffer.is_contiguous() and v_buffer.is_contiguous() and k_buffer.dtype == dtype and v_buffer.dtype == dtype
+    assert k_buffer.dtype == dtype and v_buffer.dtype == dtype
     assert k_buffer[0].numel() == hkv * head_dim and v_buffer[0].numel() == hkv * head_dim
+    assert _kv_layout(k_buffer) == _kv_layout(v_buffer) and k_buffer.shape == v_buffer.shape
     assert loc.is_contiguous() and loc.numel() == M
     if fp8:
         assert x.dtype == torch.float8_e4m3fn and x.is_contiguous()
@@ -750,7 +771,7 @@ def qkv_proj_rope_tiled(x: torch.Tensor, weight: torch.Tensor, hq: int, hkv: int
         qkv.data_ptr(), x.data_ptr(), weight.data_ptr(), _p(x_scale), _p(w_scale), M, K, x.stride(0), hq, hkv,
         head_dim, positions.data_ptr(), cos_sin_cache.data_ptr(), _dt(cos_sin_cache), cos_sin_cache.shape[1],
         1 if is_neox else 0, k_buffer.data_ptr(), v_buffer.data_ptr(), loc.data_ptr(), _IT[loc.dtype],
-        k_buffer.shape[0], _DT[dtype], _stream(x)), "qkv_proj_rope_tiled")
+        k_buffer.shape[0], _DT[dtype] | _kv_layout(k_buffer), _stream(x)), "qkv_proj_rope_tiled")
     return qkv
 
 

@@ -25,6 +25,11 @@ class ServerArgs:
     simulate_tp_shard: bool = False             # measurement aid: one TP rank, collectives stubbed
     chunked_prefill_size: Optional[int] = None   # None / -1: prompts are never split
     kv_cache_dtype: str = "auto"                  # "auto" = model dtype | "fp8_e4m3"
+    # Not in the reference: how the multi-head KV pool lies in HBM.  "token_major" is the reference's
+    # [slots, heads, d]; "head_major" stores [heads, slots, d] and hands out the permuted [slots, heads, d] view,
+    # so a kv head's rows of consecutive slots are adjacent (what one decode workgroup streams); "auto" picks
+    # head_major on the GPU for 16-bit models.
+    kv_layout: str = "auto"
     enable_mixed_chunk: bool = False              # decode requests ride along prefill batches as 1-token extends
     schedule_conservativeness: float = 1.0        # scales the initial new-token estimate (0.7) of admission
     page_size: int = 1                            # KV slots per page (> 1: page-aligned allocation)
