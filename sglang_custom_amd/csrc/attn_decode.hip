@@ -2640,11 +2640,13 @@ int mi355_decode_num_splits(int64_t bs, int hkv, int64_t max_seq_len, int max_sp
   // and every extra split costs fp32 partial traffic plus ~1 us of the merge launch.  Measured at
   // 1064 keys, head_dim 128 (microseconds, best in brackets): 8 workgroups unsplit 17.6 [6-8 splits:
   // 11.6]; 64: 19.9 [3: 14.4; 8: 19.1]; 128: 20.5 [2: 19.7; 4: 22.3]; 256: 31.7 [1; 2: 34.4].
-  // Long contexts (>= 1024 keys per split left) are split until every CU has a workgroup: 64 sequences x
-  // one kv head x 4136 keys took 35.2 / 33.4 / 33.5 us at 3 / 4 / 8 splits with the merge inside the launch.
+  // Long contexts (>= 1024 keys per split left) with fewer than 192 workgroups are split until every CU has one.
+  // 64 sequences x one kv head x 4136 keys with the merge inside the launch: 34.9 / 27.7 / 29.5 / 36.1 / 33.4 /
+  // 46.1 us at 2 / 3 / 4 / 6 / 8 / 16 splits -- 192 workgroups of 1 379 keys beat 256 of 1 034 (every split pays its
+  // own address chain and one more partial), and the same bytes unsplit (256 sequences x 1 034 keys) take 25.6.
   const int64_t wgs = bs * hkv;
   int64_t want = wgs >= 112 ? 1 : (160 + wgs - 1) / wgs;
-  if (want > 1 && wgs * want < 256 && max_seq_len / ((256 + wgs - 1) / wgs) >= 1024) want = (256 + wgs - 1) / wgs;
+  if (want > 1 && wgs * want < 192 && max_seq_len / ((256 + wgs - 1) / wgs) >= 1024) want = (256 + wgs - 1) / wgs;
   const int64_t by_len = max_seq_len / 128 > 0 ? max_seq_len / 128 : 1;
   if (want > by_len) want = by_len;
   if (want > max_splits) want = max_splits;
