@@ -47,6 +47,10 @@ extern "C" {
  * buffer.permute(1, 0, 2); num_slots must then be the buffer's true slot count (it is the head stride).  Latent
  * (MLA) caches have one head and ignore the flag. */
 #define MI355_KV_HEAD_MAJOR 0x200
+/* With MI355_KV_HEAD_MAJOR: k_buffer and v_buffer are the two halves of ONE allocation [Hkv, num_slots, 2, D]
+ * (v_buffer = k_buffer + D elements; head_dim == v_head_dim): a token's key and value row of a head are adjacent,
+ * so a decode workgroup reads one 2 D-element run per token instead of two D-element runs from two regions. */
+#define MI355_KV_INTERLEAVED 0x400
 
 #define MI355_ABI_VERSION 1
 int mi355_abi_version(void);

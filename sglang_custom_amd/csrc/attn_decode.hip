@@ -2680,6 +2680,8 @@ int mi355_decode_attention(const void* q, const void* k_buffer, const void* v_bu
   MI355_REQUIRE(num_splits == 1 || (attn_logits && attn_lse), MI355_ERR_INVALID,
                 "decode_attention: split-KV needs attn_logits and attn_lse scratch");
   MI355_REQUIRE(bs <= 65535, MI355_ERR_UNSUPPORTED, "decode_attention: batch > 65535");
+  MI355_REQUIRE(!(dtype & MI355_KV_INTERLEAVED) || ((dtype & MI355_KV_HEAD_MAJOR) && head_dim == v_head_dim), MI355_ERR_INVALID,
+                "decode_attention: an interleaved cache is head-major with head_dim == v_head_dim");
   if (bs == 0) return MI355_OK;
   DecodeParams p;
   p.page_table = page_table;

@@ -963,6 +963,8 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
   p.sliding_window = sliding_window_size;
   p.sm_scale = sm_scale;
   p.logit_cap = logit_cap;
+  MI355_REQUIRE(!(dtype & MI355_KV_INTERLEAVED) || ((dtype & MI355_KV_HEAD_MAJOR) && head_dim == v_head_dim), MI355_ERR_INVALID,
+                "extend_attention: an interleaved cache is head-major with head_dim == v_head_dim");
   kv_strides(dtype, num_slots, hkv, head_dim, p.kb_slot, p.kb_head);
   kv_strides(dtype, num_slots, hkv, v_head_dim, p.vb_slot, p.vb_head);
   int rc = MI355_OK;

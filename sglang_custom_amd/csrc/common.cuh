@@ -155,11 +155,13 @@ __device__ __forceinline__ float block_max256(float x, float* red) {
 }
 
 // Strides (elements) of a KV cache buffer of `heads` heads x `d` features over `num_slots` slots:
-// [num_slots, heads, d], or [heads, num_slots, d] when the dtype argument carries MI355_KV_HEAD_MAJOR.
+// [num_slots, heads, d], or [heads, num_slots, d] when the dtype argument carries MI355_KV_HEAD_MAJOR, or one half
+// of [heads, num_slots, 2, d] (keys | values) when it also carries MI355_KV_INTERLEAVED.
 inline void kv_strides(int dtype_flags, int64_t num_slots, int heads, int d, int64_t& slot_stride, int64_t& head_stride) {
   if (dtype_flags & MI355_KV_HEAD_MAJOR) {
-    slot_stride = d;
-    head_stride = num_slots * (int64_t)d;
+    const int64_t row = (dtype_flags & MI355_KV_INTERLEAVED) ? 2 * (int64_t)d : d;
+    slot_stride = row;
+    head_stride = num_slots * row;
   } else {
     slot_stride = (int64_t)heads * d;
     head_stride = d;

@@ -759,7 +759,7 @@ int mi355_rope_inplace(void* q, void* k, const void* v, const int64_t* positions
                        const void* loc, int loc_itype, int64_t num_slots, int dtype,
                        void* stream) {
   const int kv_flags = dtype;
-  dtype &= ~MI355_KV_HEAD_MAJOR;
+  dtype &= ~(MI355_KV_HEAD_MAJOR | MI355_KV_INTERLEAVED);
   MI355_REQUIRE(q && k && positions && cos_sin_cache, MI355_ERR_INVALID, "rope: null pointer");
   MI355_REQUIRE(tokens >= 0 && hq > 0 && hkv >= 0 && head_dim > 0 && rotary_dim > 0 &&
                     rotary_dim <= head_dim && rotary_dim % 2 == 0,
@@ -838,6 +838,8 @@ int mi355_set_kv_buffer_heads(void* k_buffer, void* v_buffer, const void* k, con
                     (reinterpret_cast<uintptr_t>(v_buffer) & (kv8 ? 7 : 15)) == 0,
                 MI355_ERR_UNSUPPORTED,
                 "set_kv_buffer_heads: needs 16-bit k / v, head dims and row strides in multiples of 8, aligned pointers");
+  MI355_REQUIRE(!(dtype & MI355_KV_INTERLEAVED) || ((dtype & MI355_KV_HEAD_MAJOR) && k_head_dim == v_head_dim), MI355_ERR_INVALID,
+                "set_kv_buffer_heads: an interleaved cache is head-major with equal head dims");
   if (tokens == 0) return MI355_OK;
   int64_t ks, kh, vs, vh;
   kv_strides(dtype, num_slots, heads, k_head_dim, ks, kh);

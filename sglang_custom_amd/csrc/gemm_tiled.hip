@@ -550,7 +550,7 @@ extern "C" int mi355_qkv_proj_rope_tiled(void* qkv, const void* x, const void* w
                                          int64_t num_slots, int dtype, void* stream) {
   const bool fp8 = x_scale != nullptr;
   const int kv_flags = dtype;
-  dtype &= ~MI355_KV_HEAD_MAJOR;
+  dtype &= ~(MI355_KV_HEAD_MAJOR | MI355_KV_INTERLEAVED);
   MI355_REQUIRE(qkv && x && w && positions && cos_sin_cache && k_buffer && v_buffer && loc, MI355_ERR_INVALID,
                 "mi355_qkv_proj_rope_tiled: null pointer");
   MI355_REQUIRE(!fp8 || w_scale, MI355_ERR_INVALID, "mi355_qkv_proj_rope_tiled: x_scale without w_scale");

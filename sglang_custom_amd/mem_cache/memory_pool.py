@@ -7,8 +7,8 @@
 
 One contiguous allocation backs all layers of K (and one of V), so a layer's buffer is a view;
 with 288 GB of HBM3E the pool is sized by the caller, not squeezed.  With head_major=True the
-memory behind a layer is [Hkv, size + page_size, D] and k_buffer[l] is its permute(1, 0, 2)
-view: the same tensor to every reader, but the rows one kv head's decode workgroup streams (one
+memory behind a layer is [Hkv, size + page_size, 2, D] (keys | values; two [Hkv, size + page_size, D]
+allocations when D != Dv) and k_buffer[l] / v_buffer[l] are permute(1, 0, 2) views of its halves: the same tensor to every reader, but the rows one kv head's decode workgroup streams (one
 head, consecutive slots) are adjacent in HBM instead of Hkv * D elements apart."""
 from typing import List, Optional, Tuple, Union
 
@@ -62,7 +62,13 @@ class MHATokenToKVPool:
         self.layer_num = layer_num
         self.device = device
         rows = size + page_size
-        if head_major:
+        if head_major and self.v_head_dim == head_dim:
+            # keys and values of a (head, slot) side by side: one 2 D run per token for the workgroup that streams them
+            self._kv_all = torch.zeros((layer_num, head_num, rows, 2, head_dim), dtype=dtype, device=device)
+            self._k_all, self._v_all = self._kv_all[..., 0, :], self._kv_all[..., 1, :]
+            self.k_buffer = [self._k_all[i].permute(1, 0, 2) for i in range(layer_num)]
+            self.v_buffer = [self._v_all[i].permute(1, 0, 2) for i in range(layer_num)]
+        elif head_major:
             self._k_all = torch.zeros((layer_num, head_num, rows, head_dim), dtype=dtype, device=device)
             self._v_all = torch.zeros((layer_num, head_num, rows, self.v_head_dim), dtype=dtype, device=device)
             self.k_buffer = [self._k_all[i].permute(1, 0, 2) for i in range(layer_num)]

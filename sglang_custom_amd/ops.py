@@ -44,14 +44,22 @@ KV_FP8 = 0x100   # MI355_KV_FP8: OR'ed into the dtype code when the KV cache hol
 KV_HEAD_MAJOR = 0x200   # MI355_KV_HEAD_MAJOR: the [slots, heads, d] cache tensors are views of [heads, slots, d] memory
 
 
+KV_INTERLEAVED = 0x400  # MI355_KV_INTERLEAVED: ... of [heads, slots, 2, d] memory, keys in [..., 0, :], values in [..., 1, :]
+
+
 def _kv_layout(buf: torch.Tensor) -> int:
     """0 for a contiguous [slots, heads, d] cache tensor, KV_HEAD_MAJOR for the permute(1, 0, 2) view of a
-    contiguous [heads, slots, d] one; anything else is refused."""
+    contiguous [heads, slots, d] one, KV_HEAD_MAJOR | KV_INTERLEAVED for one half of a contiguous
+    [heads, slots, 2, d] one seen the same way; anything else is refused."""
     if buf.is_contiguous():
         return 0
-    assert buf.dim() == 3 and buf.stride() == (buf.shape[2], buf.shape[0] * buf.shape[2], 1), \
+    assert buf.dim() == 3 and buf.stride(2) == 1, f"KV cache tensor with strides {buf.stride()}"
+    s, _, d = buf.shape
+    if buf.stride() == (d, s * d, 1):
+        return KV_HEAD_MAJOR
+    assert buf.stride() == (2 * d, 2 * s * d, 1), \
         f"KV cache tensor is neither [slots, heads, d] contiguous nor a head-major view: strides {buf.stride()}"
-    return KV_HEAD_MAJOR
+    return KV_HEAD_MAJOR | KV_INTERLEAVED
 
 
 def _kvdt(t: torch.Tensor, cache: torch.Tensor, v_cache: Optional[torch.Tensor] = None) -> int:
@@ -59,6 +67,10 @@ def _kvdt(t: torch.Tensor, cache: torch.Tensor, v_cache: Optional[torch.Tensor] 
     lay = _kv_layout(cache)
     if v_cache is not None:
         assert _kv_layout(v_cache) == lay and v_cache.shape[0] == cache.shape[0], "k and v cache layouts differ"
+        if lay & KV_INTERLEAVED:
+            assert (v_cache.shape == cache.shape
+                    and v_cache.data_ptr() == cache.data_ptr() + cache.shape[2] * cache.element_size()), \
+                "an interleaved cache holds a token's value row right behind its key row"
     return _dt(t) | (KV_FP8 if cache.dtype == torch.float8_e4m3fn else 0) | lay
 
 
@@ -771,7 +783,8 @@ def qkv_proj_rope_tiled(x: torch.Tensor, weight: torch.Tensor, hq: int, hkv: int
         qkv.data_ptr(), x.data_ptr(), weight.data_ptr(), _p(x_scale), _p(w_scale), M, K, x.stride(0), hq, hkv,
         head_dim, positions.data_ptr(), cos_sin_cache.data_ptr(), _dt(cos_sin_cache), cos_sin_cache.shape[1],
         1 if is_neox else 0, k_buffer.data_ptr(), v_buffer.data_ptr(), loc.data_ptr(), _IT[loc.dtype],
-        k_buffer.shape[0], _DT[dtype] | _kv_layout(k_buffer), _stream(x)), "qkv_proj_rope_tiled")
+        k_buffer.shape[0], _DT[dtype] | (_kvdt(qkv, k_buffer, v_buffer) & (KV_HEAD_MAJOR | KV_INTERLEAVED)), _stream(x)),
+        "qkv_proj_rope_tiled")
     return qkv
 
 

@@ -1,5 +1,6 @@
 """The head-major KV cache (MI355_KV_HEAD_MAJOR): memory [heads, slots, d] seen through permute(1, 0, 2) as the
-[slots, heads, d] tensor of MHATokenToKVPool.get_key_buffer (mem_cache/memory_pool.py:395-418).  Every entry point
+[slots, heads, d] tensor of MHATokenToKVPool.get_key_buffer (mem_cache/memory_pool.py:395-418), and its interleaved
+form (MI355_KV_INTERLEAVED): keys and values as the halves of one [heads, slots, 2, d] allocation.  Every entry point
 that reads or writes the multi-head cache must give the SAME bits over a head-major cache as over the
 reference's layout holding the same values: the scatter, the RoPE launch that writes the cache, the prefill
 projection that writes the cache, decode attention in every addressing mode and split plan (16-bit and e4m3fn
@@ -26,6 +27,22 @@ def head_major(buf):
     return hm
 
 
+def relayout(kb, vb, layout):
+    """(k, v) caches holding the values of the contiguous pair, head-major or as the halves of one
+    [heads, slots, 2, d] allocation (head-major when the two head dims differ)."""
+    if layout == "interleaved" and kb.shape == vb.shape:
+        s, h, d = kb.shape
+        kv = torch.empty((h, s, 2, d), dtype=kb.dtype, device=kb.device)
+        k, v = kv[:, :, 0, :].permute(1, 0, 2), kv[:, :, 1, :].permute(1, 0, 2)
+        k.copy_(kb)
+        v.copy_(vb)
+        return k, v
+    return head_major(kb), head_major(vb)
+
+
+LAYOUTS = pytest.mark.parametrize("layout", ["head_major", "interleaved"])
+
+
 def bits(t):
     return t.contiguous().view(torch.uint8 if t.element_size() == 1 else torch.int16 if t.element_size() == 2 else torch.int32)
 
@@ -50,17 +67,18 @@ def paged_world(bs, maxlen, hkv, d, dtype, seed, kv8=False, dv=None):
     return lens.to(DEV), r2t.to(DEV), rpi.to(DEV), kb, vb, slots
 
 
+@LAYOUTS
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
 @pytest.mark.parametrize("loc_dt", [torch.int64, torch.int32])
-def test_scatter_into_a_head_major_cache(ops, dtype, kv8, loc_dt):
+def test_scatter_into_a_head_major_cache(ops, dtype, kv8, loc_dt, layout):
     torch.manual_seed(0)
     for heads, kd, vd, tokens in [(8, 128, 128, 37), (1, 128, 128, 5), (3, 64, 40, 300), (2, 8, 16, 1)]:
         slots = 2 * tokens + 3
         cdt = torch.float8_e4m3fn if kv8 else dtype
         kb = torch.zeros(slots, heads, kd, dtype=cdt, device=DEV)
         vb = torch.zeros(slots, heads, vd, dtype=cdt, device=DEV)
-        kh, vh = head_major(kb), head_major(vb)
+        kh, vh = relayout(kb, vb, layout)
         rows = torch.randn(tokens, heads * (kd + vd) + 8, device=DEV, dtype=dtype) * 3
         if kv8:
             rows[0, :3] = torch.tensor([1000.0, -1000.0, 1e-3], dtype=dtype, device=DEV)
@@ -94,9 +112,10 @@ def test_layouts_that_are_neither_are_refused(ops):
         ops.set_kv_buffer(g32, g32, loc, k32, k32)
 
 
+@LAYOUTS
 @pytest.mark.parametrize("dtype,neox,rot", [(torch.bfloat16, True, 128), (torch.float16, True, 128), (torch.bfloat16, False, 128),
                                             (torch.bfloat16, True, 64)])
-def test_rope_launch_that_writes_a_head_major_cache(ops, dtype, neox, rot):
+def test_rope_launch_that_writes_a_head_major_cache(ops, dtype, neox, rot, layout):
     torch.manual_seed(1)
     D, hq, hkv, T = 128, 8, 4, 33
     slots = 80
@@ -108,7 +127,7 @@ def test_rope_launch_that_writes_a_head_major_cache(ops, dtype, neox, rot):
     loc = (torch.randperm(slots - 1, device=DEV)[:T] + 1).to(torch.int64)
     kb = torch.randn(slots, hkv, D, device=DEV, dtype=dtype)
     vb = torch.randn(slots, hkv, D, device=DEV, dtype=dtype)
-    kh, vh = head_major(kb), head_major(vb)
+    kh, vh = relayout(kb, vb, layout)
     q1, k1 = q.clone(), k.clone()
     ops.rope_inplace(pos, q1, k1, D, cs, neox, v=v, k_buffer=kb, v_buffer=vb, loc=loc)
     q2, k2 = q.clone(), k.clone()
@@ -118,16 +137,17 @@ def test_rope_launch_that_writes_a_head_major_cache(ops, dtype, neox, rot):
     assert torch.equal(bits(kh), bits(kb)) and torch.equal(bits(vh), bits(vb))
 
 
+@LAYOUTS
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
 @pytest.mark.parametrize("hq,hkv,d,bs,maxlen,splits,tickets", [
     (32, 8, 128, 9, 300, 1, False), (32, 8, 128, 9, 300, 4, True), (16, 2, 128, 6, 530, 3, False), (8, 8, 128, 5, 70, 2, True),
     (8, 1, 128, 19, 90, 1, False), (8, 4, 64, 7, 200, 2, False), (4, 2, 256, 3, 150, 1, False), (6, 3, 80, 4, 100, 2, False)])
-def test_decode_attention_over_a_head_major_cache(ops, dtype, kv8, hq, hkv, d, bs, maxlen, splits, tickets):
+def test_decode_attention_over_a_head_major_cache(ops, dtype, kv8, hq, hkv, d, bs, maxlen, splits, tickets, layout):
     if kv8 and d != 128:
         pytest.skip("an fp8 cache is served at head_dim 128 only")
     lens, r2t, rpi, kb, vb, slots = paged_world(bs, maxlen, hkv, d, dtype, seed=hq + d + bs, kv8=kv8)
-    kh, vh = head_major(kb), head_major(vb)
+    kh, vh = relayout(kb, vb, layout)
     q = torch.randn(bs, hq, d, device=DEV, dtype=dtype)
     lg = torch.empty(bs * hq * splits * d, dtype=torch.float32, device=DEV)
     ls = torch.empty(bs * hq * splits, dtype=torch.float32, device=DEV)
@@ -156,9 +176,10 @@ def test_decode_attention_over_a_head_major_cache(ops, dtype, kv8, hq, hkv, d, b
     assert torch.equal(bits(o3), bits(o4))
 
 
+@LAYOUTS
 @pytest.mark.parametrize("dtype,cache_dtype", [(torch.bfloat16, torch.float32), (torch.float16, torch.float16)])
 @pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
-def test_decode_launch_from_qkv_partials_over_a_head_major_cache(ops, dtype, cache_dtype, kv8):
+def test_decode_launch_from_qkv_partials_over_a_head_major_cache(ops, dtype, cache_dtype, kv8, layout):
     torch.manual_seed(2)
     D, hidden = 128, 1024
     for hq, hkv, bs, maxlen, splits in [(32, 8, 9, 300, 1), (16, 2, 6, 530, 3), (8, 1, 19, 90, 1)]:
@@ -177,7 +198,7 @@ def test_decode_launch_from_qkv_partials_over_a_head_major_cache(ops, dtype, cac
         for hm in (False, True):
             kb, vb = kb0.clone(), vb0.clone()
             if hm:
-                kb, vb = head_major(kb), head_major(vb)
+                kb, vb = relayout(kb, vb, layout)
             o = torch.empty(bs, hq, D, device=DEV, dtype=dtype)
             ops.decode_attention_fused_qkv(part, positions, loc, cs, kb, vb, o, r2t, rpi, lens, lg, ls, splits, D ** -0.5, tickets=tk)
             torch.cuda.synchronize()
@@ -186,10 +207,11 @@ def test_decode_launch_from_qkv_partials_over_a_head_major_cache(ops, dtype, cac
         assert torch.equal(bits(res[0][1]), bits(res[1][1])) and torch.equal(bits(res[0][2]), bits(res[1][2]))
 
 
+@LAYOUTS
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
 @pytest.mark.parametrize("hq,hkv,d", [(8, 2, 128), (4, 4, 128), (6, 3, 64)])
-def test_prefill_attention_over_a_cached_prefix_in_a_head_major_cache(ops, dtype, kv8, hq, hkv, d):
+def test_prefill_attention_over_a_cached_prefix_in_a_head_major_cache(ops, dtype, kv8, hq, hkv, d, layout):
     if kv8 and d != 128:
         pytest.skip("an fp8 cache is served at head_dim 128 only")
     g = torch.Generator().manual_seed(hq * 7 + d)
@@ -211,7 +233,7 @@ def test_prefill_attention_over_a_cached_prefix_in_a_head_major_cache(ops, dtype
     kvp[1:] = torch.tensor(prefix).cumsum(0)
     kvi = (torch.randperm(slots - 1, generator=g)[: sum(prefix)] + 1).to(torch.int32)
     outs = []
-    for k_, v_ in ((kb, vb), (head_major(kb), head_major(vb))):
+    for k_, v_ in ((kb, vb), relayout(kb, vb, layout)):
         o = torch.full((T, hq, d), float("nan"), device=DEV, dtype=dtype)
         ops.extend_attention_fwd(q, k, v, o, k_, v_, qo.to(DEV), kvp.to(DEV), kvi.to(DEV), None, True, None, max(ext), d ** -0.5)
         torch.cuda.synchronize()
@@ -220,8 +242,9 @@ def test_prefill_attention_over_a_cached_prefix_in_a_head_major_cache(ops, dtype
     assert torch.equal(bits(outs[0]), bits(outs[1]))
 
 
+@LAYOUTS
 @pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8_w8a8"])
-def test_prefill_projection_that_writes_a_head_major_cache(ops, fp8):
+def test_prefill_projection_that_writes_a_head_major_cache(ops, fp8, layout):
     torch.manual_seed(3)
     dtype = torch.bfloat16
     m, kdim, hq, hkv, D = 300, 512, 8, 2, 128
@@ -247,7 +270,7 @@ def test_prefill_projection_that_writes_a_head_major_cache(ops, fp8):
         kb = torch.zeros(slots, hkv, D, device=DEV, dtype=dtype)
         vb = torch.zeros(slots, hkv, D, device=DEV, dtype=dtype)
         if hm:
-            kb, vb = head_major(kb), head_major(vb)
+            kb, vb = relayout(kb, vb, layout)
         qkv = ops.qkv_proj_rope_tiled(x_in, w_in, hq, hkv, D, pos, cs, True, kb, vb, loc, **kw)
         torch.cuda.synchronize()
         res.append((qkv, kb, vb))
@@ -279,6 +302,9 @@ def test_model_runner_gives_the_same_logits_over_either_layout(graphs, quant, kv
                         cuda_graph_bs=[1, 2, 4], quantization=quant, kv_cache_dtype=kvd, kv_layout=layout)
         mr = ModelRunner(ModelConfig(cfg, dtype="bfloat16"), sa, weights={k: v.cuda() for k, v in w.items()})
         assert mr.token_to_kv_pool.head_major == (layout == "auto")
+        if layout == "auto":      # keys | values of a (head, slot) side by side in one allocation
+            kb0, vb0 = mr.token_to_kv_pool.get_kv_buffer(0)
+            assert vb0.data_ptr() == kb0.data_ptr() + kb0.shape[2] * kb0.element_size()
         prompts = cases.e2e_prompts(cfg["vocab_size"], lens)
         bob.clear_pools(mr)
         reqs = [Req(i, p) for i, p in enumerate(prompts)]
