@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(cfg_name, dtype_name, tp_rank=0, tp_size=1, init_method=None):
+def _build(cfg_name, dtype_name, tp_rank=0, tp_size=1, init_method=None, kv_layout="auto"):
     import cpu_ops
     from sglang_custom_amd import ops_backend
     from sglang_custom_amd.configs.model_config import ModelConfig
@@ -28,7 +28,7 @@ def _build(cfg_name, dtype_name, tp_rank=0, tp_size=1, init_method=None):
     dt = getattr(torch, dtype_name)
     w = make_synthetic_llama_weights(cfg, seed=1234, dtype=dt)
     sa = ServerArgs(dtype=dtype_name, device="cpu", max_total_tokens=512, max_running_requests=8,
-                    disable_cuda_graph=True, dist_backend="gloo", dist_init_method=init_method)
+                    disable_cuda_graph=True, dist_backend="gloo", dist_init_method=init_method, kv_layout=kv_layout)
     mr = ModelRunner(ModelConfig(cfg, dtype=dtype_name), sa, tp_rank=tp_rank, tp_size=tp_size, weights=w)
     return cfg, w, dt, mr
 
@@ -68,6 +68,37 @@ def test_single_process_host_path_matches_oracle():
     assert r2t[batch.req_pool_indices[1], :17].tolist() == list(range(6, 23))
     assert int(r2t[batch.req_pool_indices[0], 5]) == 55 and int(r2t[batch.req_pool_indices[1], 17]) == 56
     assert batch.seq_lens.tolist() == [5 + 3, 17 + 3, 32 + 3]
+
+
+def test_head_major_kv_pool_is_the_same_tensor_to_every_reader():
+    """kv_layout="head_major": the memory behind a layer is [heads, slots, 2, d] (keys | values), what get_key_buffer /
+    get_value_buffer hand out is still [slots, heads, d]; the host path over it gives the oracle's tokens and logits,
+    and the rows land where the views say.  "auto" keeps the reference's layout on the CPU; other values are refused."""
+    from oracle.llama_ref import OracleLlama
+
+    cfg, w, dt, mr = _build("tiny-llama-d64", "float32", kv_layout="head_major")
+    pool = mr.token_to_kv_pool
+    kb, vb = pool.get_kv_buffer(0)
+    heads, d = kb.shape[1], kb.shape[2]
+    assert pool.head_major and kb.shape == vb.shape and kb.shape[0] == pool.size + pool.page_size
+    assert kb.stride() == (2 * d, 2 * kb.shape[0] * d, 1) and vb.data_ptr() == kb.data_ptr() + d * kb.element_size()
+    prompts = _prompts(cfg)
+    ref_toks, ref_logits = OracleLlama(cfg, w, dt, max_total_tokens=512).generate_greedy(prompts, 4)
+    toks, lg, batch = _run(mr, prompts, 3)
+    assert torch.equal(toks, ref_toks)
+    for a, b in zip(lg, ref_logits):
+        assert (a - b).abs().max() < 1e-4
+    # the same run over the reference's layout leaves the same rows behind the same view
+    cfg2, w2, dt2, mr2 = _build("tiny-llama-d64", "float32", kv_layout="token_major")
+    assert not mr2.token_to_kv_pool.head_major and mr2.token_to_kv_pool.get_key_buffer(0).is_contiguous()
+    _run(mr2, prompts, 3)
+    for layer in range(cfg["num_hidden_layers"]):
+        k1, v1 = pool.get_kv_buffer(layer)
+        k2, v2 = mr2.token_to_kv_pool.get_kv_buffer(layer)
+        assert torch.equal(k1[1:], k2[1:]) and torch.equal(v1[1:], v2[1:])
+    assert not _build("tiny-llama-d64", "float32")[3].token_to_kv_pool.head_major     # "auto" on the CPU
+    with pytest.raises(ValueError):
+        _build("tiny-llama-d64", "float32", kv_layout="sideways")
 
 
 def _tp_worker(rank, world, port, q):
