@@ -747,16 +747,55 @@ __global__ __launch_bounds__(256) void decode_attn_mfma_pv_kernel(const T* __res
   __shared__ __attribute__((aligned(16))) T sm_qkv[FUSED ? (G + 2) * D : 8];
   auto reduce_qkv_to_lds = [&]() {
     const int64_t pos = fz.positions[b];
-    for (int v = threadIdx.x; v < (G + 2) * 32; v += 256) {
+    // Every thread's items (one, or two at G = 8) and up to eight splits go out as ONE batch of loads -- clamped
+    // addresses, masked values, never a condition on a load -- so a projection cut eleven ways (a tensor-parallel
+    // rank's narrow qkv) costs two memory round trips here, not six.  The sum per element stays in split order.
+    constexpr int ITEMS = ((G + 2) * 32 + 255) / 256;
+    float sums[ITEMS][4];
+    {
+      const float* srcs[ITEMS];
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        const int v = min((int)threadIdx.x + it * 256, (G + 2) * 32 - 1);
+        const int seg = v >> 5, f4 = v & 31;
+        const int64_t head = seg < G ? head0 + seg : seg == G ? p.hq + kvh : p.hq + p.hkv + kvh;
+        srcs[it] = fz.part + (int64_t)b * fz.row + head * D + 4 * f4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sums[it][j] = 0.f;
+      }
+      if (fz.nsplit <= 4) {
+        float4 f[ITEMS][4];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) f[it][u] = *reinterpret_cast<const float4*>(srcs[it] + min(u, fz.nsplit - 1) * fz.split_stride);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (u < fz.nsplit) { sums[it][0] += f[it][u].x; sums[it][1] += f[it][u].y; sums[it][2] += f[it][u].z; sums[it][3] += f[it][u].w; }
+      } else {
+        for (int sp0 = 0; sp0 < fz.nsplit; sp0 += 8) {
+          float4 f[ITEMS][8];
+#pragma unroll
+          for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[it][u] = *reinterpret_cast<const float4*>(srcs[it] + min(sp0 + u, fz.nsplit - 1) * fz.split_stride);
+#pragma unroll
+          for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (sp0 + u < fz.nsplit) { sums[it][0] += f[it][u].x; sums[it][1] += f[it][u].y; sums[it][2] += f[it][u].z; sums[it][3] += f[it][u].w; }
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int v = threadIdx.x + it * 256;
+      if (v >= (G + 2) * 32) break;   // (whole 32-lane slices drop out together)
       const int seg = v >> 5, f4 = v & 31;
       const int64_t head = seg < G ? head0 + seg : seg == G ? p.hq + kvh : p.hq + p.hkv + kvh;
-      const float* src = fz.part + (int64_t)b * fz.row + head * D + 4 * f4;
-      float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int sp = 0; sp < fz.nsplit; ++sp) {
-        const float4 f = *reinterpret_cast<const float4*>(src + sp * fz.split_stride);
-        sum[0] += f.x; sum[1] += f.y; sum[2] += f.z; sum[3] += f.w;
-      }
+      const float (&sum)[4] = sums[it];
       Vec<T, 4> out;
       if (fz.xs) {   // the fp8 GEMM's epilogue: (acc * x_scale[m]) * w_scale[n], cast once
         const float xs = fz.xs[b];

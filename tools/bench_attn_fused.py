@@ -1,5 +1,6 @@
 """Dev tool: the decode attention launch that starts from the qkv projection's split-K partials (sum, RoPE,
-KV-cache write, attention) against the plain attention launch on ready-made q, at the bench shape."""
+KV-cache write, attention) against the plain attention launch on ready-made q, at the bench shape.
+usage: [QKV_SPLITS=4] [KV_SPLITS=1] python tools/bench_attn_fused.py [bs hq hkv [ctx]]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_custom_amd import ops, _lib
@@ -38,6 +39,10 @@ def timeit(fn, reps=12):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (3 * reps) * 1e3
 nbytes = bs * ctx * hkv * D * 2 * 2
-t0 = timeit(lambda i: ops.decode_attention_paged(q, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, None, None, 1, D ** -0.5))
-t1 = timeit(lambda i: ops.decode_attention_fused_qkv(part[i % NL], pos, loc, cache, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, None, None, 1, D ** -0.5))
-print(f"plain {t0:6.1f} us {nbytes / t0 / 1e6:5.2f} TB/s   from {nsplit} qkv partials {t1:6.1f} us {nbytes / t1 / 1e6:5.2f} TB/s", flush=True)
+ks = int(os.environ.get('KV_SPLITS', '1'))       # KV splits, merged inside the launch
+lg = torch.empty(bs * hq * ks * D, dtype=torch.float32, device='cuda') if ks > 1 else None
+ls = torch.empty(bs * hq * ks, dtype=torch.float32, device='cuda') if ks > 1 else None
+tk = torch.zeros(bs * hq, dtype=torch.int32, device='cuda') if ks > 1 else None
+t0 = timeit(lambda i: ops.decode_attention_paged(q, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, lg, ls, ks, D ** -0.5, tickets=tk))
+t1 = timeit(lambda i: ops.decode_attention_fused_qkv(part[i % NL], pos, loc, cache, kb[i % NL], vb[i % NL], o, r2t, rpi, sl, lg, ls, ks, D ** -0.5, tickets=tk))
+print(f"{ks} KV split(s): plain {t0:6.1f} us {nbytes / t0 / 1e6:5.2f} TB/s   from {nsplit} qkv partials {t1:6.1f} us {nbytes / t1 / 1e6:5.2f} TB/s", flush=True)
