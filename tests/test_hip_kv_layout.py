@@ -176,6 +176,26 @@ def test_decode_attention_over_a_head_major_cache(ops, dtype, kv8, hq, hkv, d, b
     assert torch.equal(bits(o3), bits(o4))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_decode_attention_with_different_key_and_value_widths_over_a_head_major_cache(ops, dtype):
+    """head_dim != v_head_dim: two head-major allocations with their own strides (the generic kernel)."""
+    hq, hkv, d, dv, bs, maxlen = 6, 3, 80, 48, 5, 120
+    lens, r2t, rpi, kb, vb, slots = paged_world(bs, maxlen, hkv, d, dtype, seed=11, dv=dv)
+    q = torch.randn(bs, hq, d, device=DEV, dtype=dtype)
+    outs = []
+    for splits in (1, 3):
+        lg = torch.empty(bs * hq * splits * dv, dtype=torch.float32, device=DEV)
+        ls = torch.empty(bs * hq * splits, dtype=torch.float32, device=DEV)
+        pair = []
+        for k_, v_ in ((kb, vb), (head_major(kb), head_major(vb))):
+            o = torch.full((bs, hq, dv), float("nan"), device=DEV, dtype=dtype)
+            ops.decode_attention_paged(q, k_, v_, o, r2t, rpi, lens, lg, ls, splits, d ** -0.5)
+            torch.cuda.synchronize()
+            assert not torch.isnan(o.float()).any()
+            pair.append(o)
+        assert torch.equal(bits(pair[0]), bits(pair[1])), splits
+
+
 @LAYOUTS
 @pytest.mark.parametrize("dtype,cache_dtype", [(torch.bfloat16, torch.float32), (torch.float16, torch.float16)])
 @pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
