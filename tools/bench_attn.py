@@ -19,6 +19,14 @@ vb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
 import os
 if os.environ.get('KV8'):
     kb = [t.to(torch.float8_e4m3fn) for t in kb]; vb = [t.to(torch.float8_e4m3fn) for t in vb]
+if os.environ.get('LAYOUT', 'hm') == 'hm':   # the pool's layout on the GPU: [heads, slots, 2, d], keys | values (LAYOUT=tm: the reference's)
+    def _hm(k_, v_):
+        kv = torch.empty((hkv, slots, 2, D), dtype=k_.dtype, device='cuda')
+        k2, v2 = kv[:, :, 0, :].permute(1, 0, 2), kv[:, :, 1, :].permute(1, 0, 2)
+        k2.copy_(k_); v2.copy_(v_)
+        return k2, v2
+    pairs = [_hm(k_, v_) for k_, v_ in zip(kb, vb)]
+    kb, vb = [p_[0] for p_ in pairs], [p_[1] for p_ in pairs]
 q = torch.randn(bs, hq, D, device='cuda').bfloat16()
 o = torch.empty_like(q)
 # prompt tokens contiguous per request, decode tokens interleaved across requests (as the allocator hands them out)
@@ -45,7 +53,7 @@ def timeit(fn, reps=12):
     return e0.elapsed_time(e1) / (3 * reps) * 1e3
 # reference
 idx = r2t[:, :ctx].long()
-K = kb[0].float()[idx]; V = vb[0].float()[idx]            # [bs, ctx, hkv, D]
+K = kb[0][idx].float(); V = vb[0][idx].float()            # [bs, ctx, hkv, D]
 qg = q.float().view(bs, hkv, hq // hkv, D)
 s = torch.einsum('bhgd,bkhd->bhgk', qg, K) * D ** -0.5
 ref = torch.einsum('bhgk,bkhd->bhgd', s.softmax(-1), V).reshape(bs, hq, D)
