@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--simulate-tp", type=int, default=0,
                     help="measurement aid (not the contract metric): run ONE rank's shard of a TP=N "
                          "configuration on one GPU with the collectives stubbed out")
+    ap.add_argument("--kv-layout", default="auto", choices=["auto", "token_major", "head_major"],
+                    help="memory layout of the multi-head KV pool (auto: head-major on the GPU for 16-bit models)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -361,7 +363,7 @@ def main():
                     max_running_requests=max(bs, 8) + 8, context_length=in_len + out_len + 16,
                     disable_cuda_graph=args.no_graph, cuda_graph_bs=[bs], tp_size=tp,
                     quantization=args.quantization, random_seed=rank if tp == 1 else 0,
-                    simulate_tp_shard=bool(sim), kv_cache_dtype=args.kv_cache_dtype,
+                    simulate_tp_shard=bool(sim), kv_cache_dtype=args.kv_cache_dtype, kv_layout=args.kv_layout,
                     disable_custom_all_reduce=args.custom_all_reduce == "off",
                     custom_all_reduce_self_test=args.custom_all_reduce == "auto",
                     # a failed graph capture (collectives inside a capture can fail on a machine this build has not

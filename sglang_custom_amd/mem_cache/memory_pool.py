@@ -62,6 +62,15 @@ class MHATokenToKVPool:
         self.layer_num = layer_num
         self.device = device
         rows = size + page_size
+        if head_major:
+            # The head stride is rows * row_bytes.  Measured on MI355X (Llama-3-8B, 64 sequences whose
+            # prompts lie 512 KiB apart in a head's region): when the 32-KiB digit of that stride is 9 or 10 (mod 16)
+            # the eight heads of a sequence meet on the same DRAM channels and decode attention loses the whole gain
+            # of the layout (step +2.5 %); every other digit measured is fine.  A few unused rows at the end of a
+            # head's region move the stride off those digits (the allocator never hands them out).
+            row_bytes = (2 if self.v_head_dim == head_dim else 1) * head_dim * torch.empty((), dtype=dtype).element_size()
+            while ((rows * row_bytes >> 15) & 15) in (9, 10):
+                rows += max(1, (1 << 15) // row_bytes)
         if head_major and self.v_head_dim == head_dim:
             # keys and values of a (head, slot) side by side: one 2 D run per token for the workgroup that streams them
             self._kv_all = torch.zeros((layer_num, head_num, rows, 2, head_dim), dtype=dtype, device=device)

@@ -80,7 +80,7 @@ def test_head_major_kv_pool_is_the_same_tensor_to_every_reader():
     pool = mr.token_to_kv_pool
     kb, vb = pool.get_kv_buffer(0)
     heads, d = kb.shape[1], kb.shape[2]
-    assert pool.head_major and kb.shape == vb.shape and kb.shape[0] == pool.size + pool.page_size
+    assert pool.head_major and kb.shape == vb.shape and kb.shape[0] >= pool.size + pool.page_size   # (a few unused rows may pad the head stride)
     assert kb.stride() == (2 * d, 2 * kb.shape[0] * d, 1) and vb.data_ptr() == kb.data_ptr() + d * kb.element_size()
     prompts = _prompts(cfg)
     ref_toks, ref_logits = OracleLlama(cfg, w, dt, max_total_tokens=512).generate_greedy(prompts, 4)
@@ -95,7 +95,8 @@ def test_head_major_kv_pool_is_the_same_tensor_to_every_reader():
     for layer in range(cfg["num_hidden_layers"]):
         k1, v1 = pool.get_kv_buffer(layer)
         k2, v2 = mr2.token_to_kv_pool.get_kv_buffer(layer)
-        assert torch.equal(k1[1:], k2[1:]) and torch.equal(v1[1:], v2[1:])
+        n = k2.shape[0]
+        assert torch.equal(k1[1:n], k2[1:]) and torch.equal(v1[1:n], v2[1:])
     assert not _build("tiny-llama-d64", "float32")[3].token_to_kv_pool.head_major     # "auto" on the CPU
     with pytest.raises(ValueError):
         _build("tiny-llama-d64", "float32", kv_layout="sideways")

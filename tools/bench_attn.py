@@ -1,6 +1,5 @@
 """Dev tool: decode attention micro-benchmark at the bench shape (bs=64, ctx~1064, 32q/8kv x128)."""
-import ctypes, sys, torch
-import os
+import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_custom_amd import ops, _lib
 _lib.use_dev_library()   # ablation switches and probes live in the development build only
@@ -12,7 +11,7 @@ if len(sys.argv) > 4: ctx = int(sys.argv[4])
 SP = int(sys.argv[5]) if len(sys.argv) > 5 else 1024   # slot spacing between sequences' prompt regions
 NL = 3
 SP = max(SP, ctx)
-slots = bs * max(1100, SP + 80) + 16
+slots = int(os.environ.get('SLOTS', bs * max(1100, SP + 80) + 16))   # SLOTS: pool rows (the head stride of the head-major layout)
 torch.manual_seed(0)
 kb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
 vb = [torch.randn(slots, hkv, D, device='cuda').bfloat16() for _ in range(NL)]
@@ -35,6 +34,7 @@ for b in range(bs):
     PL = min(ctx, max(1024, ctx - 40))   # prompt length: the last few tokens are decode tokens
     r2t[b, :PL] = torch.arange(1 + b * SP, 1 + b * SP + PL)
     if ctx > PL: r2t[b, PL:ctx] = 1 + bs * SP + torch.arange(ctx - PL, device='cuda') * bs + b
+assert int(r2t.max()) < slots, f"SLOTS={slots} is smaller than the highest slot in use ({int(r2t.max())})"   # checked on the host: never index past the pool
 rpi = torch.arange(bs, dtype=torch.int64, device='cuda')
 sl = torch.full((bs,), ctx, dtype=torch.int64, device='cuda')
 SPLIT_LIST = [int(x) for x in os.environ.get('SPLITS', '1,2,3,4').split(',')]

@@ -47,8 +47,8 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else None
     cfg = hf_config_dict("llama-3-8b", "bfloat16")
     sa = ServerArgs(dtype="bfloat16", max_total_tokens=N_REQ * (PLEN + NEW + 8) + 64, max_running_requests=N_REQ + 8,
-                    context_length=PLEN + NEW + 16, cuda_graph_bs=[8, 16, 24, 32, 40, 48, 56, 64],
-                    max_prefill_tokens=16384, schedule_conservativeness=1.5)
+                    context_length=PLEN + NEW + 16, cuda_graph_bs=[int(x) for x in os.environ.get("GRAPH_BS", "8,16,24,32,40,48,56,64").split(",")],
+                    max_prefill_tokens=int(os.environ.get("MAX_PREFILL_TOKENS", "16384")), schedule_conservativeness=1.5, kv_layout=os.environ.get("KV_LAYOUT", "auto"))
     mr = ModelRunner(ModelConfig(cfg, dtype="bfloat16", context_length=PLEN + NEW + 16), sa)
     rng = np.random.RandomState(0)
     prompts = [rng.randint(0, cfg["vocab_size"], PLEN).tolist() for _ in range(N_REQ)]
