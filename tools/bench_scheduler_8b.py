@@ -4,7 +4,7 @@ HIP-graph decode, retirement), overlap loop on.  Two arrival patterns: all reque
 and 8 requests arriving every 6 loop iterations (the running batch grows while it decodes).  Reports
 output tok/s over the whole run (prefill included), the decode-step time at full batch, and the host time
 per loop iteration that is NOT spent waiting for the device.  Writes one JSON object per pattern.
-usage: python tools/bench_scheduler_8b.py [out.json]"""
+usage: [KV_LAYOUT=auto|token_major|head_major] [MAX_PREFILL_TOKENS=16384] [GRAPH_BS=8,16,...,64] python tools/bench_scheduler_8b.py [out.json]"""
 import json
 import os
 import sys
