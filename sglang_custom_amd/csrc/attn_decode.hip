@@ -9,6 +9,7 @@
 // LPR-lane group keeps its own online-softmax state and the groups / waves are merged once
 // at the end, so the key loop has no cross-group communication and no LDS traffic.
 // No MFMA here on purpose: at G <= 8 the kernel sits on the HBM roof with VALU to spare.
+#include <cmath>
 #include "common.cuh"
 #include <math.h>
 #include <type_traits>
@@ -2686,7 +2687,12 @@ int mi355_decode_num_splits(int64_t bs, int hkv, int64_t max_seq_len, int max_sp
   const int64_t wgs = bs * hkv;
   int64_t want = wgs >= 112 ? 1 : (160 + wgs - 1) / wgs;
   if (want > 1 && wgs * want < 192 && max_seq_len / ((256 + wgs - 1) / wgs) >= 1024) want = (256 + wgs - 1) / wgs;
-  const int64_t by_len = max_seq_len / 128 > 0 ? max_seq_len / 128 : 1;
+  // A handful of workgroups (one sequence on a tensor-parallel rank): the launch is a latency chain, ~9.5 ns per key
+  // of a split plus ~0.11 us per split merged, least at sqrt(keys / 12) splits.  One sequence x one kv head x 4104
+  // keys: 22.3 / 17.6 / 16.2 / 16.2 / 16.6 / 17.5 / 21.7 us at 4 / 8 / 12 / 16 / 24 / 32 / 64 splits.
+  int64_t by_len = max_seq_len / 128 > 0 ? max_seq_len / 128 : 1;
+  const int64_t by_merge = (int64_t)std::ceil(std::sqrt((double)max_seq_len / 12.0));
+  if (by_len > by_merge) by_len = by_merge > 1 ? by_merge : 1;
   if (want > by_len) want = by_len;
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;

@@ -71,6 +71,7 @@ def test_planner_is_pure_host_logic(lib):
     assert lib.mi355_decode_num_splits(8, 8, 1100, 64) == 3
     assert lib.mi355_decode_num_splits(1, 8, 1100, 64) == 8
     assert lib.mi355_decode_num_splits(1, 8, 100000, 16) == 16
+    assert lib.mi355_decode_num_splits(1, 1, 4104, 64) == 19     # one sequence, one kv head: sqrt(keys / 12), not keys / 128
     assert lib.mi355_decode_num_splits(256, 8, 50, 64) == 1
     # o_proj at batch 64: 64 column blocks x 4 K-splits -> 4 KiB of arrival counters + fp32 partials
     assert lib.mi355_linear_workspace_bytes(64, 4096, 4096) == 4096 + 4 * 64 * 4096 * 4

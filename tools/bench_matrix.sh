@@ -12,5 +12,6 @@ run() {  # name, args...
 }
 run bench_bs1 --batch-size 1 && run bench_bs8 --batch-size 8 && run bench_bs32 --batch-size 32 && run bench_bs64 --batch-size 64 && \
 run bench_fp8_w8a8 --quantization w8a8_fp8 && run bench_fp8_kv --kv-cache-dtype fp8_e4m3 && \
+run bench_70b_tp8_shard_bs1 --model llama-3-70b --simulate-tp 8 --batch-size 1 --input-len 4096 --steps 32 --ttft-repeats 1 && \
 run bench_70b_tp8_shard_bs16 --model llama-3-70b --simulate-tp 8 --batch-size 16 --input-len 4096 --steps 32 --ttft-repeats 1 && \
 run bench_70b_tp8_shard_bs64 --model llama-3-70b --simulate-tp 8 --batch-size 64 --input-len 4096 --steps 32 --ttft-repeats 1
