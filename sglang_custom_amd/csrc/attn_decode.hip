@@ -147,11 +147,15 @@ __device__ __forceinline__ void merge_splits_if_last(const DecodeParams& p, T* _
       di[t] = 4 * (item - gi[t] * per_head);
     }
   };
+  // (up to four splits -- the plans of full batches -- go out as a round of four: the clamped loads of a wider
+  // round are real requests to memory)
+  const bool narrow = S <= 4;
   auto load_round = [&](int s0) {
 #pragma unroll
     for (int t = 0; t < IT; ++t)
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
+        if (narrow && u >= 4) continue;   // (wave-uniform)
         const int sp = s0 + u < S ? s0 + u : S - 1;
         v[t][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, ((gi[t] * S + sp) * Dv + di[t]) * 4, 0, 16));
       }
@@ -180,6 +184,7 @@ __device__ __forceinline__ void merge_splits_if_last(const DecodeParams& p, T* _
       for (int t = 0; t < IT; ++t)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+          if (narrow && u >= 4) continue;   // (never loaded)
           if (s0 + u < S) {
             const float ws = w[gi[t] * S + s0 + u];
 #pragma unroll
