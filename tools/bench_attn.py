@@ -2,7 +2,7 @@
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_custom_amd import ops, _lib
-_lib.use_dev_library()   # ablation switches and probes live in the development build only
+_lib.use_dev_library(os.environ.get('MI355_AB_LIB'))   # MI355_AB_LIB: a development build of another source tree; ablation switches and probes live in the development build only
 lib = _lib.load()
 lib.mi355_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
 bs, ctx, hq, hkv, D = 64, 1064, 32, 8, 128
