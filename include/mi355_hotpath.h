@@ -39,7 +39,9 @@ extern "C" {
 /* OR into the `dtype` argument of the attention / KV-write entry points that document it: the KV
  * cache buffers hold OCP e4m3fn bytes (kv_cache_dtype fp8_e4m3, mem_cache/memory_pool.py:118-122,
  * 436-446) while q / k / v / o keep the 16-bit dtype in the low byte.  Values are stored as
- * clamp(x, +-448) rounded to nearest even and read back by exact widening. */
+ * clamp(x, +-448) rounded to nearest even and read back by exact widening.  head_dim 128 (16-bit q, causal or
+ * full mask) runs on the matrix-core kernels; any other head dim, a sliding window, a logit cap or a custom mask
+ * on the wave-per-head decode kernel and the vector-ALU prefill kernel (same values, slower). */
 #define MI355_KV_FP8 0x100
 /* OR into the same `dtype` argument: k_buffer / v_buffer are laid out [Hkv, num_slots, D] (head-major: the rows
  * one kv head's workgroup streams are adjacent in memory) instead of [num_slots, Hkv, D].  The same slots, heads

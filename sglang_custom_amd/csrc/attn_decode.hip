@@ -1152,7 +1152,8 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
                                                                  const T* __restrict__ kbuf,
                                                                  const T* __restrict__ vbuf,
                                                                  T* __restrict__ o, DecodeParams p,
-                                                                 int D, int Dv) {
+                                                                 int D, int Dv, int kv8 = 0) {
+  // kv8: the cache holds e4m3fn bytes behind the T pointers (strides count bytes); widened exactly on load
   const int head = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x;
   const int kvh = head / (p.hq / p.hkv);
@@ -1168,10 +1169,15 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
   float m = -INFINITY, l = 0.f;
   for (int64_t key = k0; key < k1; ++key) {
     const int64_t slot = p.page_table[page_off + key];
-    const T* kr = kbuf + slot * p.k_slot_stride + (int64_t)kvh * p.k_head_stride;
-    const T* vr = vbuf + slot * p.v_slot_stride + (int64_t)kvh * p.v_head_stride;
+    const int64_t koff = slot * p.k_slot_stride + (int64_t)kvh * p.k_head_stride;
+    const int64_t voff = slot * p.v_slot_stride + (int64_t)kvh * p.v_head_stride;
+    const T* kr = kbuf + koff;
+    const T* vr = vbuf + voff;
+    const uint8_t* kr8 = reinterpret_cast<const uint8_t*>(kbuf) + koff;
+    const uint8_t* vr8 = reinterpret_cast<const uint8_t*>(vbuf) + voff;
     float d = 0.f;
-    for (int i = lane; i < D; i += 64) d = fmaf(to_f32(qh[i]), to_f32(kr[i]), d);
+    for (int i = lane; i < D; i += 64)
+      d = fmaf(to_f32(qh[i]), kv8 ? __builtin_amdgcn_cvt_f32_fp8((int)kr8[i], 0) : to_f32(kr[i]), d);
     d = wave_sum(d) * p.sm_scale;
     if (p.logit_cap > 0.f) d = p.logit_cap * tanhf(d / p.logit_cap);
     d *= kLog2e;
@@ -1182,7 +1188,7 @@ __global__ __launch_bounds__(64) void decode_attn_generic_kernel(const T* __rest
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int dd = lane + 64 * i;
-      if (dd < Dv) acc[i] = acc[i] * alpha + pe * to_f32(vr[dd]);
+      if (dd < Dv) acc[i] = acc[i] * alpha + pe * (kv8 ? __builtin_amdgcn_cvt_f32_fp8((int)vr8[dd], 0) : to_f32(vr[dd]));
     }
   }
 #pragma unroll
@@ -2614,11 +2620,16 @@ static int launch_decode(const void* q_, const void* kb_, const void* vb_, void*
   if (!(vec && D == 128 && !std::is_same<T, float>::value && (kv8 || g_decode_variant == 0) &&
         p.num_splits > 1 && p.num_splits <= MERGE_MAX_SPLITS))
     p.tickets = nullptr;
-  if (kv8 && !(vec && D == 128 && !std::is_same<T, float>::value)) {
-    set_error("decode_attention: an fp8 KV cache needs head_dim 128, a 16-bit dtype and 16-B aligned pointers");
+  // an fp8 cache outside the matrix-core kernel's shape (head_dim 128, 16-bit, aligned): the wave-per-head kernel
+  const bool kv8_generic = kv8 && !(vec && D == 128 && !std::is_same<T, float>::value);
+  if (kv8_generic && (D > 1024 || Dv > 1024)) {
+    set_error("decode_attention: head_dim %d / v_head_dim %d > 1024 unsupported", D, Dv);
     return MI355_ERR_UNSUPPORTED;
   }
-  if (vec && D == 64) launch_decode_d<T, 64, 4>(q, kb, vb, o, p, bs, kv8, st);
+  if (kv8_generic) {
+    hipLaunchKernelGGL((decode_attn_generic_kernel<T>), dim3((unsigned)p.hq, (unsigned)p.num_splits, (unsigned)bs),
+                       dim3(64), 0, st, q, kb, vb, o, p, D, Dv, 1);
+  } else if (vec && D == 64) launch_decode_d<T, 64, 4>(q, kb, vb, o, p, bs, kv8, st);
   else if (vec && D == 128) launch_decode_d<T, 128, 4>(q, kb, vb, o, p, bs, kv8, st);
   else if (vec && D == 256 && D / VE <= 64) launch_decode_d<T, 256, 2>(q, kb, vb, o, p, bs, kv8, st);
   else {

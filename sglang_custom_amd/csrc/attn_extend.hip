@@ -28,6 +28,7 @@ struct ExtendParams {
   float sm_scale, logit_cap;
   // the cache buffers: elements between consecutive slots / consecutive kv heads ([slots, hkv, d] or head-major)
   int64_t kb_slot, kb_head, vb_slot, vb_head;
+  int kv8;   // the cache holds e4m3fn bytes behind the element pointers (strides count bytes); read by the VALU kernel
 };
 
 // DP: padded head dim (>= D, Dv; multiple of 64). BN: keys per tile. VEC: 16-B global loads.
@@ -138,6 +139,16 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const T* __restrict
             ksrc = k_ext + (int64_t)(q_start + key) * p.k_stride + (int64_t)kvh * D;
             vsrc = v_ext + (int64_t)(q_start + key) * p.v_stride + (int64_t)kvh * Dv;
           }
+          if (phase == 0 && p.kv8) {   // e4m3fn prefix rows, widened exactly
+            const int64_t slot = p.kv_indices[kv_start + key];
+            const uint8_t* k8 = reinterpret_cast<const uint8_t*>(kbuf) + slot * p.kb_slot + kvh * p.kb_head;
+            const uint8_t* v8 = reinterpret_cast<const uint8_t*>(vbuf) + slot * p.vb_slot + kvh * p.vb_head;
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+              if (c + j < D) kval.v[j] = from_f32<T>(__builtin_amdgcn_cvt_f32_fp8((int)k8[c + j], 0));
+              if (c + j < Dv) vval.v[j] = from_f32<T>(__builtin_amdgcn_cvt_f32_fp8((int)v8[c + j], 0));
+            }
+          } else {
           if (VEC && c + VE <= D) {
             kval = ldvec<T, VE>(ksrc + c);
           } else {
@@ -151,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const T* __restrict
 #pragma unroll
             for (int j = 0; j < VE; ++j)
               if (c + j < Dv) vval.v[j] = vsrc[c + j];
+          }
           }
         }
         stvec<T, VE>(ks + kr * LROW + c, kval);
@@ -895,11 +907,6 @@ static int launch_extend(const void* q, const void* k, const void* v, void* o, c
       return MI355_OK;
     }
   }
-  if (kv8) {
-    set_error("extend_attention: an fp8 KV cache needs head_dim 128, a 16-bit dtype, a causal or full mask, "
-              "no sliding window and no logit cap");
-    return MI355_ERR_UNSUPPORTED;
-  }
   if (dmax <= 64) return launch_extend_cfg<T, 64, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
   if (dmax <= 128) return launch_extend_cfg<T, 128, 64>(q, k, v, o, kb, vb, p, bs, max_len_extend, vec, st);
   if (dmax <= 256) {
@@ -969,6 +976,7 @@ int mi355_extend_attention(const void* q_extend, const void* k_extend, const voi
   kv_strides(dtype, num_slots, hkv, v_head_dim, p.vb_slot, p.vb_head);
   int rc = MI355_OK;
   const bool kv8 = (dtype & MI355_KV_FP8) != 0;
+  p.kv8 = kv8 ? 1 : 0;
   dtype &= 0xff;
   MI355_DISPATCH_DTYPE(dtype, "extend_attention",
                        rc = launch_extend<T>(q_extend, k_extend, v_extend, o_extend, k_buffer,

@@ -393,11 +393,13 @@ def test_decode_fusion_is_bit_identical_end_to_end(graphs, quant, kvd):
     assert torch.equal(u8(outs[0][2]), u8(outs[1][2])) and torch.equal(u8(outs[0][3]), u8(outs[1][3]))
 
 
-def test_fp8_kv_cache_end_to_end_close_to_16bit_cache():
+@pytest.mark.parametrize("head", ["d128", "d64"])
+def test_fp8_kv_cache_end_to_end_close_to_16bit_cache(head):
     """kv_cache_dtype fp8_e4m3 on the bf16 model (prefill, chunk-free, then decode under graphs): the
     cache holds e4m3 bytes, logits stay within fp8 rounding of the 16-bit-cache run and the greedy
-    tokens agree wherever the top-2 margin is decisive."""
-    name, preset, dtn, lens, steps = [c for c in cases.E2E_CASES if c[2] == "bf16" and "d128" in c[1]][0]
+    tokens agree wherever the top-2 margin is decisive.  d64: a head dim the matrix-core kernels do not
+    serve (Llama-3.2-1B's) -- the cache is read by the wave-per-head decode kernel and the VALU prefill kernel."""
+    name, preset, dtn, lens, steps = [c for c in cases.E2E_CASES if c[2] == "bf16" and head in c[1]][0]
     runs = {}
     for kvd in ("auto", "fp8_e4m3"):
         mr, cfg, _ = make_runner(preset, dtn, True, kv_cache_dtype=kvd)

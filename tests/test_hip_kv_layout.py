@@ -144,8 +144,6 @@ def test_rope_launch_that_writes_a_head_major_cache(ops, dtype, neox, rot, layou
     (32, 8, 128, 9, 300, 1, False), (32, 8, 128, 9, 300, 4, True), (16, 2, 128, 6, 530, 3, False), (8, 8, 128, 5, 70, 2, True),
     (8, 1, 128, 19, 90, 1, False), (8, 4, 64, 7, 200, 2, False), (4, 2, 256, 3, 150, 1, False), (6, 3, 80, 4, 100, 2, False)])
 def test_decode_attention_over_a_head_major_cache(ops, dtype, kv8, hq, hkv, d, bs, maxlen, splits, tickets, layout):
-    if kv8 and d != 128:
-        pytest.skip("an fp8 cache is served at head_dim 128 only")
     lens, r2t, rpi, kb, vb, slots = paged_world(bs, maxlen, hkv, d, dtype, seed=hq + d + bs, kv8=kv8)
     kh, vh = relayout(kb, vb, layout)
     q = torch.randn(bs, hq, d, device=DEV, dtype=dtype)
@@ -232,8 +230,6 @@ def test_decode_launch_from_qkv_partials_over_a_head_major_cache(ops, dtype, cac
 @pytest.mark.parametrize("kv8", [False, True], ids=["cache16", "cache_fp8"])
 @pytest.mark.parametrize("hq,hkv,d", [(8, 2, 128), (4, 4, 128), (6, 3, 64)])
 def test_prefill_attention_over_a_cached_prefix_in_a_head_major_cache(ops, dtype, kv8, hq, hkv, d, layout):
-    if kv8 and d != 128:
-        pytest.skip("an fp8 cache is served at head_dim 128 only")
     g = torch.Generator().manual_seed(hq * 7 + d)
     prefix = [0, 70, 300, 129]
     ext = [200, 64, 1, 130]

@@ -842,6 +842,68 @@ def test_fp8_kv_cache_write_decode_extend_and_fused(ops, dtn):
     assert torch.equal(o, o_ref)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+@pytest.mark.parametrize("Hq,Hkv,D,window,cap", [(8, 2, 64, -1, 0.0), (4, 2, 256, -1, 0.0), (6, 3, 80, -1, 0.0),
+                                                 (8, 2, 128, 24, 0.0), (8, 2, 128, -1, 30.0)])
+def test_fp8_kv_cache_outside_the_matrix_core_shapes(ops, dtn, Hq, Hkv, D, window, cap):
+    """An fp8 cache at head dims other than 128 (Llama-3.2-1B has 64), or under a sliding window / logit cap:
+    the write is torch's cast, decode agrees with the oracle on the widened values (bit for bit with the 16-bit
+    cache where one kernel serves both), prefix-extend attention equals the same call over a 16-bit cache holding
+    the widened values bit for bit (the reference's pool stores fp8 for any model, memory_pool.py:436-446)."""
+    dt = DT[dtn]
+    torch.manual_seed(D + Hq)
+    lens = [70, 1, 33, 129, 16]
+    B, total = len(lens), sum(lens)
+    slots = total + 5
+    k = torch.randn(total, Hkv, D, device=DEV, dtype=dt) * 3
+    v = torch.randn(total, Hkv, D, device=DEV, dtype=dt) * 3
+    loc = (torch.randperm(slots - 1, device=DEV)[:total] + 1)
+    kb8 = torch.zeros(slots, Hkv, D, device=DEV, dtype=torch.float8_e4m3fn)
+    vb8 = torch.zeros_like(kb8)
+    ops.set_kv_buffer(kb8, vb8, loc, k, v)
+    assert torch.equal(kb8[loc].view(torch.uint8), k.float().clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+    kbw, vbw = kb8.to(dt), vb8.to(dt)
+    r2t = torch.zeros(B, max(lens), dtype=torch.int32, device=DEV)
+    off = 0
+    for b, n in enumerate(lens):
+        r2t[b, :n] = loc[off:off + n].int()
+        off += n
+    rpi = torch.arange(B, device=DEV)
+    sl = torch.tensor(lens, device=DEV, dtype=torch.int64)
+    q = torch.randn(B, Hq, D, device=DEV, dtype=dt)
+    for splits in (1, 3):
+        lg = torch.empty(B, Hq, splits, D, dtype=torch.float32, device=DEV)
+        ls = torch.empty(B, Hq, splits, dtype=torch.float32, device=DEV)
+        o8, ow = torch.empty_like(q), torch.empty_like(q)
+        ops.decode_attention_paged(q, kb8, vb8, o8, r2t, rpi, sl, lg, ls, splits, D ** -0.5, logit_cap=cap)
+        ops.decode_attention_paged(q, kbw, vbw, ow, r2t, rpi, sl, lg, ls, splits, D ** -0.5, logit_cap=cap)
+        if D == 128:    # the same kernel serves both caches: same bits
+            assert torch.equal(o8, ow), splits
+        else:           # the fp8 cache goes through the wave-per-head kernel, the 16-bit one through the vector kernel
+            assert (o8.float() - ow.float()).abs().max().item() <= 2e-2 * max(1.0, ow.float().abs().max().item()), splits
+        ref = ops_ref.decode_attention(q.cpu().float(), kbw.cpu().float(), vbw.cpu().float(), r2t.cpu(), rpi.cpu(), sl.cpu(),
+                                       D ** -0.5, Hq != Hkv) if cap == 0.0 else None
+        if ref is not None:
+            assert (o8.cpu().float() - ref).abs().max().item() < 6e-2
+    ext = [min(n, 9) for n in lens]
+    pre = [n - e for n, e in zip(lens, ext)]
+    rows = [torch.arange(sum(lens[:b]) + pre[b], sum(lens[:b]) + lens[b], device=DEV) for b in range(B)]
+    qe = torch.randn(sum(ext), Hq, D, device=DEV, dtype=dt)
+    ke, ve = kbw[loc][torch.cat(rows)].contiguous(), vbw[loc][torch.cat(rows)].contiguous()
+    qo = torch.tensor([0] + list(np.cumsum(ext)), dtype=torch.int32, device=DEV)
+    kvp = torch.tensor([0] + list(np.cumsum(pre)), dtype=torch.int32, device=DEV)
+    kvi = torch.cat([r2t[b, :pre[b]] for b in range(B)] + [torch.zeros(1, dtype=torch.int32, device=DEV)])
+    oe8, oew = torch.empty_like(qe), torch.empty_like(qe)
+    ops.extend_attention_fwd(qe, ke, ve, oe8, kb8, vb8, qo, kvp, kvi, None, True, None, max(ext), D ** -0.5, cap,
+                             sliding_window_size=window)
+    ops.extend_attention_fwd(qe, ke, ve, oew, kbw, vbw, qo, kvp, kvi, None, True, None, max(ext), D ** -0.5, cap,
+                             sliding_window_size=window)
+    torch.cuda.synchronize()
+    assert torch.equal(oe8, oew)
+    assert oe8.float().abs().max().item() > 0
+
+
 def _extend_kernel_case(ops, dt, Hq, Hkv, D, pre, ext, window, cap, seed, tol):
     """mi355_extend_attention with the prefix lists a sliding-window layer hands it, against the
     float64 statement of the reference kernel's masking rules."""
