@@ -104,7 +104,7 @@ def test_head_major_kv_pool_is_the_same_tensor_to_every_reader():
 
 def _tp_worker(rank, world, port, q):
     try:
-        torch.set_num_threads(2)
+        torch.set_num_threads(2 if world <= 2 else 1)
         cfg, w, dt, mr = _build("tiny-llama-d64", "float32", rank, world, f"tcp://127.0.0.1:{port}")
         toks, lg, _ = _run(mr, _prompts(cfg), 3)
         # sharding facts of this rank (linear.py:724-794, 1119-1303)
@@ -128,7 +128,10 @@ def _tp_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_tensor_parallel_world2_gloo_matches_oracle():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_tensor_parallel_gloo_matches_oracle(world):
+    """8 query heads over 2 kv heads: at 4 and 8 ranks a kv head is replicated (rank r owns kv head r // replicas,
+    layers/linear.py:778-783 of the reference) and at 8 ranks every rank holds one query head."""
     from oracle.llama_ref import OracleLlama
     from sglang_custom_amd.model_loader.synthetic import hf_config_dict, make_synthetic_llama_weights
 
@@ -137,7 +140,7 @@ def test_tensor_parallel_world2_gloo_matches_oracle():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -153,10 +156,10 @@ def test_tensor_parallel_world2_gloo_matches_oracle():
         assert torch.equal(torch.from_numpy(toks), ref_toks), f"rank {rank}"
         assert (torch.from_numpy(lg) - torch.stack(ref_logits)).abs().max() < 1e-4
         hidden = cfg["hidden_size"]
-        assert shapes["qkv"] == ((hq // 2 + 2 * max(1, hkv // 2)) * d, hidden)
-        assert shapes["o"] == (hidden, hq // 2 * d)
-        assert shapes["kv"] == (max(1, hkv // 2), d)
-        assert shapes["head"][0] == cfg["vocab_size"] // 2
+        assert shapes["qkv"] == ((hq // world + 2 * max(1, hkv // world)) * d, hidden)
+        assert shapes["o"] == (hidden, hq // world * d)
+        assert shapes["kv"] == (max(1, hkv // world), d)
+        assert shapes["head"][0] == cfg["vocab_size"] // world
 
 
 def _tp_worker_deepseek(rank, world, port, preset, q):
